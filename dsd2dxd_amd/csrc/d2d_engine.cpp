@@ -1,0 +1,516 @@
+// d2d_engine.cpp -- host side of the engine and the C ABI of include/dsd2dxd_amd.h.
+//
+// One Engine is what the reference calls an Rdsd2Pcm (one per file, /root/reference/src/main.rs:
+// 325-342,361-394), widened to `n_files` files so that the Rayon par_iter over files
+// (src/main.rs:280-300) becomes a grid dimension of one launch.  The engine owns, in HBM:
+//   * the filter tables (nibble LUTs or int8 MFMA fragments; stage-B coefficients)
+//   * per (file, channel): `keep` history bytes (ping-pong), the running peak, and for the 48k
+//     cascade an f64 scratch line [P carried | stage-A outputs of this call]
+// No CPU fallback exists: without a HIP device d2d_create fails with D2D_ERR_DEVICE.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <string.h>
+
+#include <algorithm>
+#include <string>
+#include <vector>
+
+#include "../../include/dsd2dxd_amd.h"
+#include "d2d_filters.h"
+#include "d2d_internal.h"
+#include "d2d_launch.h"
+#include "d2d_mfma.h"
+
+using namespace d2d;
+
+namespace {
+
+thread_local std::string g_create_error;
+
+struct FileState {
+    uint64_t pos = 0;    // bytes per channel consumed
+    uint64_t nfir = 0;   // FIR outputs produced
+    uint64_t nres = 0;   // stage-B outputs produced (48k family)
+};
+
+constexpr int JOB_SLOTS = 8;
+
+}  // namespace
+
+struct d2d_engine {
+    d2d_params p{};
+    uint32_t n_files = 1;
+    FilterChoice fc;
+    int M = 0, Mb = 0, N = 0, Wb = 0, S = 0;
+    uint32_t B = 1, keep = 0, C = 0, nstreams = 0;
+    uint32_t kernel = D2D_KERNEL_LUT;
+    LutLayout lut{};
+    MfmaLayout mfma{};
+    Epilogue epi{};
+    std::string err;
+    std::vector<FileState> files;
+
+    // device
+    void* d_fir_tables = nullptr; size_t fir_table_bytes = 0;
+    double* d_resamp = nullptr;   size_t resamp_bytes = 0;
+    uint8_t* d_hist[2] = {nullptr, nullptr}; int hist_cur = 0;
+    double* d_peak = nullptr;
+    double* d_scratch = nullptr; size_t scratch_stride = 0;   // doubles per stream
+    StreamJob* d_jobs = nullptr;
+    StreamJob* h_jobs = nullptr;          // pinned, JOB_SLOTS x nstreams
+    hipEvent_t job_ev[JOB_SLOTS]{}; bool job_ev_used[JOB_SLOTS]{}; int job_slot = 0;
+    hipStream_t own_stream = nullptr;     // used by the host-pointer entry points
+    hipStream_t last_stream = nullptr;
+    // staging for d2d_translate (host pointers)
+    uint8_t* d_in = nullptr; size_t d_in_cap = 0;
+    uint8_t* d_out = nullptr; size_t d_out_cap = 0;
+
+    int fail(int code, const std::string& m) { err = m; return code; }
+    int hip_fail(hipError_t e, const char* what) {
+        err = std::string(what) + ": " + hipGetErrorString(e);
+        return D2D_ERR_DEVICE;
+    }
+};
+
+#define HIPCHK(e_, call)                                                  \
+    do {                                                                  \
+        hipError_t _r = (call);                                           \
+        if (_r != hipSuccess) return (e_)->hip_fail(_r, #call);           \
+    } while (0)
+
+static uint64_t res_outputs_after(const d2d_engine* e, uint64_t nx) {
+    if (!e->fc.resamp) return nx;
+    if (nx == 0) return 0;
+    return (nx * (uint64_t)e->fc.resamp->L - 1) / (uint64_t)e->fc.resamp->Mdn + 1;
+}
+
+static size_t sample_bytes_of(uint32_t bits) { return bits == 16 ? 2 : (bits == 32 ? 4 : 3); }
+
+static int validate(const d2d_params& p, std::string& err) {
+    if (p.channels < 1 || p.channels > 64) { err = "Invalid channel count"; return D2D_ERR_PARAM; }
+    if (p.bit_depth != 16 && p.bit_depth != 20 && p.bit_depth != 24 && p.bit_depth != 32) {
+        err = "Invalid bit depth; must be 16, 20, 24 or 32"; return D2D_ERR_PARAM;
+    }
+    if (p.dither != 'T' && p.dither != 'R' && p.dither != 'F' && p.dither != 'X') {
+        err = "Invalid dither type; must be T, R, F, or X"; return D2D_ERR_PARAM;   // src/main.rs:176-180
+    }
+    if (p.fmt != D2D_FMT_INTERLEAVED && p.fmt != D2D_FMT_PLANAR) {
+        err = "Invalid format; must be I (interleaved) or P (planar)"; return D2D_ERR_PARAM;  // src/main.rs:187-190
+    }
+    if (p.endianness != D2D_LSB_FIRST && p.endianness != D2D_MSB_FIRST) { err = "Invalid endianness"; return D2D_ERR_PARAM; }
+    if (p.fmt == D2D_FMT_PLANAR && p.block_size == 0) { err = "Invalid block size"; return D2D_ERR_PARAM; }
+    if (p.kernel > D2D_KERNEL_MFMA) { err = "Invalid kernel selector"; return D2D_ERR_PARAM; }
+    if (!isfinite(p.level_db)) { err = "Invalid level"; return D2D_ERR_PARAM; }
+    return D2D_OK;
+}
+
+static void free_device(d2d_engine* e) {
+    if (e->d_fir_tables) hipFree(e->d_fir_tables);
+    if (e->d_resamp) hipFree(e->d_resamp);
+    if (e->d_hist[0]) hipFree(e->d_hist[0]);
+    if (e->d_hist[1]) hipFree(e->d_hist[1]);
+    if (e->d_peak) hipFree(e->d_peak);
+    if (e->d_scratch) hipFree(e->d_scratch);
+    if (e->d_jobs) hipFree(e->d_jobs);
+    if (e->h_jobs) hipHostFree(e->h_jobs);
+    if (e->d_in) hipFree(e->d_in);
+    if (e->d_out) hipFree(e->d_out);
+    for (int i = 0; i < JOB_SLOTS; ++i)
+        if (e->job_ev[i]) hipEventDestroy(e->job_ev[i]);
+    if (e->own_stream) hipStreamDestroy(e->own_stream);
+}
+
+static int reset_state(d2d_engine* e) {
+    HIPCHK(e, hipSetDevice(e->p.device));
+    const size_t hbytes = (size_t)e->nstreams * e->keep;
+    const uint8_t idle = e->p.endianness == D2D_MSB_FIRST ? IDLE_BYTE : (uint8_t)0x96;  // 0x69 bit-reversed
+    HIPCHK(e, hipMemset(e->d_hist[0], idle, hbytes));
+    HIPCHK(e, hipMemset(e->d_hist[1], idle, hbytes));
+    HIPCHK(e, hipMemset(e->d_peak, 0, sizeof(double) * e->nstreams));
+    if (e->d_scratch) HIPCHK(e, hipMemset(e->d_scratch, 0, sizeof(double) * e->scratch_stride * e->nstreams));
+    for (auto& f : e->files) f = FileState{};
+    e->hist_cur = 0;
+    return D2D_OK;
+}
+
+extern "C" {
+
+const char* d2d_create_error(void) { return g_create_error.c_str(); }
+
+int d2d_create(const d2d_params* params, uint32_t n_files, d2d_engine** out) {
+    if (out) *out = nullptr;
+    if (!params || !out) { g_create_error = "null argument"; return D2D_ERR_PARAM; }
+    if (params->struct_size != sizeof(d2d_params)) { g_create_error = "d2d_params.struct_size mismatch"; return D2D_ERR_PARAM; }
+    if (n_files < 1 || n_files > 65535) { g_create_error = "Invalid file count"; return D2D_ERR_PARAM; }
+    d2d_engine* e = new d2d_engine();
+    e->p = *params;
+    e->n_files = n_files;
+    int rc = validate(e->p, g_create_error);
+    if (rc == D2D_OK) rc = choose_filters(e->p, e->fc, g_create_error);
+    if (rc != D2D_OK) { delete e; return rc; }
+    const d2d_filter_def& f = *e->fc.fir;
+    e->M = f.M; e->Mb = f.M / 8; e->N = f.ntaps; e->Wb = f.ntaps / 8; e->S = f.S;
+    e->C = e->p.channels;
+    e->B = e->p.fmt == D2D_FMT_INTERLEAVED ? 1u : e->p.block_size;   // README.md:9
+    e->nstreams = n_files * e->C;
+    e->files.resize(n_files);
+    e->epi.gain = pow(10.0, e->p.level_db / 20.0);
+    e->epi.scale = e->p.bit_depth == 32 ? e->epi.gain : ldexp(e->epi.gain, (int)e->p.bit_depth - 1);
+    e->epi.seed = e->p.seed;
+    e->epi.bits = e->p.bit_depth;
+    e->epi.dither = e->p.dither;
+    e->epi.sample_bytes = (uint32_t)sample_bytes_of(e->p.bit_depth);
+    e->epi.channels = e->C;
+    e->lut = lut_layout(e->Mb, e->Wb);
+    e->mfma = mfma_layout(e->M, e->N);
+    e->kernel = e->p.kernel == D2D_KERNEL_AUTO ? (mfma_supported(e->M, e->N) ? D2D_KERNEL_MFMA : D2D_KERNEL_LUT) : e->p.kernel;
+    if (e->kernel == D2D_KERNEL_MFMA && !mfma_supported(e->M, e->N)) {
+        g_create_error = "MFMA kernel does not support this decimation"; delete e; return D2D_ERR_PARAM;
+    }
+    e->keep = (uint32_t)std::max(e->Wb + e->Mb, (int)mfma_keep_bytes(e->mfma, e->Mb));
+    e->keep = (e->keep + 15u) & ~15u;
+
+    // ---- device side: fail loudly when there is no GPU ----
+    int ndev = 0;
+    hipError_t he = hipGetDeviceCount(&ndev);
+    if (he != hipSuccess || ndev <= 0) {
+        g_create_error = std::string("no HIP device available (") + (he != hipSuccess ? hipGetErrorString(he) : "device count 0") +
+                         "); this engine has no CPU path";
+        delete e; return D2D_ERR_DEVICE;
+    }
+    if (e->p.device < 0 || e->p.device >= ndev) { g_create_error = "Invalid device ordinal"; delete e; return D2D_ERR_DEVICE; }
+    auto bail = [&](hipError_t r, const char* what) {
+        g_create_error = std::string(what) + ": " + hipGetErrorString(r);
+        free_device(e); delete e; return D2D_ERR_DEVICE;
+    };
+#define CK(call) do { hipError_t _r = (call); if (_r != hipSuccess) return bail(_r, #call); } while (0)
+    CK(hipSetDevice(e->p.device));
+    CK(hipStreamCreateWithFlags(&e->own_stream, hipStreamNonBlocking));
+    const bool msb = e->p.endianness == D2D_MSB_FIRST;
+    if (e->kernel == D2D_KERNEL_LUT) {
+        std::vector<double> t = build_lut_tables(f, e->Mb, msb);
+        e->fir_table_bytes = t.size() * sizeof(double);
+        CK(hipMalloc(&e->d_fir_tables, e->fir_table_bytes));
+        CK(hipMemcpy(e->d_fir_tables, t.data(), e->fir_table_bytes, hipMemcpyHostToDevice));
+    } else {
+        std::vector<int8_t> t = build_mfma_tables(f, e->mfma, msb);
+        e->fir_table_bytes = t.size();
+        CK(hipMalloc(&e->d_fir_tables, e->fir_table_bytes));
+        CK(hipMemcpy(e->d_fir_tables, t.data(), e->fir_table_bytes, hipMemcpyHostToDevice));
+    }
+    if (e->fc.resamp) {
+        e->resamp_bytes = sizeof(double) * (size_t)e->fc.resamp->L * e->fc.resamp->P;
+        CK(hipMalloc((void**)&e->d_resamp, e->resamp_bytes));
+        CK(hipMemcpy(e->d_resamp, e->fc.resamp->coef, e->resamp_bytes, hipMemcpyHostToDevice));
+        e->scratch_stride = (size_t)e->fc.resamp->P + 4096;
+        CK(hipMalloc((void**)&e->d_scratch, sizeof(double) * e->scratch_stride * e->nstreams));
+    }
+    const size_t hbytes = (size_t)e->nstreams * e->keep;
+    CK(hipMalloc((void**)&e->d_hist[0], hbytes));
+    CK(hipMalloc((void**)&e->d_hist[1], hbytes));
+    CK(hipMalloc((void**)&e->d_peak, sizeof(double) * e->nstreams));
+    CK(hipMalloc((void**)&e->d_jobs, sizeof(StreamJob) * e->nstreams));
+    CK(hipHostMalloc((void**)&e->h_jobs, sizeof(StreamJob) * e->nstreams * JOB_SLOTS, hipHostMallocDefault));
+    for (int i = 0; i < JOB_SLOTS; ++i) CK(hipEventCreateWithFlags(&e->job_ev[i], hipEventDisableTiming));
+#undef CK
+    rc = reset_state(e);
+    if (rc != D2D_OK) { g_create_error = e->err; free_device(e); delete e; return rc; }
+    *out = e;
+    return D2D_OK;
+}
+
+void d2d_destroy(d2d_engine* e) {
+    if (!e) return;
+    hipSetDevice(e->p.device);
+    hipDeviceSynchronize();
+    free_device(e);
+    delete e;
+}
+
+int d2d_reset(d2d_engine* e) {
+    if (!e) return D2D_ERR_PARAM;
+    hipSetDevice(e->p.device);
+    hipDeviceSynchronize();
+    return reset_state(e);
+}
+
+const char* d2d_last_error(const d2d_engine* e) { return e ? e->err.c_str() : "null engine"; }
+
+size_t d2d_frame_bytes(const d2d_engine* e) { return e ? (size_t)e->epi.sample_bytes * e->C : 0; }
+
+size_t d2d_next_frames(const d2d_engine* e, uint32_t file, size_t L) {
+    if (!e || file >= e->n_files) return 0;
+    const FileState& f = e->files[file];
+    uint64_t nfir1 = (f.pos + L) / (uint64_t)e->Mb;
+    return e->fc.resamp ? (size_t)(res_outputs_after(e, nfir1) - f.nres) : (size_t)(nfir1 - f.nfir);
+}
+
+static int grow_scratch(d2d_engine* e, size_t need_stride, hipStream_t s) {
+    if (need_stride <= e->scratch_stride) return D2D_OK;
+    size_t ns = std::max(need_stride, e->scratch_stride * 2);
+    double* nb = nullptr;
+    HIPCHK(e, hipMalloc((void**)&nb, sizeof(double) * ns * e->nstreams));
+    const size_t P = (size_t)e->fc.resamp->P;
+    HIPCHK(e, hipMemcpy2DAsync(nb, ns * sizeof(double), e->d_scratch, e->scratch_stride * sizeof(double),
+                               P * sizeof(double), e->nstreams, hipMemcpyDeviceToDevice, s));
+    HIPCHK(e, hipStreamSynchronize(s));
+    HIPCHK(e, hipFree(e->d_scratch));
+    e->d_scratch = nb; e->scratch_stride = ns;
+    return D2D_OK;
+}
+
+int d2d_translate_batch_device(d2d_engine* e, d2d_file_io* io, uint32_t n_files, void* hip_stream) {
+    if (!e) return D2D_ERR_PARAM;
+    if (!io || n_files != e->n_files) return e->fail(D2D_ERR_PARAM, "file count does not match the engine");
+    hipStream_t s = (hipStream_t)hip_stream;
+    HIPCHK(e, hipSetDevice(e->p.device));
+    const size_t fb = d2d_frame_bytes(e);
+    const uint32_t C = e->C;
+    // plan
+    uint32_t max_nx = 0, max_frames = 0;
+    std::vector<uint64_t> nfir1(n_files), nres1(n_files);
+    for (uint32_t f = 0; f < n_files; ++f) {
+        const FileState& st = e->files[f];
+        const size_t L = io[f].bytes_per_channel;
+        if (L >= (1ull << 31)) return e->fail(D2D_ERR_PARAM, "bytes_per_channel must be below 2 GiB per call");
+        if (L && (!io[f].dsd || ((uintptr_t)io[f].dsd & 15))) return e->fail(D2D_ERR_PARAM, "dsd device pointer must be non-null and 16-byte aligned");
+        nfir1[f] = (st.pos + L) / (uint64_t)e->Mb;
+        nres1[f] = res_outputs_after(e, nfir1[f]);
+        const uint64_t nx = nfir1[f] - st.nfir;
+        const uint64_t frames = e->fc.resamp ? nres1[f] - st.nres : nx;
+        if (frames * fb > io[f].pcm_capacity_bytes) return e->fail(D2D_ERR_CAPACITY, "pcm buffer too small");
+        if (frames && (!io[f].pcm || ((uintptr_t)io[f].pcm & 15))) return e->fail(D2D_ERR_PARAM, "pcm device pointer must be non-null and 16-byte aligned");
+        max_nx = std::max<uint32_t>(max_nx, (uint32_t)nx);
+        max_frames = std::max<uint32_t>(max_frames, (uint32_t)frames);
+        io[f].frames_out = (size_t)frames;
+    }
+    if (e->fc.resamp) {
+        int rc = grow_scratch(e, (size_t)e->fc.resamp->P + max_nx, s);
+        if (rc) return rc;
+    }
+    // job table: pinned slot -> device
+    const int slot = e->job_slot;
+    e->job_slot = (slot + 1) % JOB_SLOTS;
+    if (e->job_ev_used[slot]) HIPCHK(e, hipEventSynchronize(e->job_ev[slot]));
+    StreamJob* hj = e->h_jobs + (size_t)slot * e->nstreams;
+    const int cur = e->hist_cur;
+    for (uint32_t f = 0; f < n_files; ++f) {
+        const FileState& st = e->files[f];
+        for (uint32_t c = 0; c < C; ++c) {
+            const uint32_t sidx = f * C + c;
+            StreamJob& j = hj[sidx];
+            j.in = (const uint8_t*)io[f].dsd;
+            j.hist = e->d_hist[cur] + (size_t)sidx * e->keep;
+            j.hist_next = e->d_hist[cur ^ 1] + (size_t)sidx * e->keep;
+            j.out = io[f].pcm;
+            j.xs = e->d_scratch ? e->d_scratch + (size_t)sidx * e->scratch_stride + e->fc.resamp->P : nullptr;
+            j.peak = e->d_peak + sidx;
+            j.L = io[f].bytes_per_channel;
+            j.e0 = (int64_t)((st.nfir + 1) * (uint64_t)e->Mb) - (int64_t)st.pos;
+            j.n0 = st.nfir;
+            j.nout = (uint32_t)(nfir1[f] - st.nfir);
+            j.ch = c;
+            j.m0 = st.nres;
+            j.nres = e->fc.resamp ? (uint32_t)(nres1[f] - st.nres) : 0;
+            j.pad_ = 0;
+        }
+    }
+    HIPCHK(e, hipMemcpyAsync(e->d_jobs, hj, sizeof(StreamJob) * e->nstreams, hipMemcpyHostToDevice, s));
+    HIPCHK(e, hipEventRecord(e->job_ev[slot], s));
+    e->job_ev_used[slot] = true;
+
+    FirArgs a{};
+    a.jobs = e->d_jobs;
+    a.tables = e->d_fir_tables;
+    a.Wb = (uint32_t)e->Wb;
+    a.ntab = (uint32_t)e->lut.ntab; a.pad = (uint32_t)e->lut.pad; a.nq = (uint32_t)e->lut.nq;
+    a.B = e->B; a.keep = e->keep;
+    a.to_scratch = e->fc.resamp ? 1u : 0u;
+    a.ksteps = (uint32_t)e->mfma.ksteps;
+    a.scale_bits = e->S;
+    a.epi = e->epi;
+    if (max_nx) {
+        if (e->kernel == D2D_KERNEL_LUT) {
+            const uint32_t per_tile = lut_outputs_per_tile(e->Mb);
+            HIPCHK(e, launch_fir_lut(a, e->Mb, (max_nx + per_tile - 1) / per_tile, e->nstreams, s));
+        } else {
+            HIPCHK(e, launch_fir_mfma(a, e->mfma, max_nx, e->nstreams, s));
+        }
+    }
+    if (e->fc.resamp) {
+        ResampArgs r{};
+        r.jobs = e->d_jobs; r.coef = e->d_resamp;
+        r.L = (uint32_t)e->fc.resamp->L; r.Mdn = (uint32_t)e->fc.resamp->Mdn; r.P = (uint32_t)e->fc.resamp->P;
+        r.epi = e->epi;
+        HIPCHK(e, launch_resample(r, max_frames, e->nstreams, s));
+        HIPCHK(e, launch_xhist(e->d_jobs, e->nstreams, r.P, s));
+    }
+    HIPCHK(e, launch_history(e->d_jobs, e->nstreams, C, e->B, e->keep, s));
+    e->hist_cur = cur ^ 1;
+    for (uint32_t f = 0; f < n_files; ++f) {
+        FileState& st = e->files[f];
+        st.pos += io[f].bytes_per_channel;
+        st.nfir = nfir1[f];
+        st.nres = nres1[f];
+    }
+    e->last_stream = s;
+    return D2D_OK;
+}
+
+static int ensure_cap(d2d_engine* e, uint8_t** buf, size_t* cap, size_t need) {
+    if (need <= *cap) return D2D_OK;
+    size_t n = std::max(need, *cap * 2);
+    n = (n + 4095) & ~(size_t)4095;
+    HIPCHK(e, hipStreamSynchronize(e->own_stream));
+    if (*buf) HIPCHK(e, hipFree(*buf));
+    *buf = nullptr; *cap = 0;
+    HIPCHK(e, hipMalloc((void**)buf, n));
+    *cap = n;
+    return D2D_OK;
+}
+
+int d2d_translate(d2d_engine* e, const uint8_t* dsd, size_t L, void* pcm, size_t cap, size_t* frames_out) {
+    if (!e) return D2D_ERR_PARAM;
+    if (frames_out) *frames_out = 0;
+    if (e->n_files != 1) return e->fail(D2D_ERR_STATE, "d2d_translate needs a single-file engine");
+    if (L && !dsd) return e->fail(D2D_ERR_PARAM, "null dsd pointer");
+    HIPCHK(e, hipSetDevice(e->p.device));
+    const size_t frames = d2d_next_frames(e, 0, L);
+    const size_t out_bytes = frames * d2d_frame_bytes(e);
+    if (out_bytes > cap) return e->fail(D2D_ERR_CAPACITY, "pcm buffer too small");
+    if (out_bytes && !pcm) return e->fail(D2D_ERR_PARAM, "null pcm pointer");
+    const size_t in_bytes = L * e->C;
+    int rc = ensure_cap(e, &e->d_in, &e->d_in_cap, std::max<size_t>(in_bytes, 16));
+    if (rc) return rc;
+    rc = ensure_cap(e, &e->d_out, &e->d_out_cap, std::max<size_t>(out_bytes, 16));
+    if (rc) return rc;
+    hipStream_t s = e->own_stream;
+    if (in_bytes) HIPCHK(e, hipMemcpyAsync(e->d_in, dsd, in_bytes, hipMemcpyHostToDevice, s));
+    d2d_file_io io{};
+    io.dsd = e->d_in; io.bytes_per_channel = L; io.pcm = e->d_out; io.pcm_capacity_bytes = e->d_out_cap;
+    rc = d2d_translate_batch_device(e, &io, 1, s);
+    if (rc) return rc;
+    if (out_bytes) HIPCHK(e, hipMemcpyAsync(pcm, e->d_out, out_bytes, hipMemcpyDeviceToHost, s));
+    HIPCHK(e, hipStreamSynchronize(s));
+    if (frames_out) *frames_out = io.frames_out;
+    return D2D_OK;
+}
+
+int d2d_peak(d2d_engine* e, uint32_t file, uint32_t channel, double* peak_out) {
+    if (!e || !peak_out) return D2D_ERR_PARAM;
+    if (file >= e->n_files || channel >= e->C) return e->fail(D2D_ERR_PARAM, "file/channel out of range");
+    HIPCHK(e, hipSetDevice(e->p.device));
+    HIPCHK(e, hipStreamSynchronize(e->last_stream));
+    HIPCHK(e, hipMemcpy(peak_out, e->d_peak + (size_t)file * e->C + channel, sizeof(double), hipMemcpyDeviceToHost));
+    return D2D_OK;
+}
+
+int d2d_peak_dbfs(d2d_engine* e, uint32_t file, float* dbfs_out) {
+    if (!e || !dbfs_out) return D2D_ERR_PARAM;
+    double m = 0.0;
+    for (uint32_t c = 0; c < e->C; ++c) {
+        double v = 0.0;
+        int rc = d2d_peak(e, file, c, &v);
+        if (rc) return rc;
+        m = std::max(m, v);
+    }
+    *dbfs_out = (float)(20.0 * log10(m));   // may be -inf/NaN-free; the CLI skips NaN (dsd_levels main.rs:188)
+    return D2D_OK;
+}
+
+int d2d_convert_stream(d2d_engine* e, d2d_read_fn read, void* ru, d2d_write_fn write, void* wu,
+                       const volatile int* cancel, d2d_progress_fn progress, void* pu,
+                       uint64_t total, size_t chunk) {
+    if (!e) return D2D_ERR_PARAM;
+    if (!read) return e->fail(D2D_ERR_PARAM, "null read callback");
+    if (e->n_files != 1) return e->fail(D2D_ERR_STATE, "d2d_convert_stream needs a single-file engine");
+    if (chunk == 0) chunk = 1u << 22;
+    if (e->B > 1) chunk = std::max<size_t>(e->B, chunk / e->B * e->B);   // whole planar blocks per read
+    std::vector<uint8_t> in(chunk * e->C);
+    std::vector<uint8_t> out;
+    uint64_t done = 0;
+    for (;;) {
+        if (cancel && *cancel) return e->fail(D2D_ERR_CANCELLED, "Conversion cancelled");
+        long got = read(ru, in.data(), chunk);
+        if (got < 0) return e->fail(D2D_ERR_IO, "read callback failed");
+        if (got == 0) break;
+        const size_t frames = d2d_next_frames(e, 0, (size_t)got);
+        out.resize(std::max<size_t>(frames * d2d_frame_bytes(e), 16));
+        size_t fo = 0;
+        int rc = d2d_translate(e, in.data(), (size_t)got, out.data(), out.size(), &fo);
+        if (rc) return rc;
+        if (write && fo) {
+            if (write(wu, out.data(), fo * d2d_frame_bytes(e)) != 0) return e->fail(D2D_ERR_IO, "write callback failed");
+        }
+        done += (uint64_t)got;
+        if (progress && total) {
+            float pct = (float)(100.0 * (double)done / (double)total);
+            if (pct >= 100.0f) pct = 99.99f;   // exactly 100 is reserved for the end (src/main.rs:417-418)
+            progress(pu, pct);
+        }
+    }
+    if (progress) progress(pu, 100.0f);
+    return D2D_OK;
+}
+
+size_t d2d_tables_bytes(const d2d_engine* e) {
+    return e ? sizeof(TableBlobHeader) + ((e->fir_table_bytes + 15) & ~(size_t)15) + e->resamp_bytes : 0;
+}
+
+static TableBlobHeader make_header(const d2d_engine* e) {
+    TableBlobHeader h{};
+    h.magic = 0x54443244u; h.abi = D2D_ABI_VERSION; h.kernel = e->kernel; h.endianness = e->p.endianness;
+    h.ntaps = (uint32_t)e->N; h.M = (uint32_t)e->M; h.scale_bits = (uint32_t)e->S; h.filter_type = (uint32_t)e->fc.fir->type;
+    h.fir_bytes = e->fir_table_bytes; h.resamp_bytes = e->resamp_bytes;
+    return h;
+}
+
+int d2d_tables_export_device(d2d_engine* e, void* dst, size_t cap, void* hip_stream) {
+    if (!e || !dst) return D2D_ERR_PARAM;
+    if (cap < d2d_tables_bytes(e)) return e->fail(D2D_ERR_CAPACITY, "table blob buffer too small");
+    HIPCHK(e, hipSetDevice(e->p.device));
+    hipStream_t s = (hipStream_t)hip_stream;
+    TableBlobHeader h = make_header(e);
+    uint8_t* p = (uint8_t*)dst;
+    HIPCHK(e, hipMemcpyAsync(p, &h, sizeof(h), hipMemcpyHostToDevice, s));
+    HIPCHK(e, hipStreamSynchronize(s));   // h is a stack object
+    p += sizeof(h);
+    HIPCHK(e, hipMemcpyAsync(p, e->d_fir_tables, e->fir_table_bytes, hipMemcpyDeviceToDevice, s));
+    p += (e->fir_table_bytes + 15) & ~(size_t)15;
+    if (e->resamp_bytes) HIPCHK(e, hipMemcpyAsync(p, e->d_resamp, e->resamp_bytes, hipMemcpyDeviceToDevice, s));
+    return D2D_OK;
+}
+
+int d2d_tables_import_device(d2d_engine* e, const void* src, size_t bytes, void* hip_stream) {
+    if (!e || !src) return D2D_ERR_PARAM;
+    if (bytes < d2d_tables_bytes(e)) return e->fail(D2D_ERR_PARAM, "table blob too small");
+    HIPCHK(e, hipSetDevice(e->p.device));
+    hipStream_t s = (hipStream_t)hip_stream;
+    TableBlobHeader h{}, want = make_header(e);
+    HIPCHK(e, hipMemcpyAsync(&h, src, sizeof(h), hipMemcpyDeviceToHost, s));
+    HIPCHK(e, hipStreamSynchronize(s));
+    if (memcmp(&h, &want, sizeof(h)) != 0) return e->fail(D2D_ERR_PARAM, "table blob does not match this engine's configuration");
+    const uint8_t* p = (const uint8_t*)src + sizeof(h);
+    HIPCHK(e, hipMemcpyAsync(e->d_fir_tables, p, e->fir_table_bytes, hipMemcpyDeviceToDevice, s));
+    p += (e->fir_table_bytes + 15) & ~(size_t)15;
+    if (e->resamp_bytes) HIPCHK(e, hipMemcpyAsync(e->d_resamp, p, e->resamp_bytes, hipMemcpyDeviceToDevice, s));
+    HIPCHK(e, hipStreamSynchronize(s));
+    return D2D_OK;
+}
+
+int d2d_get_info(const d2d_engine* e, d2d_info* out) {
+    if (!e || !out) return D2D_ERR_PARAM;
+    memset(out, 0, sizeof(*out));
+    out->decimation = (uint32_t)e->M; out->ntaps = (uint32_t)e->N; out->scale_bits = (uint32_t)e->S;
+    if (e->fc.resamp) { out->resamp_L = e->fc.resamp->L; out->resamp_M = e->fc.resamp->Mdn; out->resamp_P = e->fc.resamp->P; }
+    out->kernel = e->kernel; out->abi_version = D2D_ABI_VERSION;
+    strncpy(out->filter_name, e->fc.fir->name, sizeof(out->filter_name) - 1);
+    return D2D_OK;
+}
+
+const char* d2d_kernel_name(const d2d_engine* e) {
+    if (!e) return "";
+    return e->kernel == D2D_KERNEL_LUT ? lut_kernel_name(e->Mb) : mfma_kernel_name(e->mfma);
+}
+
+}  // extern "C"

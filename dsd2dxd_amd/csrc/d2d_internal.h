@@ -1,0 +1,82 @@
+// d2d_internal.h -- structures shared by the host engine and the device kernels.
+// Not part of the C ABI (that is include/dsd2dxd_amd.h).
+#pragma once
+#include <stddef.h>
+#include <stdint.h>
+
+namespace d2d {
+
+constexpr uint32_t DSD64_RATE = 2822400u;
+constexpr uint8_t IDLE_BYTE = 0x69;   // dsd2pcm's idle pattern (DC-free), MSB-first-in-time
+constexpr int LUT_THREADS = 256;
+
+// One (file, channel) stream for one translate call.  All byte indices are "call-relative":
+// 0 = the first byte this call feeds for the channel; negative = carried history.
+struct StreamJob {
+    const uint8_t* in;      // device: the file's call buffer (all channels, reference layout)
+    const uint8_t* hist;    // device: this channel's `keep` history bytes (raw bit order)
+    uint8_t*       hist_next; // device: where the updated history goes (ping-pong buffer)
+    void*          out;     // device: the file's interleaved PCM frames for this call
+    double*        xs;      // device: 48k cascade only -- xs[i] = stage-A output n0+i, xs[-P..-1] = carried
+    double*        peak;    // device: this channel's running peak (as non-negative f64)
+    uint64_t       L;       // bytes per channel fed by this call
+    int64_t        e0;      // one past the newest byte of output n0's window (call-relative)
+    uint64_t       n0;      // absolute index of the first FIR output of this call
+    uint32_t       nout;    // FIR outputs this call
+    uint32_t       ch;      // channel index inside the file
+    // stage B (48k family)
+    uint64_t       m0;      // absolute index of the first resampler output of this call
+    uint32_t       nres;    // resampler outputs this call
+    uint32_t       pad_;
+};
+
+// How to turn an f64 sample into output bytes (a5-a7 of SURVEY 8a).
+struct Epilogue {
+    double   gain;        // 10^(level/20)
+    double   scale;       // gain * 2^(bits-1) for integer depths
+    uint64_t seed;
+    uint32_t bits;        // 16,20,24,32
+    uint32_t dither;      // 'T','R','F','X'
+    uint32_t sample_bytes;
+    uint32_t channels;
+};
+
+struct FirArgs {
+    const StreamJob* jobs;
+    const void*      tables;   // LUT: f64 nibble tables [ntab][16]; MFMA: int8 B fragments
+    uint32_t Wb;               // window bytes = ntaps/8
+    uint32_t ntab;             // LUT: number of nibble tables incl. zero padding
+    uint32_t pad;              // LUT: zero tables in front
+    uint32_t nq;               // LUT: qwords each lane walks
+    uint32_t B;                // effective block size (1 = byte interleaved)
+    uint32_t keep;             // history bytes per channel
+    uint32_t to_scratch;       // 1: write raw f64 FIR outputs to job.out (stage A of the 48k cascade)
+    uint32_t ksteps;           // MFMA: K steps
+    int32_t  scale_bits;       // MFMA: S
+    uint32_t reserved;
+    Epilogue epi;
+};
+
+struct ResampArgs {
+    const StreamJob* jobs;
+    const double*    coef;     // [L][P] phase-major
+    uint32_t L, Mdn, P;
+    uint32_t reserved;
+    Epilogue epi;
+};
+
+// blob header for d2d_tables_export/import
+struct TableBlobHeader {
+    uint32_t magic;            // 'D2DT'
+    uint32_t abi;
+    uint32_t kernel;
+    uint32_t endianness;
+    uint32_t ntaps;
+    uint32_t M;
+    uint32_t scale_bits;
+    uint32_t filter_type;
+    uint64_t fir_bytes;
+    uint64_t resamp_bytes;
+};
+
+}  // namespace d2d

@@ -1,0 +1,212 @@
+// d2d_kernels.hip -- gfx950 device code of the DSD->PCM engine.
+//
+//   d2d_fir_lut_kernel<MB>   1-bit FIR decimator by M = 8*MB through per-nibble lookup tables in LDS
+//                            (the per-bit-pattern LUT path; 16-entry f64 tables are bank-conflict free:
+//                            16 entries x 8 B = 32 banks, equal indices broadcast)
+//   d2d_resample_kernel      stage B of the 48k cascade: polyphase L/147 on f64, one fma per tap
+//   d2d_history_kernel       carries the last `keep` bytes per channel to the next call
+//   d2d_xhist_kernel         carries the last P stage-A outputs per channel to the next call
+//
+// What they replace: the per-block translate loop inside Rdsd2Pcm::do_conversion
+// (/root/reference/src/main.rs:345,429; the rdsd2pcm crate itself is absent from the reference).
+#include <hip/hip_runtime.h>
+
+#include "d2d_device.h"
+#include "d2d_launch.h"
+
+namespace d2d {
+
+template <int MB>
+struct LutGeo {
+    static constexpr int R = MB >= 8 ? 1 : 8 / MB;   // outputs per lane
+    static constexpr int LS = MB >= 8 ? MB : 8;       // byte stride between lanes' windows
+};
+
+// Each lane walks its window as 8-byte words read from LDS, realigned in registers by the
+// block-uniform byte shift; every byte gives two nibble lookups per output the lane owns.
+// The taps are q*2^-S, so every partial sum is exact in f64 and the order of adds is free.
+template <int MB>
+__global__ __launch_bounds__(LUT_THREADS) void d2d_fir_lut_kernel(FirArgs a) {
+    constexpr int R = LutGeo<MB>::R, LS = LutGeo<MB>::LS;
+    extern __shared__ __align__(16) unsigned char smem[];
+    double* tt = reinterpret_cast<double*>(smem);
+    double* red = tt + (size_t)a.ntab * 16;                       // 4 doubles for the peak reduction
+    uint8_t* win = reinterpret_cast<uint8_t*>(red + 4);
+    const StreamJob job = a.jobs[blockIdx.y];
+    const uint32_t tid = threadIdx.x;
+
+    {   // tables: L2 -> LDS once per block
+        const double2* src = reinterpret_cast<const double2*>(a.tables);
+        double2* dst = reinterpret_cast<double2*>(tt);
+        for (uint32_t i = tid; i < a.ntab * 8; i += LUT_THREADS) dst[i] = src[i];
+    }
+    const uint32_t tile_out = LUT_THREADS * R;
+    const uint32_t ntiles = (job.nout + tile_out - 1) / tile_out;
+    const uint32_t span = (uint32_t)((255 * LS + 8 * (a.nq + 1) + 16 + 15) & ~15);
+    const uint32_t sample_bytes = a.epi.sample_bytes;
+    const uint32_t frame_bytes = sample_bytes * a.epi.channels;
+    double pk = 0.0;
+
+    for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int64_t tile_first = job.e0 - (int64_t)a.Wb + (int64_t)tile * (LUT_THREADS * LS);
+        const int64_t abeg = tile_first & ~(int64_t)15;
+        const uint32_t d = (uint32_t)(tile_first - abeg);
+        __syncthreads();
+        stage_window(win, job, a.epi.channels, a.B, a.keep, abeg, span, tid, LUT_THREADS);
+        __syncthreads();
+
+        const uint8_t* lp = win + LS * tid + 8 * (d >> 3);
+        const uint32_t sh = (d & 7) * 8;
+        double acc[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) acc[r] = 0.0;
+        uint64_t cur = *reinterpret_cast<const uint64_t*>(lp);
+        for (uint32_t k = 0; k < a.nq; ++k) {
+            const uint64_t nxt = *reinterpret_cast<const uint64_t*>(lp + 8 * (k + 1));
+            const uint64_t q = sh ? (cur >> sh) | (nxt << (64 - sh)) : cur;
+            const double* tb = tt + (size_t)(a.pad + 16 * k) * 16;
+#pragma unroll
+            for (int b = 0; b < 8; ++b) {
+                const uint32_t v = (uint32_t)(q >> (8 * b)) & 0xFFu;
+                const uint32_t hi = v >> 4, lo = v & 15u;
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const double* t0 = tb + (2 * (b - r * MB)) * 16;
+                    acc[r] += t0[hi];
+                    acc[r] += t0[16 + lo];
+                }
+            }
+            cur = nxt;
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const uint32_t nl = (tile * LUT_THREADS + tid) * R + r;
+            if (nl < job.nout) {
+                if (a.to_scratch) {
+                    job.xs[nl] = acc[r];
+                } else {
+                    uint8_t* dst = reinterpret_cast<uint8_t*>(job.out) + (size_t)nl * frame_bytes + job.ch * sample_bytes;
+                    pk = fmax(pk, emit_sample(a.epi, acc[r], job.ch, job.n0 + nl, dst));
+                }
+            }
+        }
+    }
+    if (!a.to_scratch) block_peak_max(pk, job.peak, red);
+}
+
+// Stage B of the 48k cascade: y[m] = sum_k g[phi][k] * x[i_m - k],
+// t = Mdn*m, i_m = t div L, phi = t mod L; acc = fma(g, x, acc) for k ascending (same order as
+// the oracle, so the f64 result is bit-identical).
+__global__ __launch_bounds__(256) void d2d_resample_kernel(ResampArgs a) {
+    __shared__ double red[4];
+    const StreamJob job = a.jobs[blockIdx.y];
+    const double* xs = job.xs;                          // xs[0] = stage-A output n0; xs[-P..-1] = history
+    uint8_t* pcm = reinterpret_cast<uint8_t*>(job.out);
+    const uint32_t sample_bytes = a.epi.sample_bytes;
+    const uint32_t frame_bytes = sample_bytes * a.epi.channels;
+    double pk = 0.0;
+    for (uint32_t o = blockIdx.x * blockDim.x + threadIdx.x; o < job.nres; o += gridDim.x * blockDim.x) {
+        const uint64_t m = job.m0 + o;
+        const uint64_t t = m * a.Mdn;
+        const uint64_t im = t / a.L;
+        const uint32_t phi = (uint32_t)(t - im * a.L);
+        const double* g = a.coef + (size_t)phi * a.P;
+        const double* xp = xs + (int64_t)(im - job.n0);
+        double acc = 0.0;
+        for (uint32_t k = 0; k < a.P; ++k) acc = fma(g[k], xp[-(int64_t)k], acc);
+        uint8_t* dst = pcm + (size_t)o * frame_bytes + job.ch * sample_bytes;
+        pk = fmax(pk, emit_sample(a.epi, acc, job.ch, m, dst));
+    }
+    block_peak_max(pk, job.peak, red);
+}
+
+// new_hist[j] = stream byte (L - keep + j), j in [0, keep)
+__global__ void d2d_history_kernel(const StreamJob* jobs, uint32_t C, uint32_t B, uint32_t keep) {
+    const StreamJob job = jobs[blockIdx.x];
+    for (uint32_t j = threadIdx.x; j < keep; j += blockDim.x)
+        job.hist_next[j] = stream_byte(job, C, B, keep, (int64_t)job.L - (int64_t)keep + (int64_t)j);
+}
+
+// scratch layout per stream: [P history][nout new]; move the last P to the front (regions may overlap)
+__global__ void d2d_xhist_kernel(const StreamJob* jobs, uint32_t P) {
+    const StreamJob job = jobs[blockIdx.x];
+    double* s = job.xs - P;
+    double v = 0.0;
+    if (threadIdx.x < P) v = s[job.nout + threadIdx.x];
+    __syncthreads();
+    if (threadIdx.x < P) s[threadIdx.x] = v;
+}
+
+// ---- launchers -------------------------------------------------------------------------------
+
+size_t lut_smem_bytes(const FirArgs& a, int MB) {
+    const int LS = MB >= 8 ? MB : 8;
+    const size_t span = (size_t)((255 * LS + 8 * (a.nq + 1) + 16 + 15) & ~15);
+    return (size_t)a.ntab * 128 + 4 * sizeof(double) + span;
+}
+
+template <int MB>
+static hipError_t launch_lut_t(const FirArgs& a, dim3 grid, hipStream_t s) {
+    const size_t smem = lut_smem_bytes(a, MB);
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&d2d_fir_lut_kernel<MB>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(d2d_fir_lut_kernel<MB>, grid, dim3(LUT_THREADS), smem, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_fir_lut(const FirArgs& a, int MB, uint32_t max_tiles, uint32_t nstreams, hipStream_t s) {
+    if (nstreams == 0 || max_tiles == 0) return hipSuccess;
+    // enough blocks to fill 256 CUs a few times over, the rest by the in-kernel tile loop
+    uint32_t gx = max_tiles;
+    const uint32_t cap = (4096 + nstreams - 1) / nstreams;
+    if (gx > cap) gx = cap < 1 ? 1 : cap;
+    dim3 grid(gx, nstreams);
+    switch (MB) {
+        case 1: return launch_lut_t<1>(a, grid, s);
+        case 2: return launch_lut_t<2>(a, grid, s);
+        case 4: return launch_lut_t<4>(a, grid, s);
+        case 8: return launch_lut_t<8>(a, grid, s);
+        case 16: return launch_lut_t<16>(a, grid, s);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+uint32_t lut_outputs_per_tile(int MB) { return LUT_THREADS * (MB >= 8 ? 1 : 8 / MB); }
+
+const char* lut_kernel_name(int MB) {
+    switch (MB) {
+        case 1: return "d2d_fir_lut_kernel<1>";
+        case 2: return "d2d_fir_lut_kernel<2>";
+        case 4: return "d2d_fir_lut_kernel<4>";
+        case 8: return "d2d_fir_lut_kernel<8>";
+        default: return "d2d_fir_lut_kernel<16>";
+    }
+}
+
+hipError_t launch_resample(const ResampArgs& a, uint32_t max_out, uint32_t nstreams, hipStream_t s) {
+    if (nstreams == 0 || max_out == 0) return hipSuccess;
+    uint32_t gx = (max_out + 255) / 256;
+    const uint32_t cap = (8192 + nstreams - 1) / nstreams;
+    if (gx > cap) gx = cap;
+    hipLaunchKernelGGL(d2d_resample_kernel, dim3(gx, nstreams), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_history(const StreamJob* jobs, uint32_t nstreams, uint32_t C, uint32_t B, uint32_t keep, hipStream_t s) {
+    if (nstreams == 0) return hipSuccess;
+    hipLaunchKernelGGL(d2d_history_kernel, dim3(nstreams), dim3(256), 0, s, jobs, C, B, keep);
+    return hipGetLastError();
+}
+
+hipError_t launch_xhist(const StreamJob* jobs, uint32_t nstreams, uint32_t P, hipStream_t s) {
+    if (nstreams == 0) return hipSuccess;
+    hipLaunchKernelGGL(d2d_xhist_kernel, dim3(nstreams), dim3(128), 0, s, jobs, P);
+    return hipGetLastError();
+}
+
+}  // namespace d2d

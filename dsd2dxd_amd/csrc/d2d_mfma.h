@@ -1,0 +1,28 @@
+// d2d_mfma.h -- host view of the int8-MFMA FIR kernel (d2d_kernels_mfma.hip): geometry, table
+// construction and launcher.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <vector>
+
+#include "d2d_filters.h"
+#include "d2d_internal.h"
+
+namespace d2d {
+
+struct MfmaLayout {
+    int M = 0, N = 0;
+    int ksteps = 0;       // K steps of 32 bits over the widened window
+    int phases = 8;       // output phases per matrix row
+    int limbs = 4;        // int8 limbs per 32-bit tap
+};
+
+bool mfma_supported(int M, int N);
+MfmaLayout mfma_layout(int M, int N);
+uint32_t mfma_keep_bytes(const MfmaLayout& g, int Mb);
+std::vector<int8_t> build_mfma_tables(const d2d_filter_def& f, const MfmaLayout& g, bool msb_first);
+hipError_t launch_fir_mfma(const FirArgs& a, const MfmaLayout& g, uint32_t max_nout, uint32_t nstreams, hipStream_t s);
+const char* mfma_kernel_name(const MfmaLayout& g);
+
+}  // namespace d2d

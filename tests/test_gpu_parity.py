@@ -1,0 +1,129 @@
+"""GPU parity: the HIP engine (through the C ABI) against the CPU oracle on the same seeded inputs.
+
+Bar (BASELINE.json north_star): integer output bit-exact for identical dither seed; float output
+within 1e-6 RMS of the f64 CPU path.  The taps are dyadic (q*2^-S), so the FIR sum is exact in both
+and the float output is asserted bit-identical as well; the 1e-6 RMS bound is checked alongside.
+"""
+import numpy as np
+import pytest
+
+from helpers import decode_pcm, pack_layout, random_bytes, synth
+
+pytestmark = pytest.mark.gpu
+
+FLOAT_RMS_TOL = 1e-6
+
+# (dsd_rate, out_rate, filter) -- the matrix of test_all_44k_mults.sh / test_all_48k_mults.sh plus
+# the filter-availability list of src/main.rs:62-67
+RATE_MATRIX = [
+    (1, 88200, "E"), (1, 176400, "E"), (1, 352800, "E"),
+    (2, 88200, "E"), (2, 176400, "E"), (2, 352800, "E"), (2, 705600, "E"),
+    (4, 88200, "E"), (4, 176400, "E"), (4, 352800, "E"), (4, 705600, "E"), (4, 1411200, "E"),
+    (8, 352800, "E"),
+    (1, 88200, "X"), (1, 176400, "X"), (1, 352800, "X"), (1, 352800, "D"),
+    (2, 88200, "C"), (2, 176400, "C"), (2, 352800, "C"),
+    (1, 96000, "E"), (1, 192000, "E"), (1, 384000, "E"),
+    (2, 96000, "E"), (2, 192000, "E"), (2, 384000, "E"),
+    (4, 96000, "E"), (4, 192000, "E"), (4, 384000, "E"),
+    (8, 96000, "E"),
+]
+
+
+def run_pair(engine_lib, oracle_mod, bufs, kw, kernel=0):
+    """bufs: list of call buffers fed in sequence.  Returns (gpu_bytes, oracle_bytes, gpu_engine, oracle)."""
+    e = engine_lib.Engine(kernel=kernel, **kw)
+    o = oracle_mod.Oracle(**kw)
+    g_all, o_all = [], []
+    for b in bufs:
+        g, gf = e.translate(b)
+        r, rf = o.translate(b)
+        assert gf == rf
+        g_all.append(g.copy())
+        o_all.append(r[:rf * o.frame_bytes].copy())
+    return np.concatenate(g_all), np.concatenate(o_all), e, o
+
+
+@pytest.mark.parametrize("dsd_rate,out_rate,filt", RATE_MATRIX)
+def test_rate_matrix_int24_tpdf(engine_lib, oracle_mod, dsd_rate, out_rate, filt):
+    nbytes = 4096 * 6
+    chans = [synth("sine", nbytes, seed=1, dsd_rate=dsd_rate), synth("pink", nbytes, seed=2, amp=0.098, dsd_rate=dsd_rate)]
+    buf = pack_layout(chans, "P", 4096)
+    kw = dict(dsd_rate=dsd_rate, output_rate=out_rate, channels=2, fmt="P", endianness="L", block_size=4096,
+              filter=filt, bit_depth=24, dither="T", seed=7)
+    g, r, e, o = run_pair(engine_lib, oracle_mod, [buf[:4096 * 2 * 2], buf[4096 * 2 * 2:]], kw)
+    assert g.size == r.size and g.size > 0
+    assert np.array_equal(g, r)
+    for c in range(2):
+        assert e.peak(c) == o.peak(c)
+
+
+@pytest.mark.parametrize("bits,dither", [(16, "T"), (16, "R"), (16, "X"), (20, "T"), (20, "X"), (24, "R"), (24, "X"),
+                                          (24, "F"), (32, "F"), (32, "X"), (32, "T")])
+@pytest.mark.parametrize("out_rate", [88200, 96000])
+def test_depths_and_dithers(engine_lib, oracle_mod, bits, dither, out_rate):
+    nbytes = 4096 * 4
+    chans = [synth("sine", nbytes, seed=3), synth("pink", nbytes, seed=4, amp=0.098)]
+    buf = pack_layout(chans, "P", 4096)
+    kw = dict(dsd_rate=1, output_rate=out_rate, channels=2, fmt="P", endianness="L", block_size=4096,
+              filter="E", bit_depth=bits, dither=dither, seed=11, level_db=-3.0)
+    g, r, e, o = run_pair(engine_lib, oracle_mod, [buf], kw)
+    assert np.array_equal(g, r)
+    if bits == 32:
+        a, b = decode_pcm(g, 32, 2).astype(np.float64), decode_pcm(r, 32, 2).astype(np.float64)
+        assert np.sqrt(np.mean((a - b) ** 2)) <= FLOAT_RMS_TOL
+
+
+@pytest.mark.parametrize("fmt,endian,block,channels", [
+    ("P", "L", 4096, 1), ("P", "L", 4096, 2), ("P", "M", 4096, 2), ("I", "M", 4096, 2), ("I", "L", 1, 2),
+    ("P", "L", 512, 2), ("P", "M", 24, 3), ("I", "M", 1, 6), ("P", "L", 4096, 8), ("P", "L", 100, 2),
+])
+def test_layouts_and_ragged_calls(engine_lib, oracle_mod, fmt, endian, block, channels):
+    nbytes = 4096 * 3 + 52
+    chans = [random_bytes(nbytes, 100 + c) for c in range(channels)]
+    # ragged call sizes, including a zero-length call and calls that are not a multiple of M/8
+    cuts = [0, 4096, 4096, 4099, 4800, 9000, nbytes]
+    bufs = [pack_layout([ch[a:b] for ch in chans], fmt, block) for a, b in zip(cuts[:-1], cuts[1:])]
+    kw = dict(dsd_rate=1, output_rate=88200, channels=channels, fmt=fmt, endianness=endian, block_size=block,
+              filter="E", bit_depth=24, dither="T", seed=5)
+    g, r, e, o = run_pair(engine_lib, oracle_mod, bufs, kw)
+    assert np.array_equal(g, r)
+    assert e.peak_dbfs() == o.peak_dbfs()
+
+
+def test_batch_of_files_matches_per_file(engine_lib, oracle_mod):
+    import torch
+    n_files, nbytes = 5, 4096 * 8
+    kw = dict(dsd_rate=1, output_rate=88200, channels=2, fmt="P", endianness="L", block_size=4096,
+              filter="E", bit_depth=24, dither="T", seed=9)
+    e = engine_lib.Engine(n_files=n_files, **kw)
+    files = [pack_layout([synth("sine", nbytes, seed=10 + f, freq=500.0 * (f + 1)), synth("pink", nbytes, seed=20 + f, amp=0.098)],
+                         "P", 4096) for f in range(n_files)]
+    d_in = [torch.from_numpy(b).cuda() for b in files]
+    nfr = e.next_frames(nbytes)
+    d_out = [torch.zeros(nfr * e.frame_bytes, dtype=torch.uint8, device="cuda") for _ in range(n_files)]
+    ios = (engine_lib.FileIO * n_files)()
+    for f in range(n_files):
+        ios[f].dsd = d_in[f].data_ptr(); ios[f].bytes_per_channel = nbytes
+        ios[f].pcm = d_out[f].data_ptr(); ios[f].pcm_capacity_bytes = d_out[f].numel()
+    e.translate_batch_device(ios, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    for f in range(n_files):
+        o = oracle_mod.Oracle(**kw)
+        r, rf = o.translate(files[f])
+        assert ios[f].frames_out == rf
+        assert np.array_equal(d_out[f].cpu().numpy(), r)
+        assert e.peak(0, file=f) == o.peak(0) and e.peak(1, file=f) == o.peak(1)
+
+
+def test_known_answers_on_device(engine_lib):
+    """All-ones DSD -> +full scale (taps sum to exactly 1), all-zeros -> -full scale; first frames carry
+    the idle-history transient."""
+    e = engine_lib.Engine(dsd_rate=1, output_rate=88200, channels=1, fmt="P", endianness="M", block_size=4096,
+                          filter="E", bit_depth=24, dither="X")
+    ones = np.full(4096 * 4, 0xFF, dtype=np.uint8)
+    g, fr = e.translate(ones)
+    v = decode_pcm(g, 24, 1)[:, 0]
+    assert (v[200:] == 8388607).all()
+    e.reset()
+    g, fr = e.translate(np.zeros(4096 * 4, dtype=np.uint8))
+    assert (decode_pcm(g, 24, 1)[200:, 0] == -8388608).all()
