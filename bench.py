@@ -1,0 +1,229 @@
+#!/usr/bin/env python3
+"""bench.py -- BASELINE.json's metric on MI355X: output PCM Msamples/s (+ achieved HBM GB/s) for
+DSD64 -> 88.2 kHz stereo, one process per GPU.
+
+A "step" = one pass of the hot path (unpack -> FIR decimate -> dither -> 24-bit pack) over this rank's
+shard of synthetic DSD files, device-resident in, device-resident out.  Weak scaling: every rank
+converts `--files` files of `--seconds` seconds (default 64 x 60 s = config 4's 512-file batch cut
+8 ways); files are independent, so there is no data-path collective -- RCCL only broadcasts the
+filter tables once, before the timed region.
+
+Prints ONE JSON line (rank 0).  `roofline` is for the FIR kernel, timed with HIP events on its launch
+stream inside the timed region; `cpu_baseline` is the repo's own CPU restatement (oracle/, "port" --
+the reference's Rust core is absent from the checkout and cannot be built here) on a bounded sample.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: 8 TB/s spec
+DSD64 = 2822400
+
+WORKLOADS = {
+    # name: (dsd_rate, out_rate, bit_depth, dither, channels, algorithmic bytes per output sample)
+    "dsd64_to_88k2_s24_stereo": (1, 88200, 24, "T", 2, 32 / 8 + 3),
+    "dsd64_to_352k8_f32_stereo": (1, 352800, 32, "X", 2, 8 / 8 + 4),
+    "dsd128_to_88k2_s24_stereo": (2, 88200, 24, "T", 2, 64 / 8 + 3),
+}
+
+
+def make_files(n_files, bytes_per_channel, dsd_rate, distinct, rank, threads):
+    """Synthetic planar-4096 LSB-first stereo files: half 1 kHz-family sines at 0.352 FS, half pink
+    noise at ~0.098 RMS.  `distinct` different files are generated and tiled."""
+    from helpers import pack_layout, synth
+    distinct = min(distinct, n_files)
+
+    def one(i):
+        seed = 1000 * rank + i
+        if i % 2 == 0:
+            ch = [synth("sine", bytes_per_channel, seed=seed, freq=1000.0 + 7 * i, phase=0.1 * i, dsd_rate=dsd_rate),
+                  synth("sine", bytes_per_channel, seed=seed + 500, freq=1000.0 + 7 * i, phase=0.1 * i + 0.5, dsd_rate=dsd_rate)]
+        else:
+            ch = [synth("pink", bytes_per_channel, seed=seed, amp=0.098, dsd_rate=dsd_rate),
+                  synth("pink", bytes_per_channel, seed=seed + 500, amp=0.098, dsd_rate=dsd_rate)]
+        return pack_layout(ch, "P", 4096)
+
+    with ThreadPoolExecutor(max_workers=threads) as ex:
+        base = list(ex.map(one, range(distinct)))
+    return [base[i % distinct] for i in range(n_files)]
+
+
+def cpu_baseline(kw, files, threads, budget_s):
+    """The CPU restatement on the host cores: one file per thread (the reference's Rayon policy,
+    src/main.rs:148-155,280-300: threads = logical cores / 2), chunked like its 4096-byte block loop."""
+    from oracle import oracle as O
+    O.use_native()          # -O3 -march=native, built on this box
+    chunk_blocks = 64
+    C_ = kw["channels"]
+
+    def work(buf):
+        o = O.Oracle(**kw)
+        step = 4096 * C_ * chunk_blocks
+        n = 0
+        t0 = time.perf_counter()
+        for a in range(0, len(buf), step):
+            _, fr = o.translate(buf[a:a + step])
+            n += fr * C_
+            if time.perf_counter() - t0 > budget_s:
+                break
+        return n
+
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(max_workers=threads) as ex:
+        counts = list(ex.map(work, [files[i % len(files)] for i in range(threads)]))
+    dt = time.perf_counter() - t0
+    return sum(counts) / dt / 1e6, sum(counts), dt
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--files", type=int, default=64, help="files per GPU")
+    ap.add_argument("--seconds", type=float, default=60.0, help="audio seconds per file")
+    ap.add_argument("--distinct", type=int, default=8, help="distinct synthetic files generated per rank (tiled to --files)")
+    ap.add_argument("--workload", default="dsd64_to_88k2_s24_stereo", choices=sorted(WORKLOADS))
+    ap.add_argument("--kernel", default="auto", choices=["auto", "lut", "mfma"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-budget", type=float, default=12.0, help="seconds of CPU-baseline work")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import dsd2dxd_amd as d
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    dsd_rate, out_rate, bits, dither, channels, bytes_per_sample = WORKLOADS[args.workload]
+    M = DSD64 * dsd_rate // out_rate
+    blocks = max(1, int(round(args.seconds * DSD64 * dsd_rate / 8 / 4096)))
+    bpc = blocks * 4096                                   # bytes per channel per file
+    kw = dict(dsd_rate=dsd_rate, output_rate=out_rate, channels=channels, fmt="P", endianness="L",
+              block_size=4096, filter="E", bit_depth=bits, dither=dither, seed=206)
+    kernel = {"auto": d.KERNEL_AUTO, "lut": d.KERNEL_LUT, "mfma": d.KERNEL_MFMA}[args.kernel]
+    ncpu = os.cpu_count() or 1
+    gen_threads = max(1, min(32, ncpu // max(1, min(world, 8))))
+
+    files = make_files(args.files, bpc, dsd_rate, args.distinct, rank, gen_threads)
+    eng = d.Engine(n_files=args.files, kernel=kernel, device=local_rank, **kw)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    # the shared filter tables: rank 0's copy is broadcast over RCCL and adopted by the others
+    if world > 1:
+        nb = eng.tables_bytes()
+        blob = torch.empty(nb, dtype=torch.uint8, device=dev)
+        if rank == 0:
+            eng.tables_export_device(blob.data_ptr(), nb, stream)
+        torch.cuda.synchronize()
+        dist.broadcast(blob, src=0)
+        torch.cuda.synchronize()
+        if rank != 0:
+            eng.tables_import_device(blob.data_ptr(), nb, stream)
+
+    # device-resident inputs and outputs (distinct files uploaded once, tiled by pointer)
+    uniq = {}
+    d_in = []
+    for b in files:
+        if id(b) not in uniq:
+            uniq[id(b)] = torch.from_numpy(b).to(dev)
+        d_in.append(uniq[id(b)])
+    frames = eng.next_frames(bpc)
+    fb = eng.frame_bytes
+    d_out = torch.empty((args.files, frames * fb + 16), dtype=torch.uint8, device=dev)
+    ios = (d.FileIO * args.files)()
+    for f in range(args.files):
+        ios[f].dsd = d_in[f].data_ptr()
+        ios[f].bytes_per_channel = bpc
+        ios[f].pcm = d_out[f].data_ptr()
+        ios[f].pcm_capacity_bytes = frames * fb
+    assert d_out.stride(0) % 16 == 0
+
+    def step():
+        eng.translate_batch_device(ios, stream)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    eng.profile_read()
+    eng.profile_enable(True)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    fir_ms, launches = eng.profile_read()
+    eng.profile_enable(False)
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    samples_per_step_rank = frames * channels * args.files
+    total_samples = samples_per_step_rank * args.steps * world
+    value = total_samples / dt / 1e6
+    fir_s = fir_ms / 1e3 / max(1, launches)
+    alg_bytes = samples_per_step_rank * bytes_per_sample      # per launch (one launch = one step of one rank)
+    achieved = alg_bytes / fir_s / 1e9 if fir_s > 0 else 0.0
+
+    out = {
+        "metric": "output PCM Msamples/s, DSD64->88.2k stereo" if args.workload.startswith("dsd64_to_88k2") else f"output PCM Msamples/s, {args.workload}",
+        "value": round(value, 3), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f64", "data": "synthetic (2nd-order 1-bit modulator: 1 kHz-family sines at 0.352 FS and pink noise at ~0.1 RMS; %d distinct files per rank tiled to %d)" % (min(args.distinct, args.files), args.files),
+        "config": {"workload": f"{args.workload}: {args.files} files/GPU x {blocks * 4096 * 8 / (DSD64 * dsd_rate):.1f} s, planar 4096-B LSB-first -> {bits}-bit {out_rate} Hz, dither {dither}, filter E ({eng.info()['ntaps']} taps, M={M})",
+                   "files_per_gpu": args.files, "seconds_per_file": round(blocks * 4096 * 8 / (DSD64 * dsd_rate), 3),
+                   "parallelism": f"files sharded over {world} GPU(s), no data-path collective", "kernel": eng.kernel_name()},
+        "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                     "kernel": eng.kernel_name(), "kernel_ms": round(fir_s * 1e3, 4),
+                     "algorithmic_bytes_per_launch": int(alg_bytes), "bytes_per_output_sample": bytes_per_sample},
+    }
+    # PMC traffic is collected in separate rocprofv3 --pmc passes (profiles/); bench.py only cites it
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as fjs:
+            pmc = json.load(fjs)
+        ent = pmc.get(eng.kernel_name(), {}).get(args.workload)
+        if ent and ent.get("files_per_gpu") == args.files and abs(ent.get("seconds_per_file", 0) - out["config"]["seconds_per_file"]) < 1e-3:
+            out["roofline"]["traffic"] = ent["hbm_bytes_per_launch"]
+    except Exception:
+        pass
+
+    if rank == 0 and not args.no_cpu_baseline:
+        threads = max(1, ncpu // 2)
+        v, n, secs = cpu_baseline(kw, files, threads, args.cpu_budget)
+        out["cpu_baseline"] = {"value": round(v, 3), "unit": "Msamples/s", "cores": threads, "kind": "port",
+                               "sample": f"{threads} files (one per thread, threads = logical cores/2 as src/main.rs:148-155), {n} output samples in {secs:.1f} s; oracle/d2d_oracle.c byte-LUT f64, gcc -O2 -march=native"}
+    elif rank == 0:
+        out["cpu_baseline"] = None
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

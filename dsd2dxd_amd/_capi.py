@@ -47,7 +47,8 @@ PROGRESS_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_float)
 EXPORTS = ["d2d_create", "d2d_create_error", "d2d_destroy", "d2d_reset", "d2d_last_error",
            "d2d_frame_bytes", "d2d_next_frames", "d2d_translate", "d2d_translate_batch_device",
            "d2d_peak", "d2d_peak_dbfs", "d2d_convert_stream", "d2d_tables_bytes",
-           "d2d_tables_export_device", "d2d_tables_import_device", "d2d_get_info", "d2d_kernel_name"]
+           "d2d_tables_export_device", "d2d_tables_import_device", "d2d_get_info", "d2d_kernel_name",
+           "d2d_profile_enable", "d2d_profile_read"]
 
 _lib = None
 
@@ -94,6 +95,8 @@ def lib():
     L.d2d_get_info.argtypes = [C.c_void_p, C.POINTER(Info)]
     L.d2d_kernel_name.argtypes = [C.c_void_p]
     L.d2d_kernel_name.restype = C.c_char_p
+    L.d2d_profile_enable.argtypes = [C.c_void_p, C.c_int]
+    L.d2d_profile_read.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
     _lib = L
     return L
 
@@ -184,6 +187,14 @@ class Engine:
         v = C.c_float()
         self._check(lib().d2d_peak_dbfs(self._h, file, C.byref(v)))
         return v.value
+
+    def profile_enable(self, on=True):
+        self._check(lib().d2d_profile_enable(self._h, int(on)))
+
+    def profile_read(self):
+        ms, n = C.c_double(), C.c_uint64()
+        self._check(lib().d2d_profile_read(self._h, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
 
     def tables_bytes(self):
         return lib().d2d_tables_bytes(self._h)

@@ -67,56 +67,60 @@ __device__ __forceinline__ void stage_window(uint8_t* lds, const StreamJob& job,
     }
 }
 
-// [own] counter-based dither generator, identical to orc_rng() in oracle/d2d_oracle.c.
-__device__ __forceinline__ uint64_t rng64(uint64_t seed, uint32_t channel, uint64_t n) {
-    uint64_t z = (seed ^ ((uint64_t)channel * 0xD1B54A32D192ED03ull)) + (n + 1) * 0x9E3779B97F4A7C15ull;
-    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-    return z ^ (z >> 31);
+// [own] counter-based dither generator, identical to orc_rng() in oracle/d2d_oracle.c:
+// word = lowbias32(lo32(n) + k32 + hi32(n)*kstep).  The host folds hi32(n0) into job.rng_key; a
+// call spans fewer than 2^32 outputs, so lo32(n) wraps at most once inside it.
+__device__ __forceinline__ uint32_t rng32(const StreamJob& job, uint64_t n) {
+    const uint32_t lo = (uint32_t)n;
+    uint32_t x = lo + job.rng_key + (lo < job.rng_lo0 ? job.rng_kstep : 0u);
+    x ^= x >> 16; x *= 0x7feb352dU;
+    x ^= x >> 15; x *= 0x846ca68bU;
+    x ^= x >> 16;
+    return x;
 }
 
-// a5-a7: level, dither, requantise and pack one sample; returns |y*gain| for the peak meter.
-// y = FIR (or cascade) output, exact multiple of 2^-S for the 44.1k family.
-// dst = first byte of this sample in the interleaved little-endian frame.
-__device__ __forceinline__ double emit_sample(const Epilogue& ep, double y, uint32_t ch, uint64_t n, uint8_t* dst) {
-    const double v = y * ep.gain;
-    if (ep.bits == 32) {
-        double x = v;
-        if (ep.dither == 'F') {
-            // Airwindows "Dither Float": noise scaled to the f32 ulp at the sample's exponent
-            uint32_t u1 = (uint32_t)(rng64(ep.seed, ch, n) >> 32);
-            uint32_t fb = __float_as_uint((float)x);
-            int e = (int)((fb >> 23) & 0xFF);
-            int expon = e ? e - 126 : 0;
-            double t = ((double)u1 - 2147483647.0) * 5.5e-36;
-            x = x + ldexp(t, expon + 62);
-        }
-        float o = (float)x;
-        *reinterpret_cast<float*>(dst) = o;   // frame stride is a multiple of 4 bytes
-        return fabs(v);
-    }
-    double x = y * ep.scale;
+// a5-a7 for the integer depths: level, dither, round half away from zero, clip.
+// Returns the value as it sits in the container (20-bit samples already shifted into 24 bits).
+__device__ __forceinline__ int32_t quantise_int(const Epilogue& ep, double y, uint32_t rnd) {
+    const double x = y * ep.scale;
     double d = 0.0;
-    if (ep.dither == 'T') {
-        uint64_t r = rng64(ep.seed, ch, n);
-        d = ((double)(uint32_t)(r >> 32) + (double)(uint32_t)r) * 0x1p-32 - 1.0;
-    } else if (ep.dither == 'R') {
-        uint64_t r = rng64(ep.seed, ch, n);
-        d = (double)(uint32_t)(r >> 32) * 0x1p-32 - 0.5;
+    if (ep.dither == 'T') d = (double)((rnd & 0xFFFFu) + (rnd >> 16) + 1u) * 0x1p-16 - 1.0;
+    else if (ep.dither == 'R') d = (double)(2u * (rnd >> 16) + 1u) * 0x1p-17 - 0.5;
+    const double q = x + d;
+    const double r = trunc(q + copysign(0.5, q));      // == (q >= 0 ? floor(q + .5) : ceil(q - .5))
+    const int32_t lim = 1 << (ep.bits - 1);
+    int32_t iv = (int32_t)fmax(fmin(r, 2147483520.0), -2147483648.0);
+    iv = min(max(iv, -lim), lim - 1);
+    return ep.bits == 20 ? iv * 16 : iv;
+}
+
+// ... and for 32-bit float output (Airwindows "Dither Float" when dither == 'F', else a plain cast)
+__device__ __forceinline__ float quantise_f32(const Epilogue& ep, double y, uint32_t rnd) {
+    double x = y * ep.gain;
+    if (ep.dither == 'F') {
+        const uint32_t fb = __float_as_uint((float)x);
+        const int e = (int)((fb >> 23) & 0xFF);
+        const int expon = e ? e - 126 : 0;
+        const double t = ((double)rnd - 2147483647.0) * 5.5e-36;
+        x = x + ldexp(t, expon + 62);
     }
-    double q = x + d;
-    double r = q >= 0.0 ? floor(q + 0.5) : ceil(q - 0.5);
-    double lim = (double)(1u << (ep.bits - 1));
-    r = fmin(r, lim - 1.0);
-    r = fmax(r, -lim);
-    int32_t iv = (int32_t)r;
-    if (ep.bits == 16) {
-        *reinterpret_cast<uint16_t*>(dst) = (uint16_t)iv;
+    return (float)x;
+}
+
+// One sample straight to memory (used by the LUT and resampler kernels); returns |y*gain|.
+__device__ __forceinline__ double emit_sample(const Epilogue& ep, const StreamJob& job, double y, uint64_t n, uint8_t* dst) {
+    const uint32_t rnd = rng32(job, n);
+    if (ep.bits == 32) {
+        *reinterpret_cast<float*>(dst) = quantise_f32(ep, y, rnd);   // frame stride is a multiple of 4 bytes
     } else {
-        if (ep.bits == 20) iv *= 16;
-        dst[0] = (uint8_t)iv; dst[1] = (uint8_t)(iv >> 8); dst[2] = (uint8_t)(iv >> 16);
+        const int32_t iv = quantise_int(ep, y, rnd);
+        if (ep.bits == 16) {
+            *reinterpret_cast<uint16_t*>(dst) = (uint16_t)iv;
+        } else {
+            dst[0] = (uint8_t)iv; dst[1] = (uint8_t)(iv >> 8); dst[2] = (uint8_t)(iv >> 16);
+        }
     }
-    return fabs(v);
+    return fabs(y * ep.gain);
 }
 
 // Non-negative doubles order like their bit patterns: one atomic per block for the peak meter.

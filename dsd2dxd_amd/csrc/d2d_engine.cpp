@@ -61,6 +61,9 @@ struct d2d_engine {
     hipEvent_t job_ev[JOB_SLOTS]{}; bool job_ev_used[JOB_SLOTS]{}; int job_slot = 0;
     hipStream_t own_stream = nullptr;     // used by the host-pointer entry points
     hipStream_t last_stream = nullptr;
+    // measurement
+    bool profiling = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_pool; size_t prof_used = 0;
     // staging for d2d_translate (host pointers)
     uint8_t* d_in = nullptr; size_t d_in_cap = 0;
     uint8_t* d_out = nullptr; size_t d_out_cap = 0;
@@ -82,6 +85,14 @@ static uint64_t res_outputs_after(const d2d_engine* e, uint64_t nx) {
     if (!e->fc.resamp) return nx;
     if (nx == 0) return 0;
     return (nx * (uint64_t)e->fc.resamp->L - 1) / (uint64_t)e->fc.resamp->Mdn + 1;
+}
+
+// key of the counter-based dither generator for one channel (DESIGN.md "dither")
+static uint64_t rng_key64(uint64_t seed, uint32_t channel) {
+    uint64_t z = (seed ^ ((uint64_t)channel * 0xD1B54A32D192ED03ull)) + 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
 }
 
 static size_t sample_bytes_of(uint32_t bits) { return bits == 16 ? 2 : (bits == 32 ? 4 : 3); }
@@ -118,6 +129,7 @@ static void free_device(d2d_engine* e) {
     for (int i = 0; i < JOB_SLOTS; ++i)
         if (e->job_ev[i]) hipEventDestroy(e->job_ev[i]);
     if (e->own_stream) hipStreamDestroy(e->own_stream);
+    for (auto& pr : e->prof_pool) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
 }
 
 static int reset_state(d2d_engine* e) {
@@ -312,7 +324,11 @@ int d2d_translate_batch_device(d2d_engine* e, d2d_file_io* io, uint32_t n_files,
             j.ch = c;
             j.m0 = st.nres;
             j.nres = e->fc.resamp ? (uint32_t)(nres1[f] - st.nres) : 0;
-            j.pad_ = 0;
+            const uint64_t i0 = e->fc.resamp ? st.nres : st.nfir;     // index the dither counter runs on
+            const uint64_t k = rng_key64(e->p.seed, c);
+            j.rng_kstep = (uint32_t)k | 1u;
+            j.rng_key = (uint32_t)(k >> 32) + (uint32_t)(i0 >> 32) * j.rng_kstep;
+            j.rng_lo0 = (uint32_t)i0;
         }
     }
     HIPCHK(e, hipMemcpyAsync(e->d_jobs, hj, sizeof(StreamJob) * e->nstreams, hipMemcpyHostToDevice, s));
@@ -329,6 +345,17 @@ int d2d_translate_batch_device(d2d_engine* e, d2d_file_io* io, uint32_t n_files,
     a.ksteps = (uint32_t)e->mfma.ksteps;
     a.scale_bits = e->S;
     a.epi = e->epi;
+    std::pair<hipEvent_t, hipEvent_t>* pe = nullptr;
+    if (e->profiling && max_nx) {
+        if (e->prof_used == e->prof_pool.size()) {
+            std::pair<hipEvent_t, hipEvent_t> n{};
+            HIPCHK(e, hipEventCreate(&n.first));
+            HIPCHK(e, hipEventCreate(&n.second));
+            e->prof_pool.push_back(n);
+        }
+        pe = &e->prof_pool[e->prof_used++];
+        HIPCHK(e, hipEventRecord(pe->first, s));
+    }
     if (max_nx) {
         if (e->kernel == D2D_KERNEL_LUT) {
             const uint32_t per_tile = lut_outputs_per_tile(e->Mb);
@@ -337,6 +364,7 @@ int d2d_translate_batch_device(d2d_engine* e, d2d_file_io* io, uint32_t n_files,
             HIPCHK(e, launch_fir_mfma(a, e->mfma, max_nx, e->nstreams, s));
         }
     }
+    if (pe) HIPCHK(e, hipEventRecord(pe->second, s));
     if (e->fc.resamp) {
         ResampArgs r{};
         r.jobs = e->d_jobs; r.coef = e->d_resamp;
@@ -450,6 +478,28 @@ int d2d_convert_stream(d2d_engine* e, d2d_read_fn read, void* ru, d2d_write_fn w
         }
     }
     if (progress) progress(pu, 100.0f);
+    return D2D_OK;
+}
+
+int d2d_profile_enable(d2d_engine* e, int on) {
+    if (!e) return D2D_ERR_PARAM;
+    e->profiling = on != 0;
+    return D2D_OK;
+}
+
+int d2d_profile_read(d2d_engine* e, double* ms_total, uint64_t* launches) {
+    if (!e) return D2D_ERR_PARAM;
+    HIPCHK(e, hipSetDevice(e->p.device));
+    double tot = 0.0;
+    for (size_t i = 0; i < e->prof_used; ++i) {
+        HIPCHK(e, hipEventSynchronize(e->prof_pool[i].second));
+        float ms = 0.f;
+        HIPCHK(e, hipEventElapsedTime(&ms, e->prof_pool[i].first, e->prof_pool[i].second));
+        tot += ms;
+    }
+    if (ms_total) *ms_total = tot;
+    if (launches) *launches = e->prof_used;
+    e->prof_used = 0;
     return D2D_OK;
 }
 

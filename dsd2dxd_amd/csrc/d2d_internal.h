@@ -27,7 +27,9 @@ struct StreamJob {
     // stage B (48k family)
     uint64_t       m0;      // absolute index of the first resampler output of this call
     uint32_t       nres;    // resampler outputs this call
-    uint32_t       pad_;
+    uint32_t       rng_key;   // dither key at this call's first output index i0: k32 + hi32(i0)*kstep
+    uint32_t       rng_kstep; // added once more where lo32(index) wraps inside this call
+    uint32_t       rng_lo0;   // lo32(i0); the index is n (44.1k family) or m (48k family)
 };
 
 // How to turn an f64 sample into output bytes (a5-a7 of SURVEY 8a).

@@ -86,7 +86,7 @@ __global__ __launch_bounds__(LUT_THREADS) void d2d_fir_lut_kernel(FirArgs a) {
                     job.xs[nl] = acc[r];
                 } else {
                     uint8_t* dst = reinterpret_cast<uint8_t*>(job.out) + (size_t)nl * frame_bytes + job.ch * sample_bytes;
-                    pk = fmax(pk, emit_sample(a.epi, acc[r], job.ch, job.n0 + nl, dst));
+                    pk = fmax(pk, emit_sample(a.epi, job, acc[r], job.n0 + nl, dst));
                 }
             }
         }
@@ -115,7 +115,7 @@ __global__ __launch_bounds__(256) void d2d_resample_kernel(ResampArgs a) {
         double acc = 0.0;
         for (uint32_t k = 0; k < a.P; ++k) acc = fma(g[k], xp[-(int64_t)k], acc);
         uint8_t* dst = pcm + (size_t)o * frame_bytes + job.ch * sample_bytes;
-        pk = fmax(pk, emit_sample(a.epi, acc, job.ch, m, dst));
+        pk = fmax(pk, emit_sample(a.epi, job, acc, m, dst));
     }
     block_peak_max(pk, job.peak, red);
 }

@@ -161,6 +161,15 @@ int d2d_get_info(const d2d_engine* e, d2d_info* out);
 /* Name of the device kernel that does the FIR, as rocprofv3 prints it (for bench/profiles). */
 const char* d2d_kernel_name(const d2d_engine* e);
 
+/* ---- measurement ---------------------------------------------------------------------------- */
+
+/* When enabled, every translate call brackets its FIR launch with hipEvents on the launch stream;
+ * d2d_profile_read() synchronises, returns the summed FIR kernel time and launch count since the
+ * last read, and clears them.  (The analogue of the library's own "DSP speed" log line that the
+ * reference prints per file -- asset/progress.jpg.) */
+int d2d_profile_enable(d2d_engine* e, int on);
+int d2d_profile_read(d2d_engine* e, double* fir_ms_total, uint64_t* launches);
+
 #ifdef __cplusplus
 }
 #endif

@@ -50,14 +50,28 @@ static uint8_t bitrev8(uint8_t v) {
     return v;
 }
 
-/* [own] counter-based dither generator: splitmix64 evaluated at position n of the stream seeded
- * per channel.  The reference locks rand 0.8.5 (Cargo.lock:546-552) with unknown seeding inside
- * rdsd2pcm, so its noise sequence is unobservable; bit-exactness is defined against THIS one. */
-uint64_t orc_rng(uint64_t seed, uint32_t channel, uint64_t n) {
-    uint64_t z = (seed ^ ((uint64_t)channel * 0xD1B54A32D192ED03ull)) + (n + 1) * 0x9E3779B97F4A7C15ull;
+/* [own] counter-based dither generator.  One 32-bit word per output sample, a pure function of
+ * (seed, channel, n): key = splitmix64 finaliser of (seed, channel) -> k32 and an odd step for the
+ * high half of n; word = lowbias32(lo32(n) + k32 + hi32(n) * kstep)  (lowbias32: C. Wellons'
+ * 2-multiply integer hash).  The reference locks rand 0.8.5 (Cargo.lock:546-552) with unknown
+ * seeding inside rdsd2pcm, so its noise sequence is unobservable; bit-exactness is defined against
+ * THIS generator, chosen to be cheap on a GPU lane (two 32-bit multiplies). */
+static uint64_t splitmix_fin(uint64_t z) {
     z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
     z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
     return z ^ (z >> 31);
+}
+uint64_t orc_rng_key(uint64_t seed, uint32_t channel) {
+    return splitmix_fin((seed ^ ((uint64_t)channel * 0xD1B54A32D192ED03ull)) + 0x9E3779B97F4A7C15ull);
+}
+uint32_t orc_rng(uint64_t seed, uint32_t channel, uint64_t n) {
+    uint64_t k = orc_rng_key(seed, channel);
+    uint32_t k32 = (uint32_t)(k >> 32), kstep = (uint32_t)k | 1u;
+    uint32_t x = (uint32_t)n + k32 + (uint32_t)(n >> 32) * kstep;
+    x ^= x >> 16; x *= 0x7feb352dU;
+    x ^= x >> 15; x *= 0x846ca68bU;
+    x ^= x >> 16;
+    return x;
 }
 
 /* Which (filter, dsd rate, output rate) combinations exist: src/main.rs:62-67,85-92;
@@ -204,8 +218,7 @@ static double fir_lut(const orc_ctx* c, const uint8_t* canon, const uint8_t* can
  * Dither kinds: src/main.rs:171-181, README.md:11-12,236. */
 static void emit_sample(const orc_ctx* c, double y, uint32_t ch, uint64_t n, uint8_t* dst) {
     uint32_t bits = c->p.bit_depth;
-    uint64_t rnd = orc_rng(c->p.seed, ch, n);
-    uint32_t u1 = (uint32_t)(rnd >> 32), u2 = (uint32_t)rnd;
+    uint32_t rnd = orc_rng(c->p.seed, ch, n);
     if (bits == 32) {
         double x = y * c->gain;
         if (c->p.dither == 'F') {
@@ -216,7 +229,7 @@ static void emit_sample(const orc_ctx* c, double y, uint32_t ch, uint64_t n, uin
             float xf = (float)x; uint32_t fb; memcpy(&fb, &xf, 4);
             int e = (int)((fb >> 23) & 0xFF);
             int expon = e ? e - 126 : 0;
-            double t = ((double)u1 - 2147483647.0) * 5.5e-36;
+            double t = ((double)rnd - 2147483647.0) * 5.5e-36;
             x = x + ldexp(t, expon + 62);
         } /* [own] T/R/X on float output: plain cast */
         float o = (float)x;
@@ -226,8 +239,10 @@ static void emit_sample(const orc_ctx* c, double y, uint32_t ch, uint64_t n, uin
     double scale = ldexp(c->gain, (int)bits - 1);  /* exact scaling of the gain */
     double x = y * scale;
     double d = 0.0;
-    if (c->p.dither == 'T') d = ((double)u1 + (double)u2) * 0x1p-32 - 1.0;   /* triangular, +-1 LSB */
-    else if (c->p.dither == 'R') d = (double)u1 * 0x1p-32 - 0.5;              /* rectangular, +-1/2 LSB */
+    /* the word's two 16-bit halves are the two uniforms of the triangular pdf; both forms are
+     * symmetric about zero, so the dither adds no DC */
+    if (c->p.dither == 'T') d = (double)((rnd & 0xFFFFu) + (rnd >> 16) + 1u) * 0x1p-16 - 1.0;   /* triangular, +-1 LSB */
+    else if (c->p.dither == 'R') d = (double)(2u * (rnd >> 16) + 1u) * 0x1p-17 - 0.5;          /* rectangular, +-1/2 LSB */
     /* [own] 'F' at an integer depth: no dither */
     double q = x + d;
     /* [lineage] dsd2pcm main.cpp rounds half away from zero and clips */

@@ -71,7 +71,8 @@ int    orc_filter_info(const orc_ctx* c, int* M, int* ntaps, int* S, int* resamp
 double orc_tap(const orc_ctx* c, int i);
 
 /* The dither generator, exposed so tests can pin it. */
-uint64_t orc_rng(uint64_t seed, uint32_t channel, uint64_t n);
+uint32_t orc_rng(uint64_t seed, uint32_t channel, uint64_t n);
+uint64_t orc_rng_key(uint64_t seed, uint32_t channel);
 
 #ifdef __cplusplus
 }

@@ -13,14 +13,21 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB = os.path.join(HERE, "liboracle.so")
 
 
-def build(force=False):
+LIB_NATIVE = os.path.join(HERE, "liboracle_native.so")
+
+
+def build(force=False, native=False):
+    """native=True: -O3 -march=native build for the cpu_baseline timing; always rebuilt on the box it
+    is timed on (the portable build travels with the repo snapshot, this one must not)."""
     src = os.path.join(HERE, "d2d_oracle.c")
+    out = LIB_NATIVE if native else LIB
     deps = [src, os.path.join(HERE, "d2d_oracle.h"), os.path.join(HERE, "..", "filters", "filter_tables.inc")]
-    if (not force and os.path.exists(LIB)
-            and all(os.path.getmtime(LIB) >= os.path.getmtime(d) for d in deps if os.path.exists(d))):
-        return LIB
-    subprocess.check_call(["gcc", "-O2", "-march=native", "-ffp-contract=off", "-fPIC", "-shared", "-o", LIB, src, "-lm"])
-    return LIB
+    if (not force and not native and os.path.exists(out)
+            and all(os.path.getmtime(out) >= os.path.getmtime(d) for d in deps if os.path.exists(d))):
+        return out
+    flags = ["-O3", "-march=native"] if native else ["-O2"]
+    subprocess.check_call(["gcc"] + flags + ["-ffp-contract=off", "-fPIC", "-shared", "-o", out, src, "-lm"])
+    return out
 
 
 class OrcParams(C.Structure):
@@ -33,33 +40,45 @@ class OrcParams(C.Structure):
 _lib = None
 
 
-def lib():
+def use_native():
+    """Switch this process to the -march=native build (bench.py's cpu_baseline leg)."""
     global _lib
+    build(native=True)
+    _lib = None
+    _load(LIB_NATIVE)
+
+
+def lib():
     if _lib is None:
         if not os.path.exists(LIB):
             build()
-        L = C.CDLL(LIB)
-        L.orc_create.argtypes = [C.POINTER(OrcParams), C.POINTER(C.c_void_p), C.POINTER(C.c_char_p)]
-        L.orc_create.restype = C.c_int
-        L.orc_destroy.argtypes = [C.c_void_p]
-        L.orc_max_frames.argtypes = [C.c_void_p, C.c_size_t]
-        L.orc_max_frames.restype = C.c_size_t
-        L.orc_frame_bytes.argtypes = [C.c_void_p]
-        L.orc_frame_bytes.restype = C.c_size_t
-        L.orc_translate_f64.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
-                                        C.c_void_p, C.POINTER(C.c_size_t)]
-        L.orc_translate_f64.restype = C.c_int
-        L.orc_peak.argtypes = [C.c_void_p, C.c_uint32]
-        L.orc_peak.restype = C.c_double
-        L.orc_peak_dbfs.argtypes = [C.c_void_p]
-        L.orc_peak_dbfs.restype = C.c_float
-        L.orc_filter_info.argtypes = [C.c_void_p] + [C.POINTER(C.c_int)] * 5
-        L.orc_tap.argtypes = [C.c_void_p, C.c_int]
-        L.orc_tap.restype = C.c_double
-        L.orc_rng.argtypes = [C.c_uint64, C.c_uint32, C.c_uint64]
-        L.orc_rng.restype = C.c_uint64
-        _lib = L
+        _load(LIB)
     return _lib
+
+
+def _load(path):
+    global _lib
+    L = C.CDLL(path)
+    L.orc_create.argtypes = [C.POINTER(OrcParams), C.POINTER(C.c_void_p), C.POINTER(C.c_char_p)]
+    L.orc_create.restype = C.c_int
+    L.orc_destroy.argtypes = [C.c_void_p]
+    L.orc_max_frames.argtypes = [C.c_void_p, C.c_size_t]
+    L.orc_max_frames.restype = C.c_size_t
+    L.orc_frame_bytes.argtypes = [C.c_void_p]
+    L.orc_frame_bytes.restype = C.c_size_t
+    L.orc_translate_f64.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
+                                C.c_void_p, C.POINTER(C.c_size_t)]
+    L.orc_translate_f64.restype = C.c_int
+    L.orc_peak.argtypes = [C.c_void_p, C.c_uint32]
+    L.orc_peak.restype = C.c_double
+    L.orc_peak_dbfs.argtypes = [C.c_void_p]
+    L.orc_peak_dbfs.restype = C.c_float
+    L.orc_filter_info.argtypes = [C.c_void_p] + [C.POINTER(C.c_int)] * 5
+    L.orc_tap.argtypes = [C.c_void_p, C.c_int]
+    L.orc_tap.restype = C.c_double
+    L.orc_rng.argtypes = [C.c_uint64, C.c_uint32, C.c_uint64]
+    L.orc_rng.restype = C.c_uint32
+    _lib = L
 
 
 class OracleError(Exception):

@@ -43,14 +43,19 @@ def run_pair(engine_lib, oracle_mod, bufs, kw, kernel=0):
     return np.concatenate(g_all), np.concatenate(o_all), e, o
 
 
+KERNELS = [pytest.param(1, id="lut"), pytest.param(2, id="mfma")]
+
+
+@pytest.mark.parametrize("kernel", KERNELS)
 @pytest.mark.parametrize("dsd_rate,out_rate,filt", RATE_MATRIX)
-def test_rate_matrix_int24_tpdf(engine_lib, oracle_mod, dsd_rate, out_rate, filt):
+def test_rate_matrix_int24_tpdf(engine_lib, oracle_mod, dsd_rate, out_rate, filt, kernel):
     nbytes = 4096 * 6
     chans = [synth("sine", nbytes, seed=1, dsd_rate=dsd_rate), synth("pink", nbytes, seed=2, amp=0.098, dsd_rate=dsd_rate)]
     buf = pack_layout(chans, "P", 4096)
     kw = dict(dsd_rate=dsd_rate, output_rate=out_rate, channels=2, fmt="P", endianness="L", block_size=4096,
               filter=filt, bit_depth=24, dither="T", seed=7)
-    g, r, e, o = run_pair(engine_lib, oracle_mod, [buf[:4096 * 2 * 2], buf[4096 * 2 * 2:]], kw)
+    g, r, e, o = run_pair(engine_lib, oracle_mod, [buf[:4096 * 2 * 2], buf[4096 * 2 * 2:]], kw, kernel)
+    assert e.info()["kernel"] == kernel
     assert g.size == r.size and g.size > 0
     assert np.array_equal(g, r)
     for c in range(2):
@@ -59,14 +64,15 @@ def test_rate_matrix_int24_tpdf(engine_lib, oracle_mod, dsd_rate, out_rate, filt
 
 @pytest.mark.parametrize("bits,dither", [(16, "T"), (16, "R"), (16, "X"), (20, "T"), (20, "X"), (24, "R"), (24, "X"),
                                           (24, "F"), (32, "F"), (32, "X"), (32, "T")])
+@pytest.mark.parametrize("kernel", KERNELS)
 @pytest.mark.parametrize("out_rate", [88200, 96000])
-def test_depths_and_dithers(engine_lib, oracle_mod, bits, dither, out_rate):
+def test_depths_and_dithers(engine_lib, oracle_mod, bits, dither, out_rate, kernel):
     nbytes = 4096 * 4
     chans = [synth("sine", nbytes, seed=3), synth("pink", nbytes, seed=4, amp=0.098)]
     buf = pack_layout(chans, "P", 4096)
     kw = dict(dsd_rate=1, output_rate=out_rate, channels=2, fmt="P", endianness="L", block_size=4096,
               filter="E", bit_depth=bits, dither=dither, seed=11, level_db=-3.0)
-    g, r, e, o = run_pair(engine_lib, oracle_mod, [buf], kw)
+    g, r, e, o = run_pair(engine_lib, oracle_mod, [buf], kw, kernel)
     assert np.array_equal(g, r)
     if bits == 32:
         a, b = decode_pcm(g, 32, 2).astype(np.float64), decode_pcm(r, 32, 2).astype(np.float64)
@@ -77,7 +83,8 @@ def test_depths_and_dithers(engine_lib, oracle_mod, bits, dither, out_rate):
     ("P", "L", 4096, 1), ("P", "L", 4096, 2), ("P", "M", 4096, 2), ("I", "M", 4096, 2), ("I", "L", 1, 2),
     ("P", "L", 512, 2), ("P", "M", 24, 3), ("I", "M", 1, 6), ("P", "L", 4096, 8), ("P", "L", 100, 2),
 ])
-def test_layouts_and_ragged_calls(engine_lib, oracle_mod, fmt, endian, block, channels):
+@pytest.mark.parametrize("kernel", KERNELS)
+def test_layouts_and_ragged_calls(engine_lib, oracle_mod, fmt, endian, block, channels, kernel):
     nbytes = 4096 * 3 + 52
     chans = [random_bytes(nbytes, 100 + c) for c in range(channels)]
     # ragged call sizes, including a zero-length call and calls that are not a multiple of M/8
@@ -85,17 +92,18 @@ def test_layouts_and_ragged_calls(engine_lib, oracle_mod, fmt, endian, block, ch
     bufs = [pack_layout([ch[a:b] for ch in chans], fmt, block) for a, b in zip(cuts[:-1], cuts[1:])]
     kw = dict(dsd_rate=1, output_rate=88200, channels=channels, fmt=fmt, endianness=endian, block_size=block,
               filter="E", bit_depth=24, dither="T", seed=5)
-    g, r, e, o = run_pair(engine_lib, oracle_mod, bufs, kw)
+    g, r, e, o = run_pair(engine_lib, oracle_mod, bufs, kw, kernel)
     assert np.array_equal(g, r)
     assert e.peak_dbfs() == o.peak_dbfs()
 
 
-def test_batch_of_files_matches_per_file(engine_lib, oracle_mod):
+@pytest.mark.parametrize("kernel", KERNELS)
+def test_batch_of_files_matches_per_file(engine_lib, oracle_mod, kernel):
     import torch
     n_files, nbytes = 5, 4096 * 8
     kw = dict(dsd_rate=1, output_rate=88200, channels=2, fmt="P", endianness="L", block_size=4096,
               filter="E", bit_depth=24, dither="T", seed=9)
-    e = engine_lib.Engine(n_files=n_files, **kw)
+    e = engine_lib.Engine(n_files=n_files, kernel=kernel, **kw)
     files = [pack_layout([synth("sine", nbytes, seed=10 + f, freq=500.0 * (f + 1)), synth("pink", nbytes, seed=20 + f, amp=0.098)],
                          "P", 4096) for f in range(n_files)]
     d_in = [torch.from_numpy(b).cuda() for b in files]
@@ -115,11 +123,12 @@ def test_batch_of_files_matches_per_file(engine_lib, oracle_mod):
         assert e.peak(0, file=f) == o.peak(0) and e.peak(1, file=f) == o.peak(1)
 
 
-def test_known_answers_on_device(engine_lib):
+@pytest.mark.parametrize("kernel", KERNELS)
+def test_known_answers_on_device(engine_lib, kernel):
     """All-ones DSD -> +full scale (taps sum to exactly 1), all-zeros -> -full scale; first frames carry
     the idle-history transient."""
     e = engine_lib.Engine(dsd_rate=1, output_rate=88200, channels=1, fmt="P", endianness="M", block_size=4096,
-                          filter="E", bit_depth=24, dither="X")
+                          filter="E", bit_depth=24, dither="X", kernel=kernel)
     ones = np.full(4096 * 4, 0xFF, dtype=np.uint8)
     g, fr = e.translate(ones)
     v = decode_pcm(g, 24, 1)[:, 0]

@@ -95,13 +95,13 @@ def quantise(h):
     N = len(h)
     assert N % 16 == 0
     half = 0.5 * (h[N // 2:] + h[:N // 2][::-1])        # enforce symmetry
-    S = int(np.floor(np.log2((2 ** 31 - 1) / np.abs(half).max())))
+    S = int(np.floor(np.log2((2 ** 31 - 2 ** 24) / np.abs(half).max())))
     S = min(S, 40)
     q = np.rint(half * 2.0 ** S).astype(np.int64)
     resid = (1 << (S - 1)) - int(q.sum())                 # half must sum to 2^(S-1)
     q[0] += resid                                          # fold the (tiny) residual into the centre tap
     assert abs(resid) < 4 * N, resid
-    assert np.abs(q).max() < 2 ** 31
+    assert np.abs(q).max() < 2 ** 31 - 2 ** 23     # four balanced int8 limbs (MFMA kernel) must hold every tap
     assert 2 * int(q.sum()) == 1 << S
     assert 2 * int(np.abs(q).sum()) < 1 << 52
     return S, q
