@@ -10,60 +10,71 @@
 
 namespace d2d {
 
+// Pointers read out of a StreamJob are generic to the compiler; these casts say "global memory"
+// so that loads and stores become global_* instead of flat_*.
+#define D2D_GLOBAL __attribute__((address_space(1)))
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+template <typename T>
+__device__ __forceinline__ D2D_GLOBAL T* as_global(T* p) { return (D2D_GLOBAL T*)(p); }
+
 // a2: byte j of channel `ch` in a call that feeds L bytes per channel.
 // planar = [ch0 blk][ch1 blk]..., interleaved = block size 1 (README.md:9 of the reference).
-__device__ __forceinline__ uint64_t layout_addr(uint32_t C, uint32_t B, uint64_t L, uint32_t ch, uint64_t j) {
-    if (B == 1) return j * C + ch;
-    uint64_t blk = j / B, off = j - blk * B;
-    uint64_t blen = L - blk * B;
+// 32-bit index math: one call feeds fewer than 2^31 bytes per channel.
+__device__ __forceinline__ uint64_t layout_addr(uint32_t C, uint32_t B, uint32_t L, uint32_t ch, uint32_t j) {
+    if (B == 1) return (uint64_t)j * C + ch;
+    const uint32_t blk = (B & (B - 1)) == 0 ? j >> (31 - __builtin_clz(B)) : j / B;
+    const uint32_t off = j - blk * B;
+    uint32_t blen = L - blk * B;
     if (blen > B) blen = B;
-    return blk * (uint64_t)B * C + (uint64_t)ch * blen + off;
+    return (uint64_t)blk * B * C + (uint64_t)ch * blen + off;
 }
 
 // One raw byte of the channel's stream at call-relative index j (negative = history).
-__device__ __forceinline__ uint8_t stream_byte(const StreamJob& job, uint32_t C, uint32_t B, uint32_t keep, int64_t j) {
+__device__ __noinline__ uint32_t stream_byte(const StreamJob& job, uint32_t C, uint32_t B, uint32_t keep, int32_t j) {
     if (j < 0) {
-        int64_t h = (int64_t)keep + j;
-        return h >= 0 ? job.hist[h] : (uint8_t)0;
+        const int32_t h = (int32_t)keep + j;
+        return h >= 0 ? as_global(job.hist)[h] : 0u;
     }
-    if ((uint64_t)j >= job.L) return 0;
-    return job.in[layout_addr(C, B, job.L, job.ch, (uint64_t)j)];
+    if ((uint32_t)j >= (uint32_t)job.L) return 0u;
+    return as_global(job.in)[layout_addr(C, B, (uint32_t)job.L, job.ch, (uint32_t)j)];
 }
 
 // Stage the channel bytes [abeg, abeg + nbytes) (abeg % 16 == 0, nbytes % 16 == 0) into LDS.
 // Fast path: one global_load_dwordx4 per 16 bytes when the chunk lies inside one planar block
 // whose start is 16-byte aligned; otherwise byte gathers (history, short last block, interleaved).
 __device__ __forceinline__ void stage_window(uint8_t* lds, const StreamJob& job, uint32_t C, uint32_t B,
-                                             uint32_t keep, int64_t abeg, uint32_t nbytes,
+                                             uint32_t keep, int64_t abeg64, uint32_t nbytes,
                                              uint32_t tid, uint32_t nthreads) {
     const uint32_t nchunks = nbytes >> 4;
     const bool aligned_layout = (B & 15u) == 0;
+    const uint32_t L = (uint32_t)job.L;
+    const int32_t abeg = (int32_t)abeg64;
     for (uint32_t q = tid; q < nchunks; q += nthreads) {
-        int64_t j0 = abeg + (int64_t)q * 16;
-        uint4 v;
+        const int32_t j0 = abeg + (int32_t)(q * 16);
+        u32x4 v;
         bool fast = false;
-        if (aligned_layout && j0 >= 0 && (uint64_t)j0 + 16 <= job.L) {
-            uint64_t blk = (uint64_t)j0 / B, off = (uint64_t)j0 - blk * B;
-            uint64_t blen = job.L - blk * B;
+        if (aligned_layout && j0 >= 0 && (uint32_t)j0 + 16 <= L) {
+            const uint32_t j = (uint32_t)j0;
+            const uint32_t blk = (B & (B - 1)) == 0 ? j >> (31 - __builtin_clz(B)) : j / B;
+            const uint32_t off = j - blk * B;
+            uint32_t blen = L - blk * B;
             if (blen > B) blen = B;
             if ((blen & 15u) == 0) {
-                const uint8_t* p = job.in + blk * (uint64_t)B * C + (uint64_t)job.ch * blen + off;
-                v = *reinterpret_cast<const uint4*>(p);
+                const uint8_t* p = job.in + (uint64_t)blk * B * C + (uint64_t)job.ch * blen + off;
+                v = *reinterpret_cast<D2D_GLOBAL const u32x4*>(as_global(p));
                 fast = true;
             }
         }
         if (!fast) {
-            uint32_t w[4];
-#pragma unroll
-            for (int d = 0; d < 4; ++d) {
-                uint32_t x = 0;
-#pragma unroll
-                for (int b = 0; b < 4; ++b) x |= (uint32_t)stream_byte(job, C, B, keep, j0 + d * 4 + b) << (8 * b);
-                w[d] = x;
+            uint32_t w[4] = {0, 0, 0, 0};
+#pragma unroll 1
+            for (int b = 0; b < 16; ++b) {
+                const uint32_t x = stream_byte(job, C, B, keep, j0 + b) << (8 * (b & 3));
+                if ((b >> 2) == 0) w[0] |= x; else if ((b >> 2) == 1) w[1] |= x; else if ((b >> 2) == 2) w[2] |= x; else w[3] |= x;
             }
-            v = make_uint4(w[0], w[1], w[2], w[3]);
+            v = u32x4{w[0], w[1], w[2], w[3]};
         }
-        *reinterpret_cast<uint4*>(lds + (size_t)q * 16) = v;
+        *reinterpret_cast<u32x4*>(lds + (size_t)q * 16) = v;
     }
 }
 

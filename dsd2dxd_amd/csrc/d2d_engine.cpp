@@ -175,9 +175,11 @@ int d2d_create(const d2d_params* params, uint32_t n_files, d2d_engine** out) {
     e->epi.channels = e->C;
     e->lut = lut_layout(e->Mb, e->Wb);
     e->mfma = mfma_layout(e->M, e->N);
-    e->kernel = e->p.kernel == D2D_KERNEL_AUTO ? (mfma_supported(e->M, e->N) ? D2D_KERNEL_MFMA : D2D_KERNEL_LUT) : e->p.kernel;
-    if (e->kernel == D2D_KERNEL_MFMA && !mfma_supported(e->M, e->N)) {
-        g_create_error = "MFMA kernel does not support this decimation"; delete e; return D2D_ERR_PARAM;
+    const bool mfma_ok = mfma_supported(e->M, e->N) &&
+                         mfma_smem_bytes(e->mfma, e->C, e->epi.sample_bytes) <= 160 * 1024;   // many channels x long filter: LUT
+    e->kernel = e->p.kernel == D2D_KERNEL_AUTO ? (mfma_ok ? D2D_KERNEL_MFMA : D2D_KERNEL_LUT) : e->p.kernel;
+    if (e->kernel == D2D_KERNEL_MFMA && !mfma_ok) {
+        g_create_error = "MFMA kernel does not support this configuration (decimation or LDS budget)"; delete e; return D2D_ERR_PARAM;
     }
     e->keep = (uint32_t)std::max(e->Wb + e->Mb, (int)mfma_keep_bytes(e->mfma, e->Mb));
     e->keep = (e->keep + 15u) & ~15u;

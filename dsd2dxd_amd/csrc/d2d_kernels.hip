@@ -124,7 +124,7 @@ __global__ __launch_bounds__(256) void d2d_resample_kernel(ResampArgs a) {
 __global__ void d2d_history_kernel(const StreamJob* jobs, uint32_t C, uint32_t B, uint32_t keep) {
     const StreamJob job = jobs[blockIdx.x];
     for (uint32_t j = threadIdx.x; j < keep; j += blockDim.x)
-        job.hist_next[j] = stream_byte(job, C, B, keep, (int64_t)job.L - (int64_t)keep + (int64_t)j);
+        job.hist_next[j] = (uint8_t)stream_byte(job, C, B, keep, (int32_t)job.L - (int32_t)keep + (int32_t)j);
 }
 
 // scratch layout per stream: [P history][nout new]; move the last P to the front (regions may overlap)

@@ -17,6 +17,9 @@
 #include <hip/hip_runtime.h>
 
 #include "d2d_device.h"
+#include <stdio.h>
+#include <stdlib.h>
+
 #include "d2d_mfma.h"
 
 namespace d2d {
@@ -43,7 +46,10 @@ __device__ __forceinline__ void wave_peak_flush(double pk, double* dst) {
         atomicMax(reinterpret_cast<unsigned long long*>(dst), (unsigned long long)__double_as_longlong(pk));
 }
 
-template <int MB>
+// UCT > 0: the tap fragments of all 2*UCT K steps stay in registers for the whole block (small
+// filters: no LDS traffic in the MFMA loop, fully unrolled).  UCT == 0: K steps counted at run time,
+// fragments streamed from LDS one pair ahead of the MFMAs that use them.
+template <int MB, int UCT>
 __global__ __launch_bounds__(MFMA_THREADS) void d2d_fir_mfma_kernel(MfmaArgs m) {
     const FirArgs& a = m.f;
     extern __shared__ __align__(16) unsigned char smem[];
@@ -56,10 +62,15 @@ __global__ __launch_bounds__(MFMA_THREADS) void d2d_fir_mfma_kernel(MfmaArgs m) 
     const StreamJob* jobs = a.jobs + (size_t)blockIdx.y * C;
     const StreamJob j0 = jobs[0];          // L, e0, n0, nout are common to a file's channels
 
-    {   // tap fragments: L2 -> LDS once per block
+    v4i breg[UCT > 0 ? 2 * UCT : 1];
+    if constexpr (UCT > 0) {   // tap fragments: L2 -> registers once per block
+        const v4i* s = reinterpret_cast<const v4i*>(a.tables) + lane;
+#pragma unroll
+        for (int t = 0; t < 2 * UCT; ++t) breg[t] = s[t * 64];
+    } else {                   // tap fragments: L2 -> LDS once per block
         const uint4* s = reinterpret_cast<const uint4*>(a.tables);
         uint4* d = reinterpret_cast<uint4*>(btab);
-        for (uint32_t i = tid; i < a.ksteps * 64; i += MFMA_THREADS) d[i] = s[i];
+        for (uint32_t i = tid; i < (a.ksteps + 2) * 64; i += MFMA_THREADS) d[i] = s[i];
     }
     const uint32_t FT = m.FT;
     const uint32_t ntiles = (j0.nout + FT - 1) / FT;
@@ -85,19 +96,38 @@ __global__ __launch_bounds__(MFMA_THREADS) void d2d_fir_mfma_kernel(MfmaArgs m) 
                 const uint32_t h = lane >> 5;
                 {
                     const uint32_t r = sub * 32 + (lane & 31);
-                    const uint32_t* rp = reinterpret_cast<const uint32_t*>(inb + c * m.span + (d & ~3u) + r * (8 * MB)) + h * m.U;
-                    const v4i* bp = reinterpret_cast<const v4i*>(btab) + lane;
+                    const uint32_t Urt = UCT > 0 ? (uint32_t)UCT : m.U;
+                    const uint32_t* rp = reinterpret_cast<const uint32_t*>(inb + c * m.span + (d & ~3u) + r * (8 * MB)) + h * Urt;
                     v16i acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-                    uint32_t cur = rp[0];
-                    for (uint32_t u = 0; u < m.U; ++u) {
-                        const uint32_t nxt = rp[u + 1];
-                        const uint32_t W = __builtin_amdgcn_alignbyte(nxt, cur, sh);
-                        const uint32_t K1 = 0x01010101u;
-                        v4i A0 = {(int)(W & K1), (int)((W >> 1) & K1), (int)((W >> 2) & K1), (int)((W >> 3) & K1)};
-                        v4i A1 = {(int)((W >> 4) & K1), (int)((W >> 5) & K1), (int)((W >> 6) & K1), (int)((W >> 7) & K1)};
-                        acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(A0, bp[(2 * u) * 64], acc, 0, 0, 0);
-                        acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(A1, bp[(2 * u + 1) * 64], acc, 0, 0, 0);
-                        cur = nxt;
+                    const uint32_t K1 = 0x01010101u;
+                    if constexpr (UCT > 0) {
+                        uint32_t rw[UCT + 1];
+#pragma unroll
+                        for (int u = 0; u <= UCT; ++u) rw[u] = rp[u];
+#pragma unroll
+                        for (int u = 0; u < UCT; ++u) {
+                            const uint32_t W = __builtin_amdgcn_alignbyte(rw[u + 1], rw[u], sh);
+                            v4i A0 = {(int)(W & K1), (int)((W >> 1) & K1), (int)((W >> 2) & K1), (int)((W >> 3) & K1)};
+                            v4i A1 = {(int)((W >> 4) & K1), (int)((W >> 5) & K1), (int)((W >> 6) & K1), (int)((W >> 7) & K1)};
+                            acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(A0, breg[2 * u], acc, 0, 0, 0);
+                            acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(A1, breg[2 * u + 1], acc, 0, 0, 0);
+                        }
+                    } else {
+                        const v4i* bp = reinterpret_cast<const v4i*>(btab) + lane;
+                        uint32_t cur = rp[0], nxt = rp[1];
+                        v4i B0 = bp[0], B1 = bp[64];
+                        for (uint32_t u = 0; u < m.U; ++u) {
+                            // fetch the next pair's operands before this pair's MFMAs (one extra row
+                            // dword and one extra zero fragment pair exist past the end)
+                            const uint32_t nn = rp[u + 2];
+                            const v4i B0n = bp[(2 * u + 2) * 64], B1n = bp[(2 * u + 3) * 64];
+                            const uint32_t W = __builtin_amdgcn_alignbyte(nxt, cur, sh);
+                            v4i A0 = {(int)(W & K1), (int)((W >> 1) & K1), (int)((W >> 2) & K1), (int)((W >> 3) & K1)};
+                            v4i A1 = {(int)((W >> 4) & K1), (int)((W >> 5) & K1), (int)((W >> 6) & K1), (int)((W >> 7) & K1)};
+                            acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(A0, B0, acc, 0, 0, 0);
+                            acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(A1, B1, acc, 0, 0, 0);
+                            cur = nxt; nxt = nn; B0 = B0n; B1 = B1n;
+                        }
                     }
                     // D[row][col] -> this wave's scratch as [row][col] = [output o = row*8+ph][limb]
                     uint32_t* ds = reinterpret_cast<uint32_t*>(dscr + wave * 4096);
@@ -199,7 +229,7 @@ static inline int8_t limb_of(int32_t q, int l) {
 
 std::vector<int8_t> build_mfma_tables(const d2d_filter_def& f, const MfmaLayout& g, bool msb_first) {
     const int U = g.ksteps / 2;
-    std::vector<int8_t> t((size_t)g.ksteps * 64 * 16, 0);
+    std::vector<int8_t> t((size_t)(g.ksteps + 2) * 64 * 16, 0);   // +2 zero steps: read-ahead of the LDS variant
     for (int ks = 0; ks < g.ksteps; ++ks)
         for (int l = 0; l < 64; ++l) {
             const int col = l & 31, h = l >> 5, ph = col >> 2, limb = col & 3;
@@ -218,17 +248,55 @@ std::vector<int8_t> build_mfma_tables(const d2d_filter_def& f, const MfmaLayout&
 
 static uint32_t mfma_ft(uint32_t C) { return C == 1 ? 1024u : (C == 2 ? 512u : 256u); }
 
-template <int MB>
+template <int MB, int UCT>
 static hipError_t launch_mfma_t(const MfmaArgs& m, size_t smem, dim3 grid, hipStream_t s) {
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&d2d_fir_mfma_kernel<MB>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&d2d_fir_mfma_kernel<MB, UCT>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
         attr_done = true;
     }
-    hipLaunchKernelGGL(d2d_fir_mfma_kernel<MB>, grid, dim3(MFMA_THREADS), smem, s, m);
+    hipLaunchKernelGGL((d2d_fir_mfma_kernel<MB, UCT>), grid, dim3(MFMA_THREADS), smem, s, m);
     return hipGetLastError();
+}
+
+// (MB, U) pairs whose tap fragments fit in registers: every filter of filters/filter_tables.inc
+// with at most 26 K steps.  Anything else takes the run-time-U kernel.
+#define D2D_MFMA_REG_VARIANTS(X) \
+    X(1, 3) X(1, 4) X(2, 5) X(2, 6) X(2, 7) X(4, 9) X(4, 10) X(4, 12) X(4, 13)
+
+static bool mfma_has_reg_variant(int MB, int U) {
+    static const bool off = getenv("D2D_MFMA_NO_REG") != nullptr;   // diagnostic: force the run-time-U kernel
+    if (off) return false;
+#define X(mb, u) if (MB == mb && U == u) return true;
+    D2D_MFMA_REG_VARIANTS(X)
+#undef X
+    return false;
+}
+
+static void mfma_geometry(const FirArgs& a, const MfmaLayout& g, MfmaArgs& m, size_t& smem) {
+    const uint32_t C = a.epi.channels;
+    const int MB = g.M / 8;
+    m.f = a;
+    m.yscale = ldexp(1.0, 1 - a.scale_bits);
+    m.FT = mfma_ft(C);
+    m.U = (uint32_t)g.ksteps / 2;
+    // staged bytes per channel: alignment slack + rows + one row window (+2 dwords read ahead)
+    m.span = (16u + (m.FT / 8 - 1) * 8u * MB + (2 * m.U + 3) * 4u + 16u + 15u) & ~15u;
+    const bool reg = mfma_has_reg_variant(MB, (int)m.U);
+    m.off_in = reg ? 0u : ((uint32_t)g.ksteps + 2u) * 1024u;   // +2: the zero pair the prefetch reads
+    m.off_d = m.off_in + C * m.span;
+    m.off_out = m.off_d + MFMA_WAVES * 4096u;
+    smem = (size_t)m.off_out + ((m.FT * C * a.epi.sample_bytes + 15u) & ~15u);
+}
+
+size_t mfma_smem_bytes(const MfmaLayout& g, uint32_t channels, uint32_t sample_bytes) {
+    FirArgs a{};
+    a.epi.channels = channels; a.epi.sample_bytes = sample_bytes;
+    MfmaArgs m{}; size_t smem = 0;
+    mfma_geometry(a, g, m, smem);
+    return smem;
 }
 
 hipError_t launch_fir_mfma(const FirArgs& a, const MfmaLayout& g, uint32_t max_nout, uint32_t nstreams, hipStream_t s) {
@@ -237,39 +305,32 @@ hipError_t launch_fir_mfma(const FirArgs& a, const MfmaLayout& g, uint32_t max_n
     const uint32_t nfiles = nstreams / C;
     const int MB = g.M / 8;
     MfmaArgs m{};
-    m.f = a;
-    m.yscale = ldexp(1.0, 1 - a.scale_bits);
-    m.FT = mfma_ft(C);
-    m.U = (uint32_t)g.ksteps / 2;
-    m.span = (16u + (m.FT / 8 - 1) * 8u * MB + (2 * m.U + 1) * 4u + 16u + 15u) & ~15u;
-    m.off_in = (uint32_t)g.ksteps * 1024u;
-    m.off_d = m.off_in + C * m.span;
-    m.off_out = m.off_d + MFMA_WAVES * 4096u;
-    const size_t smem = (size_t)m.off_out + ((m.FT * C * a.epi.sample_bytes + 15u) & ~15u);
+    size_t smem = 0;
+    mfma_geometry(a, g, m, smem);
     if (smem > 160 * 1024) return hipErrorInvalidValue;
     const uint32_t ntiles = (max_nout + m.FT - 1) / m.FT;
     uint32_t gx = ntiles;
     const uint32_t cap = (2048 + nfiles - 1) / nfiles;    // ~8 blocks per CU in flight, tiles looped inside
     if (gx > cap) gx = cap;
     dim3 grid(gx, nfiles);
+#define X(mb, u) if (MB == mb && m.U == u) return launch_mfma_t<mb, u>(m, smem, grid, s);
+    D2D_MFMA_REG_VARIANTS(X)
+#undef X
     switch (MB) {
-        case 1: return launch_mfma_t<1>(m, smem, grid, s);
-        case 2: return launch_mfma_t<2>(m, smem, grid, s);
-        case 4: return launch_mfma_t<4>(m, smem, grid, s);
-        case 8: return launch_mfma_t<8>(m, smem, grid, s);
-        case 16: return launch_mfma_t<16>(m, smem, grid, s);
+        case 1: return launch_mfma_t<1, 0>(m, smem, grid, s);
+        case 2: return launch_mfma_t<2, 0>(m, smem, grid, s);
+        case 4: return launch_mfma_t<4, 0>(m, smem, grid, s);
+        case 8: return launch_mfma_t<8, 0>(m, smem, grid, s);
+        case 16: return launch_mfma_t<16, 0>(m, smem, grid, s);
         default: return hipErrorInvalidValue;
     }
 }
 
 const char* mfma_kernel_name(const MfmaLayout& g) {
-    switch (g.M / 8) {
-        case 1: return "d2d_fir_mfma_kernel<1>";
-        case 2: return "d2d_fir_mfma_kernel<2>";
-        case 4: return "d2d_fir_mfma_kernel<4>";
-        case 8: return "d2d_fir_mfma_kernel<8>";
-        default: return "d2d_fir_mfma_kernel<16>";
-    }
+    static thread_local char buf[64];
+    const int MB = g.M / 8, U = g.ksteps / 2;
+    snprintf(buf, sizeof(buf), "d2d_fir_mfma_kernel<%d, %d>", MB, mfma_has_reg_variant(MB, U) ? U : 0);
+    return buf;
 }
 
 }  // namespace d2d
