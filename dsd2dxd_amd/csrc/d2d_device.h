@@ -118,6 +118,30 @@ __device__ __forceinline__ float quantise_f32(const Epilogue& ep, double y, uint
     return (float)x;
 }
 
+// The same two steps for callers that already hold x = round(y*scale) (integer depths) or
+// x = round(y*gain) (float): identical arithmetic from `x` on.
+__device__ __forceinline__ int32_t finish_int(const Epilogue& ep, double x, uint32_t rnd) {
+    double d = 0.0;
+    if (ep.dither == 'T') d = fma((double)((rnd & 0xFFFFu) + (rnd >> 16) + 1u), 0x1p-16, -1.0);   // exact either way
+    else if (ep.dither == 'R') d = fma((double)(2u * (rnd >> 16) + 1u), 0x1p-17, -0.5);
+    const double q = x + d;
+    const double lim = (double)(1u << (ep.bits - 1));
+    const double r = fmax(fmin(trunc(q + copysign(0.5, q)), lim - 1.0), -lim);
+    const int32_t iv = (int32_t)r;
+    return ep.bits == 20 ? iv * 16 : iv;
+}
+
+__device__ __forceinline__ float finish_f32(const Epilogue& ep, double x, uint32_t rnd) {
+    if (ep.dither == 'F') {
+        const uint32_t fb = __float_as_uint((float)x);
+        const int e = (int)((fb >> 23) & 0xFF);
+        const int expon = e ? e - 126 : 0;
+        const double t = ((double)rnd - 2147483647.0) * 5.5e-36;
+        x = x + ldexp(t, expon + 62);
+    }
+    return (float)x;
+}
+
 // One sample straight to memory (used by the LUT and resampler kernels); returns |y*gain|.
 __device__ __forceinline__ double emit_sample(const Epilogue& ep, const StreamJob& job, double y, uint64_t n, uint8_t* dst) {
     const uint32_t rnd = rng32(job, n);

@@ -21,7 +21,7 @@ struct MfmaLayout {
 bool mfma_supported(int M, int N);
 MfmaLayout mfma_layout(int M, int N);
 uint32_t mfma_keep_bytes(const MfmaLayout& g, int Mb);
-size_t mfma_smem_bytes(const MfmaLayout& g, uint32_t channels, uint32_t sample_bytes);
+size_t mfma_smem_bytes(const MfmaLayout& g, uint32_t channels, uint32_t sample_bytes, uint32_t* waves_per_block);
 std::vector<int8_t> build_mfma_tables(const d2d_filter_def& f, const MfmaLayout& g, bool msb_first);
 hipError_t launch_fir_mfma(const FirArgs& a, const MfmaLayout& g, uint32_t max_nout, uint32_t nstreams, hipStream_t s);
 const char* mfma_kernel_name(const MfmaLayout& g);
