@@ -10,8 +10,11 @@ constraints of the reference:
   * 44.1k multiples: ONE filter; 48k multiples: CASCADED gentle FIRs (README.md:230)
   * filter families E / X / D / C and where each is legal  (src/main.rs:62-67)
 
-Every integer-decimator tap is rounded to a dyadic grid c = q * 2^-S with |q| < 2^31
-and the taps sum to exactly 2^S (unity DC gain).  Consequence: a +-1 weighted sum of
+Every integer-decimator tap is rounded to a dyadic grid c = q * 2^-S with |q| < 2^23 (24-bit
+fixed point: the coefficient-rounding floor sits near -150 dB, 40 dB under the designs' own stop
+bands) and the taps sum to exactly 2^S (unity DC gain).  24 bits is what lets the matrix-core kernel
+feed stream bits to the int8 MFMA with ONE mask per operand register (the bit keeps its position
+2^p inside the byte, the table holds q * 2^(7-p) in four int8 limbs).  Consequence: a +-1 weighted sum of
 the taps is exactly representable in f64 whatever the summation order, so the CPU
 oracle (f64, like the reference: README.md:230,236), the LDS-LUT kernel (f64) and the
 int8-limb MFMA kernel (exact integers) all produce the SAME number.
@@ -89,19 +92,19 @@ def design_cheby(M, N, fc_rel, at):
 
 
 def quantise(h):
-    """Round symmetric even-length h to q*2^-S, |q| < 2^31, sum(q) == 2^S exactly."""
+    """Round symmetric even-length h to q*2^-S, |q| < 2^23, sum(q) == 2^S exactly."""
     h = np.asarray(h, dtype=np.float64)
     h = h / h.sum()                                       # unity DC gain (dsd2pcm's own table sums to 1 - 3e-6)
     N = len(h)
     assert N % 16 == 0
     half = 0.5 * (h[N // 2:] + h[:N // 2][::-1])        # enforce symmetry
-    S = int(np.floor(np.log2((2 ** 31 - 2 ** 24) / np.abs(half).max())))
+    S = int(np.floor(np.log2((2 ** 23 - 2 ** 16) / np.abs(half).max())))
     S = min(S, 40)
     q = np.rint(half * 2.0 ** S).astype(np.int64)
     resid = (1 << (S - 1)) - int(q.sum())                 # half must sum to 2^(S-1)
     q[0] += resid                                          # fold the (tiny) residual into the centre tap
     assert abs(resid) < 4 * N, resid
-    assert np.abs(q).max() < 2 ** 31 - 2 ** 23     # four balanced int8 limbs (MFMA kernel) must hold every tap
+    assert np.abs(q).max() < 2 ** 23 - 2 ** 15     # q * 2^7 must fit four balanced int8 limbs (MFMA kernel)
     assert 2 * int(q.sum()) == 1 << S
     assert 2 * int(np.abs(q).sum()) < 1 << 52
     return S, q
