@@ -90,12 +90,6 @@ __device__ __forceinline__ u32x4 load_chunk(const StreamJob* jobs, const StreamJ
     return u32x4{w[0], w[1], w[2], w[3]};
 }
 
-struct ChainOps {          // operands of one K pair (two K steps) for a channel pair
-    v4i B0, B1;            // tap fragments of K steps 2u, 2u+1
-    uint32_t lo0, lo1;     // row word u of channel 0 / 1
-    uint32_t hi0, hi1;     // row word u+1 (for the in-register byte realignment)
-};
-
 template <int MB>
 __global__ __launch_bounds__(MFMA_MAX_THREADS) void d2d_fir_mfma_kernel(MfmaArgs m) {
     const FirArgs& a = m.f;
@@ -112,7 +106,7 @@ __global__ __launch_bounds__(MFMA_MAX_THREADS) void d2d_fir_mfma_kernel(MfmaArgs
     {   // tap fragments: L2 -> LDS once per block (two extra zero K steps for the read-ahead)
         const uint4* s = reinterpret_cast<const uint4*>(a.tables);
         uint4* d = reinterpret_cast<uint4*>(smem);
-        for (uint32_t i = tid; i < (a.ksteps + 2) * 64; i += blockDim.x) d[i] = s[i];
+        for (uint32_t i = tid; i < (a.ksteps + 4) * 64; i += blockDim.x) d[i] = s[i];
     }
     for (uint32_t c = 0; c < C; ++c) pkw[c * 64 + lane] = 0.0;
     if (lane < C) {   // per-channel dither keys: global -> this wave's LDS once
@@ -148,11 +142,31 @@ __global__ __launch_bounds__(MFMA_MAX_THREADS) void d2d_fir_mfma_kernel(MfmaArgs
     u32x4 pf[MFMA_PF];
     uint32_t wt = blockIdx.x * m.nwaves + wave;
     auto tile_abeg = [&](uint32_t w) -> int32_t { return (int32_t)((first0 + (int64_t)w * (256 * MB)) & ~(int64_t)15); };
+    // planar layout with power-of-two blocks of >= 16 bytes: a staged range that lies inside the
+    // call's FULL blocks needs no per-chunk checks (wave-uniform test, a handful of VALU per chunk)
+    const uint32_t Bsz = a.B, Lcall = (uint32_t)j0.L;
+    const bool pow2B = Bsz >= 16 && (Bsz & (Bsz - 1)) == 0;
+    const uint32_t bshift = pow2B ? 31 - __builtin_clz(Bsz) : 0;
+    const uint32_t full_bytes = pow2B ? (Lcall >> bshift) << bshift : 0;   // bytes per channel in full blocks
+    uint32_t pf_cb[MFMA_PF];                                               // channel offset inside a block group
+#pragma unroll
+    for (int i = 0; i < MFMA_PF; ++i) pf_cb[i] = pf_c[i] << bshift;
     auto prefetch = [&](uint32_t w) {
         const int32_t ab = tile_abeg(w);
+        if (pow2B && ab >= 0 && (uint32_t)ab + m.span <= full_bytes) {
 #pragma unroll
-        for (int i = 0; i < MFMA_PF; ++i)
-            if (lane + 64 * i < nch) pf[i] = load_chunk(jobs, j0, pf_c[i], ab + (int32_t)(pf_q[i] * 16), C, a.B, a.keep);
+            for (int i = 0; i < MFMA_PF; ++i)
+                if (lane + 64 * i < nch) {
+                    const uint32_t j = (uint32_t)ab + pf_q[i] * 16;
+                    const uint64_t off = (uint64_t)((j >> bshift) * C) << bshift;   // start of the block group
+                    const uint8_t* p = j0.in + off + (pf_cb[i] + (j & (Bsz - 1)));
+                    pf[i] = *reinterpret_cast<D2D_GLOBAL const u32x4*>(as_global(p));
+                }
+        } else {
+#pragma unroll
+            for (int i = 0; i < MFMA_PF; ++i)
+                if (lane + 64 * i < nch) pf[i] = load_chunk(jobs, j0, pf_c[i], ab + (int32_t)(pf_q[i] * 16), C, a.B, a.keep);
+        }
     };
     if (wt < nwt) prefetch(wt);
 
@@ -191,38 +205,47 @@ __global__ __launch_bounds__(MFMA_MAX_THREADS) void d2d_fir_mfma_kernel(MfmaArgs
             const uint8_t* prow = wbase + pr * m.ppair + rbase;
             v16i acc0 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
             v16i acc1 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-            auto load_ops = [&](ChainOps& o, uint32_t u) {
-                const uint32_t t0 = X0 + u, t1 = t0 + 1;
-                const u32x2 w0 = *reinterpret_cast<const u32x2*>(prow + 8u * (t0 + (t0 >> ls)));
-                const u32x2 w1 = *reinterpret_cast<const u32x2*>(prow + 8u * (t1 + (t1 >> ls)));
-                o.lo0 = w0.x; o.lo1 = w0.y; o.hi0 = w1.x; o.hi1 = w1.y;
-                o.B0 = bp[(2 * u) * 64];
-                o.B1 = bp[(2 * u + 1) * 64];
+            auto row_word = [&](uint32_t t) -> u32x2 {      // both channels' dword t of this lane's row
+                return *reinterpret_cast<const u32x2*>(prow + 8u * (t + (t >> ls)));
             };
-            auto step = [&](const ChainOps& o) {
-                const uint32_t W0 = __builtin_amdgcn_alignbyte(o.hi0, o.lo0, sh);
-                const uint32_t W1 = __builtin_amdgcn_alignbyte(o.hi1, o.lo1, sh);
+            auto kpair = [&](const u32x2& lo, const u32x2& hi, const v4i& B0, const v4i& B1, auto two_tag) {
+                constexpr bool TWO = decltype(two_tag)::value;
+                const uint32_t W0 = __builtin_amdgcn_alignbyte(hi.x, lo.x, sh);
                 const v4i A00 = {(int)(W0 & K1), (int)(W0 & (K1 << 1)), (int)(W0 & (K1 << 2)), (int)(W0 & (K1 << 3))};
-                const v4i A10 = {(int)(W1 & K1), (int)(W1 & (K1 << 1)), (int)(W1 & (K1 << 2)), (int)(W1 & (K1 << 3))};
-                acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(o.B0, A00, acc0, 0, 0, 0);
-                if (two) acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(o.B0, A10, acc1, 0, 0, 0);
-                const v4i A01 = {(int)(W0 & (K1 << 4)), (int)(W0 & (K1 << 5)), (int)(W0 & (K1 << 6)), (int)(W0 & (K1 << 7))};
-                const v4i A11 = {(int)(W1 & (K1 << 4)), (int)(W1 & (K1 << 5)), (int)(W1 & (K1 << 6)), (int)(W1 & (K1 << 7))};
-                acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(o.B1, A01, acc0, 0, 0, 0);
-                if (two) acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(o.B1, A11, acc1, 0, 0, 0);
-            };
-            {   // operands of the next K pair are fetched before this pair's MFMAs (ping-pong sets)
-                ChainOps P, Q;
-                load_ops(P, 0);
-                uint32_t u = 0;
-                for (; u + 2 <= U; u += 2) {
-                    load_ops(Q, u + 1);
-                    step(P);
-                    load_ops(P, u + 2);     // u + 2 == U reads the zero pair past the end
-                    step(Q);
+                acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(B0, A00, acc0, 0, 0, 0);
+                uint32_t W1 = 0;
+                if constexpr (TWO) {
+                    W1 = __builtin_amdgcn_alignbyte(hi.y, lo.y, sh);
+                    const v4i A10 = {(int)(W1 & K1), (int)(W1 & (K1 << 1)), (int)(W1 & (K1 << 2)), (int)(W1 & (K1 << 3))};
+                    acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(B0, A10, acc1, 0, 0, 0);
                 }
-                if (u < U) step(P);
-            }
+                const v4i A01 = {(int)(W0 & (K1 << 4)), (int)(W0 & (K1 << 5)), (int)(W0 & (K1 << 6)), (int)(W0 & (K1 << 7))};
+                acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(B1, A01, acc0, 0, 0, 0);
+                if constexpr (TWO) {
+                    const v4i A11 = {(int)(W1 & (K1 << 4)), (int)(W1 & (K1 << 5)), (int)(W1 & (K1 << 6)), (int)(W1 & (K1 << 7))};
+                    acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(B1, A11, acc1, 0, 0, 0);
+                }
+            };
+            auto chain = [&](auto two_tag) {
+                // Two K pairs per trip.  Row words slide (w0,w1 -> w2,w3), tap fragments ping-pong;
+                // everything the NEXT trip needs is requested before this trip's MFMAs issue.  One
+                // zero fragment pair and spare row words exist past the end for the read-ahead.
+                u32x2 w0 = row_word(X0), w1 = row_word(X0 + 1);
+                v4i Ba0 = bp[0], Ba1 = bp[64];
+                uint32_t u = 0;
+                const v4i* bq = bp;
+                for (; u + 2 <= U; u += 2) {
+                    const u32x2 w2 = row_word(X0 + u + 2), w3 = row_word(X0 + u + 3);
+                    const v4i Bb0 = bq[2 * 64], Bb1 = bq[3 * 64];
+                    const v4i Bc0 = bq[4 * 64], Bc1 = bq[5 * 64];
+                    bq += 4 * 64;
+                    kpair(w0, w1, Ba0, Ba1, two_tag);
+                    kpair(w1, w2, Bb0, Bb1, two_tag);
+                    w0 = w2; w1 = w3; Ba0 = Bc0; Ba1 = Bc1;
+                }
+                if (u < U) kpair(w0, w1, Ba0, Ba1, two_tag);
+            };
+            if (two) chain(std::true_type{}); else chain(std::false_type{});
 
             // ---- epilogue: lane (r, h) owns phases ph = h + 2k of row r for both channels ----
             auto finish = [&](const v16i& acc, uint32_t c, auto full_tag) {
@@ -360,7 +383,7 @@ static inline int8_t limb_of(int64_t v, int l) {
 // as 2^p (p = 7: -128): the table holds q * 2^(7-p), negated for p = 7.
 std::vector<int8_t> build_mfma_tables(const d2d_filter_def& f, const MfmaLayout& g, bool msb_first) {
     const int U = g.ksteps / 2;
-    std::vector<int8_t> t((size_t)(g.ksteps + 2) * 64 * 16, 0);   // +2 zero steps: the kernel's read-ahead
+    std::vector<int8_t> t((size_t)(g.ksteps + 4) * 64 * 16, 0);   // +4 zero steps: the kernel's read-ahead
     for (int ks = 0; ks < g.ksteps; ++ks)
         for (int l = 0; l < 64; ++l) {
             const int row = l & 31, h = l >> 5, ph = row >> 2, limb = row & 3;
@@ -401,10 +424,10 @@ static void mfma_geometry(const FirArgs& a, const MfmaLayout& g, MfmaArgs& m, si
     m.ls = (uint32_t)ls;
     // logical staged bytes per channel: 16-byte alignment slack + 31 row strides + one row window
     // (+3 dwords read ahead) + slack for the in-register byte realignment
-    m.span = (16u + 31u * 8u * MB + (2 * m.U + 4) * 4u + 16u + 15u) & ~15u;
+    m.span = (16u + 31u * 8u * MB + (2 * m.U + 5) * 4u + 16u + 15u) & ~15u;
     const uint32_t ldw = m.span / 4;
     m.ppair = ((2u * (ldw + (ldw >> ls) + 2u)) * 4u + 15u) & ~15u;
-    m.off_waves = ((uint32_t)g.ksteps + 2u) * 1024u;
+    m.off_waves = ((uint32_t)g.ksteps + 4u) * 1024u;
     m.off_out = ((C + 1) / 2) * m.ppair;
     m.off_pk = m.off_out + ((256u * C * a.epi.sample_bytes + 15u) & ~15u);
     m.wave_lds = m.off_pk + C * 64u * 8u + ((C * 16u + 15u) & ~15u);   // peaks + per-channel dither keys
