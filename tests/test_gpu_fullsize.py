@@ -1,0 +1,101 @@
+"""Full-size (BASELINE.json sizes) checks through size-independent properties, where the CPU oracle
+would take too long to be the comparator: the two kernels against each other, streaming against
+one-shot, exact DC levels, shift invariance.  A 1/16 slice of every file is still checked bit-exactly
+against the oracle."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from helpers import pack_layout, synth
+
+pytestmark = pytest.mark.gpu
+
+SECONDS = 60
+BLOCKS = int(round(SECONDS * 2822400 / 8 / 4096))     # 4096-byte blocks per channel in a 60 s DSD64 file
+
+
+def _run_batch(engine_lib, files, kw, kernel, chunks=1):
+    import torch
+    n = len(files)
+    e = engine_lib.Engine(n_files=n, kernel=kernel, **kw)
+    bpc = files[0].size // kw["channels"]
+    d_in = [torch.from_numpy(f).cuda() for f in files]
+    outs = [[] for _ in range(n)]
+    blocks = bpc // 4096
+    per = (blocks + chunks - 1) // chunks
+    for k in range(chunks):
+        b0, b1 = k * per, min(blocks, (k + 1) * per)
+        if b0 >= b1:
+            break
+        nb = (b1 - b0) * 4096
+        frames = e.next_frames(nb)
+        d_out = [torch.empty(frames * e.frame_bytes + 16, dtype=torch.uint8, device="cuda") for _ in range(n)]
+        ios = (engine_lib.FileIO * n)()
+        for f in range(n):
+            # planar blocks are contiguous groups of C*4096 bytes: a block range is a byte range
+            ios[f].dsd = d_in[f].data_ptr() + b0 * 4096 * kw["channels"]
+            ios[f].bytes_per_channel = nb
+            ios[f].pcm = d_out[f].data_ptr()
+            ios[f].pcm_capacity_bytes = frames * e.frame_bytes
+        e.translate_batch_device(ios, torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        for f in range(n):
+            outs[f].append(d_out[f][:frames * e.frame_bytes].cpu().numpy())
+    return [np.concatenate(o) for o in outs], e
+
+
+def test_c4_full_length_files_kernels_agree_and_stream(engine_lib, oracle_mod):
+    """config 4 shape: DSD64 stereo 60 s files -> 24-bit 88.2 kHz TPDF"""
+    kw = dict(dsd_rate=1, output_rate=88200, channels=2, fmt="P", endianness="L", block_size=4096, filter="E",
+              bit_depth=24, dither="T", seed=206)
+    nbytes = BLOCKS * 4096
+    files = [pack_layout([synth("sine", nbytes, seed=f, freq=1000.0 + f), synth("pink", nbytes, seed=50 + f, amp=0.098)], "P", 4096)
+             for f in range(3)]
+    mf, e_m = _run_batch(engine_lib, files, kw, 2)
+    lu, e_l = _run_batch(engine_lib, files, kw, 1)
+    st, e_s = _run_batch(engine_lib, files, kw, 2, chunks=7)
+    frames = BLOCKS * 4096 * 8 // 32
+    for f in range(3):
+        assert mf[f].size == frames * 6
+        assert np.array_equal(mf[f], lu[f])            # matrix-core kernel == LUT kernel, every byte
+        assert np.array_equal(mf[f], st[f])            # 7 streaming calls == one shot
+        for c in range(2):
+            assert e_m.peak(c, f) == e_l.peak(c, f) == e_s.peak(c, f)
+        # a slice against the oracle (the first 1/16 of the file)
+        sl = (BLOCKS // 16) * 4096 * 2
+        r, rf = oracle_mod.Oracle(**kw).translate(files[f][:sl])
+        assert np.array_equal(mf[f][:rf * 6], r)
+
+
+def test_c2_full_length_float_and_dc_levels(engine_lib):
+    """config 2 shape: DSD64 stereo -> f32 352.8 kHz, no dither; ones/zeros channels give exactly +-1"""
+    kw = dict(dsd_rate=1, output_rate=352800, channels=2, fmt="P", endianness="L", block_size=4096, filter="E",
+              bit_depth=32, dither="X")
+    nbytes = (BLOCKS // 4) * 4096
+    files = [pack_layout([np.full(nbytes, 0xFF, np.uint8), np.zeros(nbytes, np.uint8)], "P", 4096)]
+    peaks = []
+    for kernel in (1, 2):
+        out, e = _run_batch(engine_lib, files, kw, kernel)
+        v = out[0].view(np.float32).reshape(-1, 2)
+        assert v.shape[0] == nbytes
+        assert (v[64:, 0] == 1.0).all() and (v[64:, 1] == -1.0).all()
+        peaks.append((e.peak(0), e.peak(1)))            # includes the step from the idle history: > 1
+        assert 1.0 <= peaks[-1][0] < 1.2 and 1.0 <= peaks[-1][1] < 1.2
+    assert peaks[0] == peaks[1]
+
+
+def test_c3_dsd128_shift_invariance(engine_lib):
+    """config 3 shape: DSD128 -> 24-bit 88.2 kHz.  Without dither the converter is time invariant: the
+    same stream delayed by k*M bits gives the same samples k frames later."""
+    kw = dict(dsd_rate=2, output_rate=88200, channels=2, fmt="P", endianness="L", block_size=4096, filter="E",
+              bit_depth=24, dither="X")
+    nbytes = 4096 * 512
+    a = [synth("sine", nbytes, seed=1, dsd_rate=2), synth("pink", nbytes, seed=2, amp=0.098, dsd_rate=2)]
+    k = 4096 // 8                                       # one whole block = 512 frames at M = 64
+    idle = np.full(4096, 0x96, np.uint8)                # the LSB-first idle byte the engine starts from
+    b = [np.concatenate([idle, ch[:-4096]]) for ch in a]
+    oa, _ = _run_batch(engine_lib, [pack_layout(a, "P", 4096)], kw, 2)
+    ob, _ = _run_batch(engine_lib, [pack_layout(b, "P", 4096)], kw, 2)
+    fa, fb = oa[0].reshape(-1, 6), ob[0].reshape(-1, 6)
+    assert np.array_equal(fb[k:], fa[:-k])

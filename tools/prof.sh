@@ -1,7 +1,6 @@
 #!/bin/bash
 # usage (on the GPU box, from the repo root): tools/prof.sh <tag> [bench args...]
 # 1) kernel-trace + stats  2) PMC passes (separate runs, as the pool requires)
-set -e
 TAG=$1; shift
 cd /tmp && export TMPDIR=/tmp
 OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_$TAG
