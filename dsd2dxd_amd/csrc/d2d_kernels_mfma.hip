@@ -91,7 +91,7 @@ __device__ __forceinline__ u32x4 load_chunk(const StreamJob* jobs, const StreamJ
 }
 
 template <int MB>
-__global__ __launch_bounds__(MFMA_MAX_THREADS) void d2d_fir_mfma_kernel(MfmaArgs m) {
+__global__ __launch_bounds__(MFMA_MAX_THREADS, 4) void d2d_fir_mfma_kernel(MfmaArgs m) {
     const FirArgs& a = m.f;
     extern __shared__ __align__(16) unsigned char smem[];
     const uint32_t C = a.epi.channels, sb = a.epi.sample_bytes, fbytes = sb * C;
