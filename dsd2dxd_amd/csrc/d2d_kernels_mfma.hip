@@ -103,10 +103,14 @@ __global__ __launch_bounds__(MFMA_MAX_THREADS, 4) void d2d_fir_mfma_kernel(MfmaA
     const StreamJob* jobs = a.jobs + (size_t)blockIdx.y * C;
     const StreamJob j0 = jobs[0];          // in, L, e0, n0, nout are common to a file's channels
 
-    {   // tap fragments: L2 -> LDS once per block (two extra zero K steps for the read-ahead)
-        const uint4* s = reinterpret_cast<const uint4*>(a.tables);
-        uint4* d = reinterpret_cast<uint4*>(smem);
-        for (uint32_t i = tid; i < (a.ksteps + 4) * 64; i += blockDim.x) d[i] = s[i];
+    const int64_t first0 = j0.e0 - (int64_t)a.Wb;          // first byte of output 0's window
+    const uint32_t d = (uint32_t)(first0 & 15);
+    {   // tap fragments: L2 -> LDS once per block (six extra zero K steps for the read-ahead).  The
+        // table comes in four variants, one per byte misalignment of the window inside its first
+        // LDS dword: the row words are used as they lie, the taps are shifted instead.
+        const uint4* s = reinterpret_cast<const uint4*>(a.tables) + (size_t)(d & 3u) * ((a.ksteps + 6) * 64);
+        uint4* dl = reinterpret_cast<uint4*>(smem);
+        for (uint32_t i = tid; i < (a.ksteps + 6) * 64; i += blockDim.x) dl[i] = s[i];
     }
     for (uint32_t c = 0; c < C; ++c) pkw[c * 64 + lane] = 0.0;
     if (lane < C) {   // per-channel dither keys: global -> this wave's LDS once
@@ -124,9 +128,6 @@ __global__ __launch_bounds__(MFMA_MAX_THREADS, 4) void d2d_fir_mfma_kernel(MfmaA
     const uint32_t npairs = (C + 1) >> 1;
     // The staging geometry does not change from wave-tile to wave-tile (a wave-tile advances the
     // stream by 256*MB bytes, a multiple of 16): chunk -> (channel, LDS address) once.
-    const int64_t first0 = j0.e0 - (int64_t)a.Wb;          // first byte of output 0's window
-    const uint32_t d = (uint32_t)(first0 & 15);
-    const uint32_t sh = d & 3u;
     uint32_t pf_c[MFMA_PF], pf_q[MFMA_PF], pf_w[MFMA_PF][4];
     auto lds_word_addr = [&](uint32_t c, uint32_t Ld) -> uint32_t {   // byte offset of staged dword Ld of channel c
         return (c >> 1) * m.ppair + (2u * (Ld + (Ld >> ls)) + (c & 1u)) * 4u;
@@ -208,14 +209,12 @@ __global__ __launch_bounds__(MFMA_MAX_THREADS, 4) void d2d_fir_mfma_kernel(MfmaA
             auto row_word = [&](uint32_t t) -> u32x2 {      // both channels' dword t of this lane's row
                 return *reinterpret_cast<const u32x2*>(prow + 8u * (t + (t >> ls)));
             };
-            auto kpair = [&](const u32x2& lo, const u32x2& hi, const v4i& B0, const v4i& B1, auto two_tag) {
+            auto kpair = [&](const u32x2& w, const v4i& B0, const v4i& B1, auto two_tag) {
                 constexpr bool TWO = decltype(two_tag)::value;
-                const uint32_t W0 = __builtin_amdgcn_alignbyte(hi.x, lo.x, sh);
+                const uint32_t W0 = w.x, W1 = w.y;
                 const v4i A00 = {(int)(W0 & K1), (int)(W0 & (K1 << 1)), (int)(W0 & (K1 << 2)), (int)(W0 & (K1 << 3))};
                 acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(B0, A00, acc0, 0, 0, 0);
-                uint32_t W1 = 0;
                 if constexpr (TWO) {
-                    W1 = __builtin_amdgcn_alignbyte(hi.y, lo.y, sh);
                     const v4i A10 = {(int)(W1 & K1), (int)(W1 & (K1 << 1)), (int)(W1 & (K1 << 2)), (int)(W1 & (K1 << 3))};
                     acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(B0, A10, acc1, 0, 0, 0);
                 }
@@ -227,23 +226,22 @@ __global__ __launch_bounds__(MFMA_MAX_THREADS, 4) void d2d_fir_mfma_kernel(MfmaA
                 }
             };
             auto chain = [&](auto two_tag) {
-                // Two K pairs per trip.  Row words slide (w0,w1 -> w2,w3), tap fragments ping-pong;
-                // everything the NEXT trip needs is requested before this trip's MFMAs issue.  One
-                // zero fragment pair and spare row words exist past the end for the read-ahead.
+                // Two K pairs per trip; everything the NEXT trip needs (two row words, four tap
+                // fragments) is requested before this trip's MFMAs issue.  Zero fragments and spare
+                // row words exist past the end for the read-ahead.
                 u32x2 w0 = row_word(X0), w1 = row_word(X0 + 1);
-                v4i Ba0 = bp[0], Ba1 = bp[64];
+                v4i Ba0 = bp[0], Ba1 = bp[64], Bb0 = bp[2 * 64], Bb1 = bp[3 * 64];
                 uint32_t u = 0;
                 const v4i* bq = bp;
                 for (; u + 2 <= U; u += 2) {
                     const u32x2 w2 = row_word(X0 + u + 2), w3 = row_word(X0 + u + 3);
-                    const v4i Bb0 = bq[2 * 64], Bb1 = bq[3 * 64];
-                    const v4i Bc0 = bq[4 * 64], Bc1 = bq[5 * 64];
+                    const v4i Bc0 = bq[4 * 64], Bc1 = bq[5 * 64], Bd0 = bq[6 * 64], Bd1 = bq[7 * 64];
                     bq += 4 * 64;
-                    kpair(w0, w1, Ba0, Ba1, two_tag);
-                    kpair(w1, w2, Bb0, Bb1, two_tag);
-                    w0 = w2; w1 = w3; Ba0 = Bc0; Ba1 = Bc1;
+                    kpair(w0, Ba0, Ba1, two_tag);
+                    kpair(w1, Bb0, Bb1, two_tag);
+                    w0 = w2; w1 = w3; Ba0 = Bc0; Ba1 = Bc1; Bb0 = Bd0; Bb1 = Bd1;
                 }
-                if (u < U) kpair(w0, w1, Ba0, Ba1, two_tag);
+                if (u < U) kpair(w0, Ba0, Ba1, two_tag);
             };
             if (two) chain(std::true_type{}); else chain(std::false_type{});
 
@@ -358,7 +356,7 @@ bool mfma_supported(int M, int N) {
 MfmaLayout mfma_layout(int M, int N) {
     MfmaLayout g;
     g.M = M; g.N = N;
-    const int wd = (N + 7 * M + 31) / 32;   // dwords of one row's window
+    const int wd = (N + 7 * M + 24 + 31) / 32;   // dwords of one row's window (+ up to 3 bytes of misalignment)
     const int U = (wd + 1) / 2;
     g.ksteps = 2 * U;
     return g;
@@ -377,30 +375,32 @@ static inline int8_t limb_of(int64_t v, int l) {
     return dgt;
 }
 
-// Tap fragments [ksteps + 2][64 lanes][16 bytes].  Lane l supplies matrix row (l & 31) = 4*phase + limb
+// Tap fragments [4 byte shifts][ksteps + 6][64 lanes][16 bytes].  Lane l supplies matrix row (l & 31) = 4*phase + limb
 // for the K slots (l >> 5)*16 + j; slot (ks, h, j) reads bit `wb` of the row window (see the
 // kernel's A00/A01), which sits at bit position p = wb & 7 of its stream byte and therefore arrives
 // as 2^p (p = 7: -128): the table holds q * 2^(7-p), negated for p = 7.
 std::vector<int8_t> build_mfma_tables(const d2d_filter_def& f, const MfmaLayout& g, bool msb_first) {
     const int U = g.ksteps / 2;
-    std::vector<int8_t> t((size_t)(g.ksteps + 4) * 64 * 16, 0);   // +4 zero steps: the kernel's read-ahead
-    for (int ks = 0; ks < g.ksteps; ++ks)
-        for (int l = 0; l < 64; ++l) {
-            const int row = l & 31, h = l >> 5, ph = row >> 2, limb = row & 3;
-            for (int j = 0; j < 16; ++j) {
-                const int p = 4 * (ks & 1) + (j >> 2);                        // register v = j>>2 of step ks
-                const int wb = 32 * (h * U + (ks >> 1)) + 8 * (j & 3) + p;     // bit of the row window
-                const int tau = msb_first ? (wb & ~7) + 7 - (wb & 7) : wb;     // its time index
-                const int tap = tau - ph * g.M;
-                int8_t v = 0;
-                if (tap >= 0 && tap < f.ntaps) {
-                    int64_t q = tap_q(f, tap);
-                    q = p == 7 ? -q : q * (int64_t)(1 << (7 - p));
-                    v = limb_of(q, limb);
+    const size_t per = (size_t)(g.ksteps + 6) * 64 * 16;           // +6 zero steps: the kernel's read-ahead
+    std::vector<int8_t> t(4 * per, 0);
+    for (int sh = 0; sh < 4; ++sh)                                  // window starts `sh` bytes into its first dword
+        for (int ks = 0; ks < g.ksteps; ++ks)
+            for (int l = 0; l < 64; ++l) {
+                const int row = l & 31, h = l >> 5, ph = row >> 2, limb = row & 3;
+                for (int j = 0; j < 16; ++j) {
+                    const int p = 4 * (ks & 1) + (j >> 2);                        // register v = j>>2 of step ks
+                    const int wb = 32 * (h * U + (ks >> 1)) + 8 * (j & 3) + p;     // bit of the LDS row words
+                    const int tau = (msb_first ? (wb & ~7) + 7 - (wb & 7) : wb) - 8 * sh;   // its time index in the window
+                    const int tap = tau - ph * g.M;
+                    int8_t v = 0;
+                    if (tau >= 0 && tap >= 0 && tap < f.ntaps) {
+                        int64_t q = tap_q(f, tap);
+                        q = p == 7 ? -q : q * (int64_t)(1 << (7 - p));
+                        v = limb_of(q, limb);
+                    }
+                    t[sh * per + ((size_t)ks * 64 + l) * 16 + j] = v;
                 }
-                t[((size_t)ks * 64 + l) * 16 + j] = v;
             }
-        }
     return t;
 }
 
@@ -427,7 +427,7 @@ static void mfma_geometry(const FirArgs& a, const MfmaLayout& g, MfmaArgs& m, si
     m.span = (16u + 31u * 8u * MB + (2 * m.U + 5) * 4u + 16u + 15u) & ~15u;
     const uint32_t ldw = m.span / 4;
     m.ppair = ((2u * (ldw + (ldw >> ls) + 2u)) * 4u + 15u) & ~15u;
-    m.off_waves = ((uint32_t)g.ksteps + 4u) * 1024u;
+    m.off_waves = ((uint32_t)g.ksteps + 6u) * 1024u;
     m.off_out = ((C + 1) / 2) * m.ppair;
     m.off_pk = m.off_out + ((256u * C * a.epi.sample_bytes + 15u) & ~15u);
     m.wave_lds = m.off_pk + C * 64u * 8u + ((C * 16u + 15u) & ~15u);   // peaks + per-channel dither keys
