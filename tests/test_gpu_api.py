@@ -1,0 +1,122 @@
+"""GPU tests of the rest of the C ABI: ragged batches, table blob export/import (the multi-GPU
+broadcast path), the whole-stream driver with cancel and progress, reset, error codes at run time."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from helpers import pack_layout, random_bytes, synth
+
+pytestmark = pytest.mark.gpu
+
+KW = dict(dsd_rate=1, output_rate=88200, channels=2, fmt="P", endianness="L", block_size=4096, filter="E",
+          bit_depth=24, dither="T", seed=77)
+
+
+@pytest.mark.parametrize("kernel", [1, 2])
+def test_ragged_batch(engine_lib, oracle_mod, kernel):
+    """files of different lengths (one of them empty) advance together; each matches its own oracle"""
+    import torch
+    lens = [4096 * 5, 0, 4096 * 2 + 300, 4096 * 9, 40]
+    files = [pack_layout([random_bytes(n, 10 + i), random_bytes(n, 20 + i)], "P", 4096) for i, n in enumerate(lens)]
+    e = engine_lib.Engine(n_files=len(lens), kernel=kernel, **KW)
+    oracles = [oracle_mod.Oracle(**KW) for _ in lens]
+    for rnd in range(2):                               # two calls: state carries per file
+        d_in = [torch.from_numpy(f).cuda() if f.size else torch.zeros(16, dtype=torch.uint8, device="cuda") for f in files]
+        d_out = [torch.zeros(e.next_frames(n, file=i) * e.frame_bytes + 16, dtype=torch.uint8, device="cuda") for i, n in enumerate(lens)]
+        ios = (engine_lib.FileIO * len(lens))()
+        for i, n in enumerate(lens):
+            ios[i].dsd = d_in[i].data_ptr(); ios[i].bytes_per_channel = n
+            ios[i].pcm = d_out[i].data_ptr(); ios[i].pcm_capacity_bytes = d_out[i].numel()
+        e.translate_batch_device(ios, torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        for i in range(len(lens)):
+            r, rf = oracles[i].translate(files[i])
+            assert ios[i].frames_out == rf
+            assert np.array_equal(d_out[i][:rf * e.frame_bytes].cpu().numpy(), r[:rf * e.frame_bytes])
+
+
+@pytest.mark.parametrize("kernel", [1, 2])
+@pytest.mark.parametrize("out_rate", [88200, 96000])
+def test_table_blob_roundtrip(engine_lib, oracle_mod, kernel, out_rate):
+    """rank 0 exports its tables, another engine adopts them and still converts correctly;
+    a blob from a different configuration is refused"""
+    import torch
+    kw = dict(KW, output_rate=out_rate)
+    a = engine_lib.Engine(kernel=kernel, **kw)
+    b = engine_lib.Engine(kernel=kernel, **kw)
+    nb = a.tables_bytes()
+    assert nb == b.tables_bytes() and nb > 1024
+    blob = torch.zeros(nb, dtype=torch.uint8, device="cuda")
+    a.tables_export_device(blob.data_ptr(), nb)
+    torch.cuda.synchronize()
+    b.tables_import_device(blob.data_ptr(), nb)
+    buf = pack_layout([synth("sine", 4096 * 4, seed=1), synth("pink", 4096 * 4, seed=2, amp=0.098)], "P", 4096)
+    g, gf = b.translate(buf)
+    r, rf = oracle_mod.Oracle(**kw).translate(buf)
+    assert gf == rf and np.array_equal(g, r[:rf * 6])
+    other = engine_lib.Engine(kernel=kernel, **dict(kw, endianness="M"))
+    with pytest.raises(engine_lib.D2DError) as ei:
+        other.tables_import_device(blob.data_ptr(), nb)
+    assert ei.value.code == -1
+    # a corrupted table must change the output (i.e. the imported bytes are really what runs)
+    blob[256:(3 * nb) // 4] = 0      # (the MFMA table holds four byte-shift variants; wipe most of them)
+    b2 = engine_lib.Engine(kernel=kernel, **kw)
+    b2.tables_import_device(blob.data_ptr(), nb)
+    g2, _ = b2.translate(buf)
+    assert not np.array_equal(g2, g)
+
+
+def test_convert_stream_progress_and_cancel(engine_lib, oracle_mod):
+    nbytes = 4096 * 40
+    chans = [synth("sine", nbytes, seed=3), synth("pink", nbytes, seed=4, amp=0.098)]
+    whole = pack_layout(chans, "P", 4096)
+    pos = [0]
+    chunk_blocks = 8
+
+    def read(cap):
+        assert cap % 4096 == 0
+        a = pos[0]
+        b = min(nbytes, a + min(cap, chunk_blocks * 4096))
+        pos[0] = b
+        return pack_layout([c[a:b] for c in chans], "P", 4096).tobytes() if b > a else b""
+
+    out, prog = [], []
+    e = engine_lib.Engine(**KW)
+    e.convert_stream(read, out.append, total_bytes_per_channel=nbytes, chunk_bytes_per_channel=chunk_blocks * 4096,
+                     progress=prog.append)
+    r, rf = oracle_mod.Oracle(**KW).translate(whole)
+    assert np.array_equal(np.frombuffer(b"".join(out), dtype=np.uint8), r[:rf * 6])
+    assert prog[-1] == 100.0 and all(p < 100.0 for p in prog[:-1]) and prog == sorted(prog)   # src/main.rs:417-418
+    # cancel: the flag is polled between chunks (src/main.rs:38,429)
+    pos[0] = 0
+    flag = C.c_int(0)
+    seen = []
+
+    def write_then_cancel(b):
+        seen.append(len(b))
+        flag.value = 1
+
+    e2 = engine_lib.Engine(**KW)
+    with pytest.raises(engine_lib.D2DError) as ei:
+        e2.convert_stream(read, write_then_cancel, total_bytes_per_channel=nbytes,
+                          chunk_bytes_per_channel=chunk_blocks * 4096, cancel=flag)
+    assert ei.value.code == -30 and len(seen) == 1
+
+
+def test_runtime_errors(engine_lib):
+    e = engine_lib.Engine(**KW)
+    L = engine_lib.lib()
+    buf = np.zeros(4096 * 2, dtype=np.uint8)
+    out = np.zeros(16, dtype=np.uint8)
+    fr = C.c_size_t()
+    rc = L.d2d_translate(e._h, buf.ctypes.data, 4096, out.ctypes.data, out.size, C.byref(fr))
+    assert rc == -20 and b"too small" in L.d2d_last_error(e._h)          # D2D_ERR_CAPACITY
+    eb = engine_lib.Engine(n_files=2, **KW)
+    rc = L.d2d_translate(eb._h, buf.ctypes.data, 2048, out.ctypes.data, out.size, C.byref(fr))
+    assert rc == -40                                                     # single-file entry point on a batch engine
+    e.reset()
+    g1, _ = e.translate(buf)
+    e.reset()
+    g2, _ = e.translate(buf)
+    assert np.array_equal(g1, g2)
