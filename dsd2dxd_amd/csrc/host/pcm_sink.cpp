@@ -1,0 +1,246 @@
+#include "pcm_sink.h"
+
+#include <math.h>
+#include <string.h>
+
+namespace d2dhost {
+
+const char* output_extension(OutputType t) {
+    switch (t) {
+        case OutputType::Aiff: return "aif";
+        case OutputType::Aifc: return "aifc";
+        case OutputType::Wav: return "wav";
+        case OutputType::Flac: return "flac";
+        default: return "pcm";
+    }
+}
+
+static void put_le32(uint8_t* p, uint32_t v) { p[0] = v; p[1] = v >> 8; p[2] = v >> 16; p[3] = v >> 24; }
+static void put_le16(uint8_t* p, uint16_t v) { p[0] = (uint8_t)v; p[1] = (uint8_t)(v >> 8); }
+static void put_be32(uint8_t* p, uint32_t v) { p[3] = v; p[2] = v >> 8; p[1] = v >> 16; p[0] = v >> 24; }
+static void put_be16(uint8_t* p, uint16_t v) { p[1] = (uint8_t)v; p[0] = (uint8_t)(v >> 8); }
+
+namespace {
+
+struct RawSink : PcmSink {
+    FILE* f;
+    explicit RawSink(FILE* fp) : f(fp) {}
+    std::string write(const uint8_t* p, size_t n) override { return fwrite(p, 1, n, f) == n ? "" : "short write"; }
+    std::string close() override { fflush(f); return ""; }
+};
+
+struct WavSink : PcmSink {
+    FILE* f; uint32_t ch, rate, bits; uint64_t data = 0; size_t hdr = 0;
+    std::string begin() {
+        const uint32_t cont = bits == 16 ? 16 : (bits == 32 ? 32 : 24);
+        const bool ext = bits == 20 || ch > 2;                      // valid-bits / channel mask need EXTENSIBLE
+        uint8_t h[68]; memset(h, 0, sizeof(h));
+        memcpy(h, "RIFF", 4); memcpy(h + 8, "WAVE", 4); memcpy(h + 12, "fmt ", 4);
+        const uint32_t fmtsz = ext ? 40 : 16;
+        put_le32(h + 16, fmtsz);
+        put_le16(h + 20, ext ? 0xFFFE : (bits == 32 ? 3 : 1));
+        put_le16(h + 22, (uint16_t)ch); put_le32(h + 24, rate);
+        put_le32(h + 28, rate * ch * cont / 8); put_le16(h + 32, (uint16_t)(ch * cont / 8)); put_le16(h + 34, (uint16_t)cont);
+        size_t o = 36;
+        if (ext) {
+            put_le16(h + 36, 22); put_le16(h + 38, (uint16_t)(bits == 32 ? 32 : bits)); put_le32(h + 40, 0);
+            static const uint8_t guid_tail[14] = {0x00, 0x00, 0x00, 0x00, 0x10, 0x00, 0x80, 0x00, 0x00, 0xAA, 0x00, 0x38, 0x9B, 0x71};
+            put_le16(h + 44, bits == 32 ? 3 : 1); memcpy(h + 46, guid_tail, 14);
+            o = 60;
+        }
+        memcpy(h + o, "data", 4); o += 8;
+        hdr = o;
+        return fwrite(h, 1, o, f) == o ? "" : "short write";
+    }
+    std::string write(const uint8_t* p, size_t n) override { data += n; return fwrite(p, 1, n, f) == n ? "" : "short write"; }
+    std::string close() override {
+        if (data & 1) fputc(0, f);
+        if (data + hdr > 0xFFFFFFFFull) { fclose(f); return "WAV output exceeds 4 GiB"; }
+        uint8_t v[4];
+        put_le32(v, (uint32_t)(hdr - 8 + data + (data & 1))); fseek(f, 4, SEEK_SET); fwrite(v, 1, 4, f);
+        put_le32(v, (uint32_t)data); fseek(f, (long)hdr - 4, SEEK_SET); fwrite(v, 1, 4, f);
+        return fclose(f) == 0 ? "" : "close failed";
+    }
+};
+
+// 80-bit IEEE extended, big-endian (AIFF sample rate)
+static void put_ext80(uint8_t* p, double v) {
+    memset(p, 0, 10);
+    if (v <= 0) return;
+    int e; double m = frexp(v, &e);                   // v = m * 2^e, 0.5 <= m < 1
+    uint64_t mant = (uint64_t)ldexp(m, 64);
+    uint16_t ex = (uint16_t)(e - 1 + 16383);
+    put_be16(p, ex);
+    for (int i = 0; i < 8; ++i) p[2 + i] = (uint8_t)(mant >> (56 - 8 * i));
+}
+
+struct AiffSink : PcmSink {
+    FILE* f; uint32_t ch, rate, bits; bool aifc; uint64_t data = 0; size_t comm_frames_at = 0, ssnd_size_at = 0;
+    std::vector<uint8_t> tmp;
+    std::string begin() {
+        const uint32_t cont = bits == 16 ? 16 : (bits == 32 ? 32 : 24);
+        std::vector<uint8_t> h;
+        auto app = [&](const void* s, size_t n) { h.insert(h.end(), (const uint8_t*)s, (const uint8_t*)s + n); };
+        uint8_t b[16];
+        app("FORM\0\0\0\0", 8); app(aifc ? "AIFC" : "AIFF", 4);
+        if (aifc) { app("FVER", 4); put_be32(b, 4); app(b, 4); put_be32(b, 0xA2805140u); app(b, 4); }
+        app("COMM", 4);
+        const char* ctype = bits == 32 ? "fl32" : "NONE";
+        const char* cname = bits == 32 ? "\x0CIEEE 32-bit\0" : "\x0Enot compressed\0";      // pascal strings, even total
+        const size_t cname_len = bits == 32 ? 14 : 16;
+        put_be32(b, (uint32_t)(18 + (aifc ? 4 + cname_len : 0))); app(b, 4);
+        put_be16(b, (uint16_t)ch); app(b, 2);
+        comm_frames_at = h.size(); put_be32(b, 0); app(b, 4);
+        put_be16(b, (uint16_t)(bits == 20 ? 20 : cont)); app(b, 2);
+        uint8_t e80[10]; put_ext80(e80, (double)rate); app(e80, 10);
+        if (aifc) { app(ctype, 4); app(cname, cname_len); }
+        app("SSND", 4); ssnd_size_at = h.size(); put_be32(b, 0); app(b, 4); put_be32(b, 0); app(b, 4); put_be32(b, 0); app(b, 4);
+        return fwrite(h.data(), 1, h.size(), f) == h.size() ? "" : "short write";
+    }
+    std::string write(const uint8_t* p, size_t n) override {           // little-endian samples -> big-endian
+        const size_t sb = bits == 16 ? 2 : (bits == 32 ? 4 : 3);
+        tmp.resize(n);
+        for (size_t i = 0; i + sb <= n; i += sb)
+            for (size_t k = 0; k < sb; ++k) tmp[i + k] = p[i + sb - 1 - k];
+        data += n;
+        return fwrite(tmp.data(), 1, n, f) == n ? "" : "short write";
+    }
+    std::string close() override {
+        if (data & 1) fputc(0, f);
+        const size_t sb = bits == 16 ? 2 : (bits == 32 ? 4 : 3);
+        long end = ftell(f);
+        if ((uint64_t)end > 0xFFFFFFFFull) { fclose(f); return "AIFF output exceeds 4 GiB"; }
+        uint8_t v[4];
+        put_be32(v, (uint32_t)(end - 8)); fseek(f, 4, SEEK_SET); fwrite(v, 1, 4, f);
+        put_be32(v, (uint32_t)(data / (sb * ch))); fseek(f, (long)comm_frames_at, SEEK_SET); fwrite(v, 1, 4, f);
+        put_be32(v, (uint32_t)(data + 8)); fseek(f, (long)ssnd_size_at, SEEK_SET); fwrite(v, 1, 4, f);
+        return fclose(f) == 0 ? "" : "close failed";
+    }
+};
+
+// FLAC with fixed-order-2 prediction and one Rice partition per subframe (valid, modest compression;
+// the reference uses the flac-codec crate, Cargo.lock:299-307).  Integer depths only.
+struct FlacSink : PcmSink {
+    FILE* f; uint32_t ch, rate, bits; uint64_t frames = 0; uint32_t frame_no = 0;
+    static constexpr uint32_t BS = 4096;
+    std::vector<int32_t> buf;      // interleaved pending samples
+    std::vector<uint8_t> out;
+    uint32_t min_fs = 0xFFFFFF, max_fs = 0;
+    uint64_t bitacc = 0; int bitn = 0;
+    static uint8_t crc8(const uint8_t* p, size_t n) { uint8_t c = 0; for (size_t i = 0; i < n; ++i) { c ^= p[i]; for (int k = 0; k < 8; ++k) c = (uint8_t)((c & 0x80) ? (c << 1) ^ 0x07 : (c << 1)); } return c; }
+    static uint16_t crc16(const uint8_t* p, size_t n) { uint16_t c = 0; for (size_t i = 0; i < n; ++i) { c ^= (uint16_t)(p[i] << 8); for (int k = 0; k < 8; ++k) c = (uint16_t)((c & 0x8000) ? (c << 1) ^ 0x8005 : (c << 1)); } return c; }
+    void bits_put(uint64_t v, int n) {
+        while (n > 0) {
+            int take = n > 32 ? 32 : n;
+            uint64_t part = (v >> (n - take)) & ((take == 64) ? ~0ull : ((1ull << take) - 1));
+            bitacc = (bitacc << take) | part; bitn += take; n -= take;
+            while (bitn >= 8) { out.push_back((uint8_t)(bitacc >> (bitn - 8))); bitn -= 8; }
+        }
+    }
+    void bits_flush() { if (bitn) { out.push_back((uint8_t)(bitacc << (8 - bitn))); bitn = 0; } bitacc = 0; }
+    void put_utf8(uint32_t v) {
+        if (v < 0x80) { bits_put(v, 8); return; }
+        int n = v < 0x800 ? 1 : v < 0x10000 ? 2 : v < 0x200000 ? 3 : v < 0x4000000 ? 4 : 5;
+        bits_put(((0xFF00 >> (n + 1)) & 0xFF) | (v >> (6 * n)), 8);
+        for (int i = n - 1; i >= 0; --i) bits_put(0x80 | ((v >> (6 * i)) & 0x3F), 8);
+    }
+    uint32_t depth() const { return bits == 20 ? 20 : bits; }
+    std::string begin() {
+        uint8_t h[4 + 4 + 34]; memset(h, 0, sizeof(h));
+        memcpy(h, "fLaC", 4); h[4] = 0x80; h[7] = 34;                 // last metadata block: STREAMINFO
+        return fwrite(h, 1, sizeof(h), f) == sizeof(h) ? "" : "short write";
+    }
+    void encode_frame(uint32_t n) {
+        out.clear(); bitn = 0; bitacc = 0;
+        bits_put(0xFFF8, 16);                                          // sync, fixed block size
+        bits_put(n == BS ? 0xC : 0x7, 4);                              // 4096, or 16-bit (n-1) at the end of the header
+        bits_put(0x0, 4);                                              // sample rate from STREAMINFO
+        bits_put(ch - 1, 4);                                           // independent channels
+        bits_put(depth() == 16 ? 4 : depth() == 20 ? 5 : 6, 3); bits_put(0, 1);
+        put_utf8(frame_no);
+        if (n != BS) bits_put(n - 1, 16);
+        bits_flush();
+        out.push_back(crc8(out.data(), out.size()));
+        std::vector<int32_t> res(n);
+        for (uint32_t c = 0; c < ch; ++c) {
+            auto s = [&](uint32_t i) -> int64_t { return buf[(size_t)i * ch + c]; };
+            const uint32_t order = n > 2 ? 2 : 0;
+            uint64_t sum = 0;
+            for (uint32_t i = order; i < n; ++i) {
+                int64_t r = order == 2 ? s(i) - 2 * s(i - 1) + s(i - 2) : s(i);
+                res[i] = (int32_t)r; sum += (uint64_t)(r < 0 ? -r : r);
+            }
+            bool fits = true;
+            for (uint32_t i = order; i < n && fits; ++i) { int64_t r = order == 2 ? s(i) - 2 * s(i - 1) + s(i - 2) : s(i); if (r > 0x3FFFFFFF || r < -0x3FFFFFFF) fits = false; }
+            if (!fits || order == 0) {                                   // verbatim subframe
+                bits_put(0, 1); bits_put(1, 6); bits_put(0, 1);
+                for (uint32_t i = 0; i < n; ++i) bits_put((uint64_t)s(i) & ((1ull << depth()) - 1), (int)depth());
+                continue;
+            }
+            bits_put(0, 1); bits_put(8 + order, 6); bits_put(0, 1);    // fixed predictor, no wasted bits
+            for (uint32_t i = 0; i < order; ++i) bits_put((uint64_t)s(i) & ((1ull << depth()) - 1), (int)depth());
+            uint32_t k = 0;
+            const uint64_t mean = sum / (n - order ? n - order : 1);
+            while (k < 30 && (1ull << k) < mean) ++k;
+            bits_put(1, 2);                                             // residual coding method 1: 5-bit Rice parameters
+            bits_put(0, 4);                                             // partition order 0
+            bits_put(k, 5);
+            for (uint32_t i = order; i < n; ++i) {
+                uint32_t u = res[i] >= 0 ? (uint32_t)res[i] << 1 : (((uint32_t)(-(int64_t)res[i])) << 1) - 1;
+                uint32_t q = u >> k;
+                while (q >= 32) { bits_put(0, 32); q -= 32; }
+                bits_put(1, (int)q + 1);
+                if (k) bits_put(u & ((1u << k) - 1), (int)k);
+            }
+        }
+        bits_flush();
+        uint16_t c16 = crc16(out.data(), out.size());
+        out.push_back((uint8_t)(c16 >> 8)); out.push_back((uint8_t)c16);
+        fwrite(out.data(), 1, out.size(), f);
+        if (out.size() < min_fs) min_fs = (uint32_t)out.size();
+        if (out.size() > max_fs) max_fs = (uint32_t)out.size();
+        ++frame_no; frames += n;
+    }
+    std::string write(const uint8_t* p, size_t nbytes) override {
+        const size_t sb = bits == 16 ? 2 : 3;
+        for (size_t i = 0; i + sb <= nbytes; i += sb) {
+            int32_t v = sb == 2 ? (int16_t)(p[i] | (p[i + 1] << 8)) : (int32_t)((p[i] | (p[i + 1] << 8) | (p[i + 2] << 16)) << 8) >> 8;
+            if (bits == 20) v >>= 4;
+            buf.push_back(v);
+        }
+        while (buf.size() >= (size_t)BS * ch) {
+            encode_frame(BS);
+            buf.erase(buf.begin(), buf.begin() + (size_t)BS * ch);
+        }
+        return "";
+    }
+    std::string close() override {
+        if (!buf.empty()) encode_frame((uint32_t)(buf.size() / ch));
+        uint8_t si[34]; memset(si, 0, sizeof(si));
+        put_be16(si, BS); put_be16(si + 2, BS);
+        si[4] = min_fs >> 16; si[5] = min_fs >> 8; si[6] = (uint8_t)min_fs; si[7] = max_fs >> 16; si[8] = max_fs >> 8; si[9] = (uint8_t)max_fs;
+        const uint64_t v = ((uint64_t)rate << 44) | ((uint64_t)(ch - 1) << 41) | ((uint64_t)(depth() - 1) << 36) | (frames & 0xFFFFFFFFFull);
+        for (int i = 0; i < 8; ++i) si[10 + i] = (uint8_t)(v >> (56 - 8 * i));   // MD5 left zero = "not computed"
+        fseek(f, 8, SEEK_SET); fwrite(si, 1, 34, f);
+        return fclose(f) == 0 ? "" : "close failed";
+    }
+};
+
+}  // namespace
+
+std::string open_sink(OutputType type, const std::string& path, uint32_t channels, uint32_t rate, uint32_t bit_depth, PcmSink** out) {
+    *out = nullptr;
+    if (type == OutputType::Stdout) { *out = new RawSink(stdout); return ""; }
+    if (type == OutputType::Flac && bit_depth == 32) return "FLAC cannot hold 32-bit float; choose 16, 20 or 24 bits";
+    if (type == OutputType::Flac && rate > 655350) return "FLAC cannot describe this sample rate";
+    if (type == OutputType::Aiff && bit_depth == 32) return "AIFF cannot hold 32-bit float; use AIFC (C)";
+    FILE* f = fopen(path.c_str(), "wb");
+    if (!f) return "cannot create " + path;
+    std::string err;
+    if (type == OutputType::Wav) { auto* s = new WavSink(); s->f = f; s->ch = channels; s->rate = rate; s->bits = bit_depth; err = s->begin(); *out = s; }
+    else if (type == OutputType::Flac) { auto* s = new FlacSink(); s->f = f; s->ch = channels; s->rate = rate; s->bits = bit_depth; err = s->begin(); *out = s; }
+    else { auto* s = new AiffSink(); s->f = f; s->ch = channels; s->rate = rate; s->bits = bit_depth; s->aifc = type == OutputType::Aifc; err = s->begin(); *out = s; }
+    return err;
+}
+
+}  // namespace d2dhost

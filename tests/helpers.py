@@ -67,3 +67,43 @@ def decode_pcm(raw, bit_depth, channels):
     v = b[:, 0] | (b[:, 1] << 8) | (b[:, 2] << 16)
     v = np.where(v >= 1 << 23, v - (1 << 24), v)
     return v.reshape(-1, channels)
+
+
+# ---- container writers (for the host-driver tests): built from the public DSF / DSDIFF layouts ----
+import struct
+
+
+def write_dsf(path, chans, dsd_rate=1, lsb_first=True, block=4096, sample_count=None, id3=b""):
+    C_ = len(chans)
+    n = len(chans[0])
+    nblk = -(-n // block)
+    payload = bytearray()
+    for b in range(nblk):
+        for c in range(C_):
+            piece = bytes(chans[c][b * block:(b + 1) * block])
+            payload += piece + bytes(block - len(piece))
+    sc = sample_count if sample_count is not None else n * 8
+    data_sz = 12 + len(payload)
+    total = 28 + 52 + data_sz + len(id3)
+    meta = 28 + 52 + data_sz if id3 else 0
+    with open(path, "wb") as f:
+        f.write(b"DSD " + struct.pack("<QQQ", 28, total, meta))
+        f.write(b"fmt " + struct.pack("<QIIIIIIQII", 52, 1, 0, 2 if C_ == 2 else 1, C_, 2822400 * dsd_rate,
+                                      1 if lsb_first else 8, sc, block, 0))
+        f.write(b"data" + struct.pack("<Q", data_sz) + payload + id3)
+
+
+def write_dff(path, chans, dsd_rate=1, tail=b""):
+    C_ = len(chans)
+    data = np.stack(chans, axis=1).reshape(-1).tobytes()
+    ids = [b"SLFT", b"SRGT", b"C   ", b"LFE ", b"LS  ", b"RS  "][:C_] if C_ != 1 else [b"C   "]
+    while len(ids) < C_:
+        ids.append(b"C%03d" % len(ids))
+    chnl = struct.pack(">H", C_) + b"".join(ids)
+    cmpr = b"DSD " + bytes([14]) + b"not compressed" + b"\x00"
+    prop_body = b"SND " + b"FS  " + struct.pack(">QI", 4, 2822400 * dsd_rate) + b"CHNL" + struct.pack(">Q", len(chnl)) + chnl \
+        + b"CMPR" + struct.pack(">Q", len(cmpr)) + cmpr
+    body = b"DSD " + b"FVER" + struct.pack(">QI", 4, 0x01050000) + b"PROP" + struct.pack(">Q", len(prop_body)) + prop_body \
+        + b"DSD " + struct.pack(">Q", len(data)) + data + (b"\x00" if len(data) & 1 else b"") + tail
+    with open(path, "wb") as f:
+        f.write(b"FRM8" + struct.pack(">Q", len(body)) + body)

@@ -1,0 +1,237 @@
+"""The host side above the C ABI: container readers, PCM sinks, the Rdsd2Pcm mirror and
+its small CLI (dsd2dxd_amd/dsd2dxd_amd_cli).  CPU tests cover what needs no GPU (the readers, found
+through `probe`); GPU tests convert whole files and compare the written audio with the oracle."""
+import json
+import os
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+
+from helpers import decode_pcm, pack_layout, random_bytes, synth, write_dff, write_dsf
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CLI = os.path.join(ROOT, "dsd2dxd_amd", "dsd2dxd_amd_cli")
+REF = "/root/reference"
+
+
+@pytest.fixture(scope="module")
+def cli(engine_lib):
+    if not os.path.exists(CLI):
+        engine_lib.build_library()
+    return CLI
+
+
+def probe(cli, *paths):
+    return json.loads(subprocess.check_output([cli, "probe", *paths]))
+
+
+def test_probe_synthetic_containers(cli, tmp_path):
+    chans = [random_bytes(4096 * 3 + 100, 1), random_bytes(4096 * 3 + 100, 2)]
+    p1, p2 = str(tmp_path / "a.dsf"), str(tmp_path / "b.dff")
+    write_dsf(p1, chans, dsd_rate=2, lsb_first=True, sample_count=(4096 * 3 + 100) * 8 - 3, id3=b"ID3" + bytes(20))
+    write_dff(p2, chans, dsd_rate=4, tail=b"ID3 " + struct.pack(">Q", 5000) + b"xx")     # truncated tag
+    a, b = probe(cli, p1, p2)
+    assert a["error"] == "" and (a["format"], a["channels"], a["dsd_rate"], a["planar"], a["msb_first"], a["block_size"]) == ("dsf", 2, 2, True, False, 4096)
+    assert a["data_offset"] == 92 and a["data_bytes"] == 4 * 4096 * 2 and a["bytes_per_channel"] == 4096 * 3 + 100
+    assert a["metadata_offset"] == 92 + a["data_bytes"] and not a["metadata_truncated"]
+    assert b["error"] == "" and (b["format"], b["channels"], b["dsd_rate"], b["planar"], b["msb_first"], b["block_size"]) == ("dff", 2, 4, False, True, 1)
+    assert b["bytes_per_channel"] == 4096 * 3 + 100 and b["metadata_truncated"] and "audio is intact" in b["warning"]
+    bad = str(tmp_path / "c.dsf")
+    open(bad, "wb").write(b"RIFFxxxx" + bytes(200))
+    assert "bad 'DSD ' chunk" in probe(cli, bad)[0]["error"]
+
+
+@pytest.mark.skipif(not os.path.isdir(REF + "/test"), reason="reference fixtures not present")
+def test_probe_reference_fixtures(cli):
+    """the facts SURVEY.md 4.3 measured from the fixture files, including the damaged-ID3 ones"""
+    r = {os.path.basename(d["path"]): d for d in probe(
+        cli, REF + "/test/1kHz_mono_p.dsf", REF + "/test/1kHz_stereo_128.dsf", REF + "/test/pinknoise_mono_128.dsf",
+        REF + "/id3_test/1kHz_mono_brokenid3.dsf", REF + "/id3_test/dff/1kHz_stereo_i.dff", REF + "/id3_test/dff/1kHz_stereo_i_brokenid3.dff")}
+    m = r["1kHz_mono_p.dsf"]
+    assert (m["channels"], m["dsd_rate"], m["msb_first"], m["block_size"], m["sample_count"], m["data_offset"], m["data_bytes"]) == (1, 1, False, 4096, 14112000, 92, 1765376)
+    s = r["1kHz_stereo_128.dsf"]
+    assert (s["channels"], s["dsd_rate"], s["sample_count"], s["data_bytes"]) == (2, 2, 11289600, 2 * 345 * 4096)
+    assert r["1kHz_mono_brokenid3.dsf"]["error"] == "" and r["1kHz_mono_brokenid3.dsf"]["metadata_truncated"]
+    d = r["1kHz_stereo_i.dff"]
+    assert (d["channels"], d["dsd_rate"], d["planar"], d["msb_first"], d["data_offset"], d["bytes_per_channel"]) == (2, 1, False, True, 130, 1058400)
+    assert r["1kHz_stereo_i_brokenid3.dff"]["error"] == "" and r["1kHz_stereo_i_brokenid3.dff"]["metadata_truncated"]
+    # payload identities the README states (README.md:205): the .dsd files are the containers' payloads
+    raw = np.fromfile(REF + "/test/1kHz_mono_p.dsd", dtype=np.uint8)
+    dsf = np.fromfile(REF + "/test/1kHz_mono_p.dsf", dtype=np.uint8)
+    assert np.array_equal(raw, dsf[92:92 + 1765376])
+    dff = np.fromfile(REF + "/id3_test/dff/1kHz_stereo_i.dff", dtype=np.uint8)
+    assert np.array_equal(np.fromfile(REF + "/test/1kHz_stereo_i.dsd", dtype=np.uint8), dff[130:130 + 2116800])
+
+
+# ---- GPU: whole-file conversions through the CLI --------------------------------------------------
+
+def _wav_payload(path):
+    b = open(path, "rb").read()
+    assert b[:4] == b"RIFF" and b[8:12] == b"WAVE"
+    pos = 12
+    fmt = None
+    while pos + 8 <= len(b):
+        cid, sz = b[pos:pos + 4], struct.unpack("<I", b[pos + 4:pos + 8])[0]
+        if cid == b"fmt ":
+            fmt = struct.unpack("<HHIIHH", b[pos + 8:pos + 24])
+        if cid == b"data":
+            return fmt, np.frombuffer(b[pos + 8:pos + 8 + sz], dtype=np.uint8)
+        pos += 8 + sz + (sz & 1)
+    raise AssertionError("no data chunk")
+
+
+def _aiff_payload(path):
+    b = open(path, "rb").read()
+    assert b[:4] == b"FORM" and b[8:12] in (b"AIFF", b"AIFC")
+    pos = 12
+    comm = None
+    while pos + 8 <= len(b):
+        cid, sz = b[pos:pos + 4], struct.unpack(">I", b[pos + 4:pos + 8])[0]
+        if cid == b"COMM":
+            comm = struct.unpack(">hIh", b[pos + 8:pos + 16])
+        if cid == b"SSND":
+            return comm, np.frombuffer(b[pos + 16:pos + 8 + sz], dtype=np.uint8)
+        pos += 8 + sz + (sz & 1)
+    raise AssertionError("no SSND chunk")
+
+
+def _flac_decode(path):
+    """decoder for the subset the sink writes: fixed order 0/2 or verbatim, one Rice partition"""
+    b = open(path, "rb").read()
+    assert b[:4] == b"fLaC"
+    si = b[8:42]
+    v = int.from_bytes(si[10:18], "big")
+    rate, ch, bps, total = v >> 44, ((v >> 41) & 7) + 1, ((v >> 36) & 31) + 1, v & ((1 << 36) - 1)
+    bits = "".join(f"{x:08b}" for x in b[42:])
+    pos = 0
+
+    def rd(n):
+        nonlocal pos
+        x = int(bits[pos:pos + n], 2) if n else 0
+        pos += n
+        return x
+
+    def sgn(x, n):
+        return x - (1 << n) if x >> (n - 1) else x
+    out = []
+    while len(out) < total:
+        assert rd(16) == 0xFFF8
+        bsc = rd(4); rd(4); assert rd(4) == ch - 1; rd(3); rd(1)
+        first = rd(8)
+        if first >= 0x80:
+            n = 1 if first < 0xE0 else 2 if first < 0xF0 else 3 if first < 0xF8 else 4
+            for _ in range(n):
+                rd(8)
+        n = 4096 if bsc == 0xC else rd(16) + 1
+        rd(8)
+        chans = []
+        for _ in range(ch):
+            assert rd(1) == 0
+            t = rd(6); assert rd(1) == 0
+            if t == 1:
+                s = [sgn(rd(bps), bps) for _ in range(n)]
+            else:
+                order = t - 8
+                s = [sgn(rd(bps), bps) for _ in range(order)]
+                assert rd(2) == 1 and rd(4) == 0
+                k = rd(5)
+                for i in range(order, n):
+                    q = 0
+                    while bits[pos] == "0":
+                        q += 1; pos += 1
+                    pos += 1
+                    u = (q << k) | rd(k)
+                    r = (u >> 1) if not (u & 1) else -((u + 1) >> 1)
+                    s.append(r + (2 * s[i - 1] - s[i - 2] if order == 2 else 0))
+            chans.append(s)
+        pos = (pos + 7) & ~7
+        rd(16)
+        out.extend(zip(*chans))
+    return rate, ch, bps, np.array(out[:total], dtype=np.int64)
+
+
+@pytest.mark.gpu
+def test_dsf_to_wav_respects_sample_count(cli, oracle_mod, tmp_path):
+    n = 4096 * 5 + 1000
+    chans = [synth("sine", n, seed=1), synth("pink", n, seed=2, amp=0.098)]
+    src = str(tmp_path / "tone.dsf")
+    write_dsf(src, chans, dsd_rate=1, lsb_first=True)            # last block group is padded inside the file
+    out_dir = tmp_path / "out"
+    out_dir.mkdir()
+    subprocess.check_call([cli, "-o", "w", "-r", "88200", "-b", "24", "-d", "T", "-a", "-p", str(out_dir), "-q", src])
+    fmt, pay = _wav_payload(str(out_dir / "tone_88_2K.wav"))
+    assert fmt[:4] == (1, 2, 88200, 88200 * 6) and fmt[5] == 24
+    o = oracle_mod.Oracle(dsd_rate=1, output_rate=88200, channels=2, fmt="P", endianness="L", block_size=4096,
+                          bit_depth=24, dither="T", seed=0)
+    r, rf = o.translate(pack_layout(chans, "P", 4096))            # the padding must NOT be converted
+    assert rf == n * 8 // 32 and np.array_equal(pay, r[:rf * 6])
+
+
+@pytest.mark.gpu
+def test_dff_to_aiff_and_raw_stdin_to_stdout(cli, oracle_mod, tmp_path):
+    n = 4096 * 4
+    chans = [synth("sine", n, seed=3, msb_first=True), synth("pink", n, seed=4, amp=0.098, msb_first=True)]
+    src = str(tmp_path / "x.dff")
+    write_dff(src, chans)
+    subprocess.check_call([cli, "-o", "a", "-r", "176400", "-b", "16", "-d", "X", "-q", src])
+    comm, pay = _aiff_payload(str(tmp_path / "x.aif"))
+    o = oracle_mod.Oracle(dsd_rate=1, output_rate=176400, channels=2, fmt="I", endianness="M", bit_depth=16, dither="X")
+    r, rf = o.translate(pack_layout(chans, "I", 1))
+    assert comm == (2, rf, 16)
+    assert np.array_equal(pay.reshape(-1, 2)[:, ::-1].reshape(-1), r[:rf * 4])        # AIFF is big-endian
+    # the README's pipe example: raw planar LSB-first on stdin, f32 on stdout (build_test_stereo_flt.sh)
+    raw = pack_layout([synth("sine", n, seed=5), synth("sine", n, seed=6, freq=3000.0)], "P", 4096)
+    got = subprocess.run([cli, "-f", "P", "-e", "L", "-b", "32", "-d", "F", "--level=-3", "-q"], input=raw.tobytes(),
+                         stdout=subprocess.PIPE, check=True).stdout
+    o = oracle_mod.Oracle(dsd_rate=1, output_rate=352800, channels=2, fmt="P", endianness="L", block_size=4096,
+                          bit_depth=32, dither="F", level_db=-3.0, seed=0)
+    r, rf = o.translate(raw)
+    assert np.array_equal(np.frombuffer(got, dtype=np.uint8), r[:rf * 8])
+
+
+@pytest.mark.gpu
+def test_flac_and_wav20_sinks(cli, oracle_mod, tmp_path):
+    n = 4096 * 6
+    chans = [synth("sine", n, seed=7), synth("pink", n, seed=8, amp=0.098)]
+    src = str(tmp_path / "y.dsf")
+    write_dsf(src, chans)
+    subprocess.check_call([cli, "-o", "f", "-r", "88200", "-b", "24", "-d", "T", "-q", src])
+    rate, ch, bps, pcm = _flac_decode(str(tmp_path / "y.flac"))
+    o = oracle_mod.Oracle(dsd_rate=1, output_rate=88200, channels=2, fmt="P", endianness="L", block_size=4096,
+                          bit_depth=24, dither="T", seed=0)
+    r, rf = o.translate(pack_layout(chans, "P", 4096))
+    assert (rate, ch, bps, len(pcm)) == (88200, 2, 24, rf)
+    assert np.array_equal(pcm, decode_pcm(r[:rf * 6], 24, 2))
+    assert os.path.getsize(str(tmp_path / "y.flac")) < rf * 6           # the fixed predictor + Rice coding do compress
+    subprocess.check_call([cli, "-o", "w", "-r", "88200", "-b", "20", "-d", "X", "-q", src])
+    fmt, pay = _wav_payload(str(tmp_path / "y.wav"))
+    assert fmt[0] == 0xFFFE and fmt[5] == 24                              # EXTENSIBLE: 20 valid bits in 24
+    o = oracle_mod.Oracle(dsd_rate=1, output_rate=88200, channels=2, fmt="P", endianness="L", block_size=4096, bit_depth=20, dither="X")
+    r, rf = o.translate(pack_layout(chans, "P", 4096))
+    assert np.array_equal(pay, r[:rf * 6])
+
+
+@pytest.mark.gpu
+def test_levels_tool_and_error_exit(cli, oracle_mod, tmp_path):
+    n = 4096 * 8
+    a = [synth("sine", n, seed=9, amp=0.5), synth("sine", n, seed=10, amp=0.2)]
+    b = [synth("pink", n, seed=11, amp=0.098)]
+    pa, pb = str(tmp_path / "a.dsf"), str(tmp_path / "b.dsf")
+    write_dsf(pa, a)
+    write_dsf(pb, b)
+    out = subprocess.check_output([cli, "levels", "-r", "88200", pa, pb]).decode().splitlines()
+    want = []
+    for chans in (a, b):
+        o = oracle_mod.Oracle(dsd_rate=1, output_rate=88200, channels=len(chans), fmt="P", endianness="L", block_size=4096,
+                              bit_depth=32, dither="X")
+        o.translate(pack_layout(chans, "P", 4096))
+        want.append(float(o.peak_dbfs()))
+    assert out[0] == "a.dsf: %.4f dBFS" % want[0] and out[1] == "b.dsf: %.4f dBFS" % want[1]
+    assert out[2] == "Highest peak: %.4f dBFS" % max(want)
+    # errors: message on stderr, failure exit code (src/lib.rs:26-35)
+    p = subprocess.run([cli, "-r", "705600", "-o", "w", pa], stderr=subprocess.PIPE)
+    assert p.returncode == 1 and b"705600 output needs DSD128 or DSD256 input" in p.stderr
+    p = subprocess.run([cli, "-d", "N", pa], stderr=subprocess.PIPE)
+    assert p.returncode == 1 and b"Invalid dither type; must be T, R, F, or X" in p.stderr
