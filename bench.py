@@ -34,6 +34,8 @@ WORKLOADS = {
     "dsd64_to_88k2_s24_stereo": (1, 88200, 24, "T", 2, 32 / 8 + 3),
     "dsd64_to_352k8_f32_stereo": (1, 352800, 32, "X", 2, 8 / 8 + 4),
     "dsd128_to_88k2_s24_stereo": (2, 88200, 24, "T", 2, 64 / 8 + 3),
+    "dsd64_to_96k_s24_stereo": (1, 96000, 24, "T", 2, 29.4 / 8 + 3),
+    "dsd512_to_96k_s24_8ch": (8, 96000, 24, "T", 8, 235.2 / 8 + 3),
 }
 
 
@@ -115,11 +117,13 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
 
     dsd_rate, out_rate, bits, dither, channels, bytes_per_sample = WORKLOADS[args.workload]
-    M = DSD64 * dsd_rate // out_rate
+    M = DSD64 * dsd_rate / out_rate
     blocks = max(1, int(round(args.seconds * DSD64 * dsd_rate / 8 / 4096)))
     bpc = blocks * 4096                                   # bytes per channel per file
     kw = dict(dsd_rate=dsd_rate, output_rate=out_rate, channels=channels, fmt="P", endianness="L",
               block_size=4096, filter="E", bit_depth=bits, dither=dither, seed=206)
+    if channels != 2:
+        raise SystemExit("bench.py generates stereo files; use tools/bench_extra.py for other channel counts")
     kernel = {"auto": d.KERNEL_AUTO, "lut": d.KERNEL_LUT, "mfma": d.KERNEL_MFMA}[args.kernel]
     ncpu = os.cpu_count() or 1
     gen_threads = max(1, min(32, ncpu // max(1, min(world, 8))))
@@ -151,7 +155,7 @@ def main():
         d_in.append(uniq[id(b)])
     frames = eng.next_frames(bpc)
     fb = eng.frame_bytes
-    d_out = torch.empty((args.files, frames * fb + 16), dtype=torch.uint8, device=dev)
+    d_out = torch.empty((args.files, (frames * fb + 31) // 16 * 16), dtype=torch.uint8, device=dev)
     ios = (d.FileIO * args.files)()
     for f in range(args.files):
         ios[f].dsd = d_in[f].data_ptr()
@@ -197,7 +201,7 @@ def main():
         "value": round(value, 3), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f64", "data": "synthetic (2nd-order 1-bit modulator: 1 kHz-family sines at 0.352 FS and pink noise at ~0.1 RMS; %d distinct files per rank%s)" % (min(args.distinct, args.files), "" if args.distinct >= args.files else " tiled to %d" % args.files),
-        "config": {"workload": f"{args.workload}: {args.files} files/GPU x {blocks * 4096 * 8 / (DSD64 * dsd_rate):.1f} s, planar 4096-B LSB-first -> {bits}-bit {out_rate} Hz, dither {dither}, filter E ({eng.info()['ntaps']} taps, M={M})",
+        "config": {"workload": f"{args.workload}: {args.files} files/GPU x {blocks * 4096 * 8 / (DSD64 * dsd_rate):.1f} s, planar 4096-B LSB-first -> {bits}-bit {out_rate} Hz, dither {dither}, filter E ({eng.info()['ntaps']} taps, M={M:g})",
                    "files_per_gpu": args.files, "seconds_per_file": round(blocks * 4096 * 8 / (DSD64 * dsd_rate), 3),
                    "parallelism": f"files sharded over {world} GPU(s), no data-path collective", "kernel": eng.kernel_name()},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -95,27 +95,67 @@ __global__ __launch_bounds__(LUT_THREADS) void d2d_fir_lut_kernel(FirArgs a) {
 }
 
 // Stage B of the 48k cascade: y[m] = sum_k g[phi][k] * x[i_m - k],
-// t = Mdn*m, i_m = t div L, phi = t mod L; acc = fma(g, x, acc) for k ascending (same order as
-// the oracle, so the f64 result is bit-identical).
-__global__ __launch_bounds__(256) void d2d_resample_kernel(ResampArgs a) {
+// t = Mdn*m, i_m = t div L, phi = t mod L; acc = fma(g, x, acc) for k ascending (the oracle's order,
+// so the f64 result is bit-identical).  A block converts RS_TILE consecutive outputs of one stream:
+// the coefficient table ([k][phase], so lanes with different phases hit different banks) and the
+// stretch of stage-A samples the tile needs sit in LDS; each thread carries four independent fma
+// chains (outputs t, t+256, t+512, t+768) so the dependent-fma latency is covered.
+constexpr int RS_THREADS = 256;
+constexpr int RS_PER_THREAD = 4;
+constexpr int RS_TILE = RS_THREADS * RS_PER_THREAD;
+
+__global__ __launch_bounds__(RS_THREADS) void d2d_resample_kernel(ResampArgs a, uint32_t xcap) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    double* gk = reinterpret_cast<double*>(smem);              // [P][L]
+    double* xt = gk + (size_t)a.P * a.L;                       // [xcap]
     __shared__ double red[4];
     const StreamJob job = a.jobs[blockIdx.y];
-    const double* xs = job.xs;                          // xs[0] = stage-A output n0; xs[-P..-1] = history
+    const uint32_t tid = threadIdx.x;
+    const uint32_t L = a.L, P = a.P, Mdn = a.Mdn;
+    for (uint32_t i = tid; i < L * P; i += RS_THREADS) {       // global [phase][k] -> LDS [k][phase]
+        const uint32_t phi = i / P, k = i - phi * P;
+        gk[k * L + phi] = a.coef[i];
+    }
+    const D2D_GLOBAL double* xs = as_global(job.xs);
     uint8_t* pcm = reinterpret_cast<uint8_t*>(job.out);
     const uint32_t sample_bytes = a.epi.sample_bytes;
     const uint32_t frame_bytes = sample_bytes * a.epi.channels;
+    const uint32_t ntiles = (job.nres + RS_TILE - 1) / RS_TILE;
     double pk = 0.0;
-    for (uint32_t o = blockIdx.x * blockDim.x + threadIdx.x; o < job.nres; o += gridDim.x * blockDim.x) {
-        const uint64_t m = job.m0 + o;
-        const uint64_t t = m * a.Mdn;
-        const uint64_t im = t / a.L;
-        const uint32_t phi = (uint32_t)(t - im * a.L);
-        const double* g = a.coef + (size_t)phi * a.P;
-        const double* xp = xs + (int64_t)(im - job.n0);
-        double acc = 0.0;
-        for (uint32_t k = 0; k < a.P; ++k) acc = fma(g[k], xp[-(int64_t)k], acc);
-        uint8_t* dst = pcm + (size_t)o * frame_bytes + job.ch * sample_bytes;
-        pk = fmax(pk, emit_sample(a.epi, job, acc, m, dst));
+    for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const uint32_t o0 = tile * RS_TILE;
+        const uint32_t o1 = min(o0 + RS_TILE, job.nres) - 1;   // last output of the tile
+        // stage-A samples the tile touches, as indices relative to job.n0 (history is negative)
+        const int64_t ifirst = (int64_t)(((job.m0 + o0) * (uint64_t)Mdn) / L) - (int64_t)job.n0 - (int64_t)(P - 1);
+        const int64_t ilast = (int64_t)(((job.m0 + o1) * (uint64_t)Mdn) / L) - (int64_t)job.n0;
+        const uint32_t nx = (uint32_t)(ilast - ifirst + 1);
+        __syncthreads();
+        for (uint32_t i = tid; i < nx && i < xcap; i += RS_THREADS) xt[i] = xs[ifirst + (int64_t)i];
+        __syncthreads();
+        double acc[RS_PER_THREAD];
+        uint32_t xoff[RS_PER_THREAD], phi[RS_PER_THREAD];
+#pragma unroll
+        for (int j = 0; j < RS_PER_THREAD; ++j) {
+            const uint32_t o = min(o0 + tid + j * RS_THREADS, o1);       // clamp: lanes past the end redo the last one
+            const uint64_t t = (job.m0 + o) * (uint64_t)Mdn;
+            const uint64_t im = t / L;
+            phi[j] = (uint32_t)(t - im * L);
+            xoff[j] = (uint32_t)((int64_t)im - (int64_t)job.n0 - ifirst);  // xt index of x[i_m]
+            acc[j] = 0.0;
+        }
+        for (uint32_t k = 0; k < P; ++k) {
+            const double* gr = gk + k * L;
+#pragma unroll
+            for (int j = 0; j < RS_PER_THREAD; ++j) acc[j] = fma(gr[phi[j]], xt[xoff[j] - k], acc[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < RS_PER_THREAD; ++j) {
+            const uint32_t o = o0 + tid + j * RS_THREADS;
+            if (o <= o1) {
+                uint8_t* dst = pcm + (size_t)o * frame_bytes + job.ch * sample_bytes;
+                pk = fmax(pk, emit_sample(a.epi, job, acc[j], job.m0 + o, dst));
+            }
+        }
     }
     block_peak_max(pk, job.peak, red);
 }
@@ -190,10 +230,20 @@ const char* lut_kernel_name(int MB) {
 
 hipError_t launch_resample(const ResampArgs& a, uint32_t max_out, uint32_t nstreams, hipStream_t s) {
     if (nstreams == 0 || max_out == 0) return hipSuccess;
-    uint32_t gx = (max_out + 255) / 256;
-    const uint32_t cap = (8192 + nstreams - 1) / nstreams;
+    // stage-A samples one tile can touch: RS_TILE * Mdn / L advance + P taps (+ rounding slack)
+    const uint32_t xcap = (uint32_t)(((uint64_t)RS_TILE * a.Mdn) / a.L) + a.P + 8;
+    const size_t smem = ((size_t)a.L * a.P + xcap) * sizeof(double);
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&d2d_resample_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);   // + 32 B static
+        if (e != hipSuccess) return e;
+        attr_done = true;
+    }
+    uint32_t gx = (max_out + RS_TILE - 1) / RS_TILE;
+    const uint32_t cap = (2048 + nstreams - 1) / nstreams;
     if (gx > cap) gx = cap;
-    hipLaunchKernelGGL(d2d_resample_kernel, dim3(gx, nstreams), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(d2d_resample_kernel, dim3(gx, nstreams), dim3(RS_THREADS), smem, s, a, xcap);
     return hipGetLastError();
 }
 
