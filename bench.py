@@ -111,10 +111,22 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # one process per GPU over RCCL ("nccl" IS RCCL on ROCm).  D2D_BENCH_BACKEND=gloo is a rehearsal
+    # mode for boxes with fewer GPUs than ranks: same protocol, collectives on host tensors, ranks
+    # folded onto the GPUs that exist.
+    backend = os.environ.get("D2D_BENCH_BACKEND", "nccl")
+    ndev = torch.cuda.device_count()
+    if backend == "nccl" and local_rank >= ndev:
+        raise SystemExit(f"rank {rank}: no GPU {local_rank} on this node")
+    local_dev = local_rank % max(ndev, 1)
+    torch.cuda.set_device(local_dev)
+    dev = torch.device("cuda", local_dev)
+    cdev = dev if backend == "nccl" else torch.device("cpu")      # where collective payloads live
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     dsd_rate, out_rate, bits, dither, channels, bytes_per_sample = WORKLOADS[args.workload]
     M = DSD64 * dsd_rate / out_rate
@@ -131,7 +143,7 @@ def main():
     if args.distinct <= 0:
         args.distinct = args.files
     files = make_files(args.files, bpc, dsd_rate, args.distinct, rank, gen_threads)
-    eng = d.Engine(n_files=args.files, kernel=kernel, device=local_rank, **kw)
+    eng = d.Engine(n_files=args.files, kernel=kernel, device=local_dev, **kw)
     stream = torch.cuda.current_stream().cuda_stream
 
     # the shared filter tables: rank 0's copy is broadcast over RCCL and adopted by the others
@@ -141,7 +153,9 @@ def main():
         if rank == 0:
             eng.tables_export_device(blob.data_ptr(), nb, stream)
         torch.cuda.synchronize()
-        dist.broadcast(blob, src=0)
+        wire = blob.to(cdev)
+        dist.broadcast(wire, src=0)
+        blob.copy_(wire)
         torch.cuda.synchronize()
         if rank != 0:
             eng.tables_import_device(blob.data_ptr(), nb, stream)
@@ -185,7 +199,7 @@ def main():
     fir_ms, launches = eng.profile_read()
     eng.profile_enable(False)
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 

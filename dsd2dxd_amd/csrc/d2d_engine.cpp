@@ -563,6 +563,9 @@ int d2d_get_info(const d2d_engine* e, d2d_info* out) {
     return D2D_OK;
 }
 
+// diagnostic, not part of the public header: per-phase wave-cycle sums of the MFMA kernel (D2D_DBG=16)
+void d2d_debug_stamps(unsigned long long* out8) { hipDeviceSynchronize(); mfma_debug_stamps(out8); }
+
 const char* d2d_kernel_name(const d2d_engine* e) {
     if (!e) return "";
     return e->kernel == D2D_KERNEL_LUT ? lut_kernel_name(e->Mb) : mfma_kernel_name(e->mfma);

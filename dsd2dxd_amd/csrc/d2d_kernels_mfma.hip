@@ -41,13 +41,17 @@ typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 constexpr int MFMA_MAX_THREADS = 512;
 constexpr int MFMA_PF = 3;   // 16-byte chunks per lane fetched one wave-tile ahead
 
+// diagnostic build only (D2D_DBG bit 4): wave-cycles per phase, summed over all waves
+__device__ unsigned long long d2d_stamp_acc[8];
+
 struct MfmaArgs {
     FirArgs f;
     double c1, c0;        // x = fma(acc128, c1, -c0) == round(y*c0): c1 = 2^(1-S-7)*c0, c0 = scale | gain | 1
     // integer-depth epilogue as data: d = fma(term, dmul, dadd), clamp to [qmin, qmax], * qmul
     double dmul, dadd, qmin, qmax;
     uint32_t dsel;        // 1: triangular term, 0: rectangular term
-    uint32_t qmul;        // 16 for 20-bit samples in a 24-bit container, else 1
+    uint32_t qsh;         // 4 for 20-bit samples in a 24-bit container, else 0
+    int32_t qmin_i, qmax_i;
     uint32_t wide;        // 1: limb sums may exceed 2^23, recombine in f64
     uint32_t U;           // dwords of row window per lane half; K steps = 2U
     uint32_t span;        // logical staged bytes per channel (multiple of 16)
@@ -57,6 +61,8 @@ struct MfmaArgs {
     uint32_t wave_lds;    // LDS bytes per wave
     uint32_t off_out, off_pk;   // inside a wave's region
     uint32_t nwaves;      // waves per block
+    uint32_t dbg;         // diagnostic ablation mask (env D2D_DBG), 0 in production
+    uint32_t stagger;     // start offset between wave slots, in units of 1024 cycles
 };
 
 __device__ __forceinline__ void wave_sync() {
@@ -91,7 +97,7 @@ __device__ __forceinline__ u32x4 load_chunk(const StreamJob* jobs, const StreamJ
 }
 
 template <int MB>
-__global__ __launch_bounds__(MFMA_MAX_THREADS, 4) void d2d_fir_mfma_kernel(MfmaArgs m) {
+__global__ __launch_bounds__(MFMA_MAX_THREADS, 3) void d2d_fir_mfma_kernel(MfmaArgs m) {
     const FirArgs& a = m.f;
     extern __shared__ __align__(16) unsigned char smem[];
     const uint32_t C = a.epi.channels, sb = a.epi.sample_bytes, fbytes = sb * C;
@@ -112,6 +118,8 @@ __global__ __launch_bounds__(MFMA_MAX_THREADS, 4) void d2d_fir_mfma_kernel(MfmaA
         uint4* dl = reinterpret_cast<uint4*>(smem);
         for (uint32_t i = tid; i < (a.ksteps + 6) * 64; i += blockDim.x) dl[i] = s[i];
     }
+    uint32_t* tokens = reinterpret_cast<uint32_t*>(smem + (a.ksteps + 6) * 1024);
+    if (tid < 16) tokens[tid] = 0;
     for (uint32_t c = 0; c < C; ++c) pkw[c * 64 + lane] = 0.0;
     if (lane < C) {   // per-channel dither keys: global -> this wave's LDS once
         rngw[lane * 4 + 0] = jobs[lane].rng_key;
@@ -120,7 +128,8 @@ __global__ __launch_bounds__(MFMA_MAX_THREADS, 4) void d2d_fir_mfma_kernel(MfmaA
     }
     __syncthreads();
 
-    const uint32_t U = m.U, ls = m.ls;
+    const uint32_t U = m.U;
+    constexpr uint32_t ls = MB == 1 ? 1 : MB == 2 ? 2 : MB == 4 ? 3 : MB == 8 ? 4 : 5;   // log2(row stride in dwords)
     const uint32_t nwt = (j0.nout + 255u) >> 8;            // wave-tiles in this file
     const uint32_t wstride = gridDim.x * m.nwaves;
     const uint32_t cpc = m.span >> 4;                      // 16-byte chunks per channel
@@ -128,7 +137,7 @@ __global__ __launch_bounds__(MFMA_MAX_THREADS, 4) void d2d_fir_mfma_kernel(MfmaA
     const uint32_t npairs = (C + 1) >> 1;
     // The staging geometry does not change from wave-tile to wave-tile (a wave-tile advances the
     // stream by 256*MB bytes, a multiple of 16): chunk -> (channel, LDS address) once.
-    uint32_t pf_c[MFMA_PF], pf_q[MFMA_PF], pf_w[MFMA_PF][4];
+    uint32_t pf_c[MFMA_PF], pf_q[MFMA_PF];
     auto lds_word_addr = [&](uint32_t c, uint32_t Ld) -> uint32_t {   // byte offset of staged dword Ld of channel c
         return (c >> 1) * m.ppair + (2u * (Ld + (Ld >> ls)) + (c & 1u)) * 4u;
     };
@@ -137,8 +146,6 @@ __global__ __launch_bounds__(MFMA_MAX_THREADS, 4) void d2d_fir_mfma_kernel(MfmaA
         const uint32_t ch = lane + 64 * i;
         pf_c[i] = ch / cpc;
         pf_q[i] = ch - pf_c[i] * cpc;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) pf_w[i][k] = lds_word_addr(pf_c[i], pf_q[i] * 4 + k);
     }
     u32x4 pf[MFMA_PF];
     uint32_t wt = blockIdx.x * m.nwaves + wave;
@@ -149,9 +156,6 @@ __global__ __launch_bounds__(MFMA_MAX_THREADS, 4) void d2d_fir_mfma_kernel(MfmaA
     const bool pow2B = Bsz >= 16 && (Bsz & (Bsz - 1)) == 0;
     const uint32_t bshift = pow2B ? 31 - __builtin_clz(Bsz) : 0;
     const uint32_t full_bytes = pow2B ? (Lcall >> bshift) << bshift : 0;   // bytes per channel in full blocks
-    uint32_t pf_cb[MFMA_PF];                                               // channel offset inside a block group
-#pragma unroll
-    for (int i = 0; i < MFMA_PF; ++i) pf_cb[i] = pf_c[i] << bshift;
     auto prefetch = [&](uint32_t w) {
         const int32_t ab = tile_abeg(w);
         if (pow2B && ab >= 0 && (uint32_t)ab + m.span <= full_bytes) {
@@ -160,7 +164,7 @@ __global__ __launch_bounds__(MFMA_MAX_THREADS, 4) void d2d_fir_mfma_kernel(MfmaA
                 if (lane + 64 * i < nch) {
                     const uint32_t j = (uint32_t)ab + pf_q[i] * 16;
                     const uint64_t off = (uint64_t)((j >> bshift) * C) << bshift;   // start of the block group
-                    const uint8_t* p = j0.in + off + (pf_cb[i] + (j & (Bsz - 1)));
+                    const uint8_t* p = j0.in + off + ((pf_c[i] << bshift) + (j & (Bsz - 1)));
                     pf[i] = *reinterpret_cast<D2D_GLOBAL const u32x4*>(as_global(p));
                 }
         } else {
@@ -170,7 +174,22 @@ __global__ __launch_bounds__(MFMA_MAX_THREADS, 4) void d2d_fir_mfma_kernel(MfmaA
         }
     };
     if (wt < nwt) prefetch(wt);
+    {   // Waves that run the same program fall into lockstep (all in the MFMA loop together, then all in
+        // the VALU epilogue together) and the two pipes never overlap.  A one-off start offset per wave
+        // slot keeps them apart: the work per wave-tile is identical, so the offset persists.
+        const uint32_t slot = ((wave >> 2) + 2u * (blockIdx.x & 1u) + (m.dbg >> 8)) & 3u;
+        for (uint32_t i = 0; i < slot * m.stagger; ++i) __builtin_amdgcn_s_sleep(16);
+    }
 
+    unsigned long long st_sum[6] = {0, 0, 0, 0, 0, 0}, st_last = 0;
+    auto stamp = [&](int slot) {
+        if (m.dbg & 16) {
+            unsigned long long t;
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
+            if (slot >= 0) st_sum[slot] += t - st_last;
+            st_last = t;
+        }
+    };
     const uint32_t r = lane & 31, h = lane >> 5;
     // this lane's row words: logical dword X0 + u of row r, pair-interleaved and padded in LDS
     const uint32_t X0 = (d >> 2) + h * U;
@@ -178,15 +197,16 @@ __global__ __launch_bounds__(MFMA_MAX_THREADS, 4) void d2d_fir_mfma_kernel(MfmaA
     const v4i* bp = reinterpret_cast<const v4i*>(smem) + lane;
     const uint32_t K1 = 0x01010101u;
 
+    stamp(-1);
     for (; wt < nwt; wt += wstride) {
         // staged bytes of this wave-tile: registers -> LDS
 #pragma unroll
         for (int i = 0; i < MFMA_PF; ++i)
             if (lane + 64 * i < nch) {
-                *reinterpret_cast<uint32_t*>(wbase + pf_w[i][0]) = pf[i].x;
-                *reinterpret_cast<uint32_t*>(wbase + pf_w[i][1]) = pf[i].y;
-                *reinterpret_cast<uint32_t*>(wbase + pf_w[i][2]) = pf[i].z;
-                *reinterpret_cast<uint32_t*>(wbase + pf_w[i][3]) = pf[i].w;
+                *reinterpret_cast<uint32_t*>(wbase + lds_word_addr(pf_c[i], pf_q[i] * 4 + 0)) = pf[i].x;
+                *reinterpret_cast<uint32_t*>(wbase + lds_word_addr(pf_c[i], pf_q[i] * 4 + 1)) = pf[i].y;
+                *reinterpret_cast<uint32_t*>(wbase + lds_word_addr(pf_c[i], pf_q[i] * 4 + 2)) = pf[i].z;
+                *reinterpret_cast<uint32_t*>(wbase + lds_word_addr(pf_c[i], pf_q[i] * 4 + 3)) = pf[i].w;
             }
         for (uint32_t ch = lane + 64 * MFMA_PF; ch < nch; ch += 64) {   // many channels / long windows
             const uint32_t c = ch / cpc, q = ch - c * cpc;
@@ -196,10 +216,13 @@ __global__ __launch_bounds__(MFMA_MAX_THREADS, 4) void d2d_fir_mfma_kernel(MfmaA
             *reinterpret_cast<uint32_t*>(wbase + lds_word_addr(c, q * 4 + 2)) = v.z;
             *reinterpret_cast<uint32_t*>(wbase + lds_word_addr(c, q * 4 + 3)) = v.w;
         }
+        stamp(0);
         if (wt + wstride < nwt) prefetch(wt + wstride);   // next wave-tile's bytes: in flight during the MFMAs
         wave_sync();
+        stamp(1);
         const bool full = wt * 256u + 256u <= j0.nout;
 
+        bool stored_from_regs = false;
         for (uint32_t pr = 0; pr < npairs; ++pr) {
             const uint32_t c0 = 2 * pr, c1 = c0 + 1;
             const bool two = c1 < C;
@@ -226,27 +249,50 @@ __global__ __launch_bounds__(MFMA_MAX_THREADS, 4) void d2d_fir_mfma_kernel(MfmaA
                 }
             };
             auto chain = [&](auto two_tag) {
-                // Two K pairs per trip; everything the NEXT trip needs (two row words, four tap
-                // fragments) is requested before this trip's MFMAs issue.  Zero fragments and spare
-                // row words exist past the end for the read-ahead.
-                u32x2 w0 = row_word(X0), w1 = row_word(X0 + 1);
-                v4i Ba0 = bp[0], Ba1 = bp[64], Bb0 = bp[2 * 64], Bb1 = bp[3 * 64];
+                // Two operand sets in ping-pong: set P serves K pair u, set Q serves u+1; as soon as
+                // a set's MFMAs are issued its registers are reloaded for two pairs later, so every
+                // LDS read has one whole K pair (four MFMAs) of cover and no register is copied.
+                // Zero fragments and spare row words exist past the end for the read-ahead.
+                u32x2 wP = row_word(X0), wQ = row_word(X0 + 1);
+                v4i P0 = bp[0], P1 = bp[64], Q0 = bp[2 * 64], Q1 = bp[3 * 64];
                 uint32_t u = 0;
                 const v4i* bq = bp;
+                if (m.dbg & 32) {          // diagnostic: the chain without its LDS reads
+                    for (; u + 2 <= U; u += 2) {
+                        kpair(wP, P0, P1, two_tag);
+                        wP.x += 0x01010101u; P0.x ^= (int)u;
+                        kpair(wQ, Q0, Q1, two_tag);
+                        wQ.y += 0x01010101u; Q1.y ^= (int)u;
+                    }
+                } else
                 for (; u + 2 <= U; u += 2) {
-                    const u32x2 w2 = row_word(X0 + u + 2), w3 = row_word(X0 + u + 3);
-                    const v4i Bc0 = bq[4 * 64], Bc1 = bq[5 * 64], Bd0 = bq[6 * 64], Bd1 = bq[7 * 64];
+                    kpair(wP, P0, P1, two_tag);
+                    wP = row_word(X0 + u + 2); P0 = bq[4 * 64]; P1 = bq[5 * 64];
+                    kpair(wQ, Q0, Q1, two_tag);
+                    wQ = row_word(X0 + u + 3); Q0 = bq[6 * 64]; Q1 = bq[7 * 64];
                     bq += 4 * 64;
-                    kpair(w0, Ba0, Ba1, two_tag);
-                    kpair(w1, Bb0, Bb1, two_tag);
-                    w0 = w2; w1 = w3; Ba0 = Bc0; Ba1 = Bc1; Bb0 = Bd0; Bb1 = Bd1;
                 }
-                if (u < U) kpair(w0, Ba0, Ba1, two_tag);
+                if (u < U) kpair(wP, P0, P1, two_tag);
             };
-            if (two) chain(std::true_type{}); else chain(std::false_type{});
+            // Waves that share a SIMD (w and w+4 of a block) take turns in the MFMA phase: while one
+            // multiplies, the other runs its VALU/memory phases, so the two pipes overlap instead of
+            // all waves queueing on the matrix pipe together and then on the VALU together.
+            const bool use_token = (m.dbg & 64) != 0;
+            if (use_token) {
+                if (lane == 0) { while (atomicCAS(&tokens[wave & 3u], 0u, 1u) != 0u) __builtin_amdgcn_s_sleep(2); }
+                __builtin_amdgcn_wave_barrier();
+            }
+            if (m.dbg & 1) { acc0[0] = (int)lane; acc1[0] = (int)r; }
+            else if (two) chain(std::true_type{}); else chain(std::false_type{});
+            if (use_token) {
+                asm volatile("" :: "v"(acc0[15]), "v"(acc1[15]));
+                if (lane == 0) atomicExch(&tokens[wave & 3u], 0u);
+            }
+            if (m.dbg & 16) { asm volatile("" :: "v"(acc0[15]), "v"(acc1[15])); }
+            stamp(2);
 
             // ---- epilogue: lane (r, h) owns phases ph = h + 2k of row r for both channels ----
-            auto finish = [&](const v16i& acc, uint32_t c, auto full_tag) {
+            auto finish = [&](const v16i& acc, uint32_t c, auto full_tag, int32_t* iv_out) {
                 constexpr bool FULL = decltype(full_tag)::value;
                 const uint32_t rkey = rngw[c * 4], rstep = rngw[c * 4 + 1], rlo0 = rngw[c * 4 + 2];
                 double pkx = pkw[c * 64 + lane];
@@ -264,7 +310,7 @@ __global__ __launch_bounds__(MFMA_MAX_THREADS, 4) void d2d_fir_mfma_kernel(MfmaA
                     }
                     // x = y*c0 with ONE rounding: acc*c1 - c0 is exactly y*c0 before the fma rounds
                     xv[k] = fma(accd, m.c1, -m.c0);
-                    const uint32_t nlo = (uint32_t)j0.n0 + wt * 256u + (8 * r + h + 2 * k);
+                    const uint32_t nlo = (uint32_t)j0.n0 + wt * 256u + (8 * r + 4 * h + k);
                     uint32_t z = nlo + rkey + (nlo < rlo0 ? rstep : 0u);
                     z ^= z >> 16; z *= 0x7feb352dU;
                     z ^= z >> 15; z *= 0x846ca68bU;
@@ -274,21 +320,23 @@ __global__ __launch_bounds__(MFMA_MAX_THREADS, 4) void d2d_fir_mfma_kernel(MfmaA
                 if (a.to_scratch) {
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
-                        const uint32_t nl = wt * 256u + (8 * r + h + 2 * k);
+                        const uint32_t nl = wt * 256u + (8 * r + 4 * h + k);
                         if (FULL || nl < j0.nout) as_global(jobs[c].xs)[nl] = xv[k];
                     }
                     return;
                 }
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    const bool ok = FULL || (wt * 256u + (8 * r + h + 2 * k) < j0.nout);
-                    pkx = fmax(pkx, ok ? fabs(xv[k]) : 0.0);
+                    const bool ok = FULL || (wt * 256u + (8 * r + 4 * h + k) < j0.nout);
+                    // plain v_max_f64 with the |.| source modifier (fmax() would canonicalise both operands first)
+                    const double cand = ok ? xv[k] : 0.0;
+                    asm("v_max_f64 %0, %1, |%2|" : "=v"(pkx) : "v"(pkx), "v"(cand));
                 }
                 pkw[c * 64 + lane] = pkx;
                 if (a.epi.bits == 32) {
 #pragma unroll
                     for (int k = 0; k < 4; ++k)
-                        *reinterpret_cast<float*>(outw + (size_t)((8 * r + h + 2 * k) * C + c) * 4) = finish_f32(a.epi, xv[k], zv[k]);
+                        *reinterpret_cast<float*>(outw + (size_t)((8 * r + 4 * h + k) * C + c) * 4) = finish_f32(a.epi, xv[k], zv[k]);
                 } else {
                     int32_t iv[4];
 #pragma unroll
@@ -297,31 +345,93 @@ __global__ __launch_bounds__(MFMA_MAX_THREADS, 4) void d2d_fir_mfma_kernel(MfmaA
                         const uint32_t term = m.dsel ? (zv[k] & 0xFFFFu) + (zv[k] >> 16) + 1u : 2u * (zv[k] >> 16) + 1u;
                         const double dd = fma((double)term, m.dmul, m.dadd);
                         const double q = xv[k] + dd;
-                        const double rr = fmax(fmin(trunc(q + copysign(0.5, q)), m.qmax), m.qmin);
-                        iv[k] = (int32_t)rr * (int32_t)m.qmul;
+                        // round half away from zero; v_cvt_i32_f64 saturates, the clip is an integer med3
+                        const int32_t ri = (int32_t)trunc(q + copysign(0.5, q));
+                        iv[k] = min(max(ri, m.qmin_i), m.qmax_i) << m.qsh;
+                    }
+                    if (iv_out) {          // the caller packs and stores from registers
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) iv_out[k] = iv[k];
+                        return;
                     }
                     if (sb == 2) {
 #pragma unroll
                         for (int k = 0; k < 4; ++k)
-                            *reinterpret_cast<uint16_t*>(outw + (size_t)((8 * r + h + 2 * k) * C + c) * 2) = (uint16_t)iv[k];
+                            *reinterpret_cast<uint16_t*>(outw + (size_t)((8 * r + 4 * h + k) * C + c) * 2) = (uint16_t)iv[k];
                     } else {
 #pragma unroll
                         for (int k = 0; k < 4; ++k) {
-                            uint8_t* p = outw + (size_t)((8 * r + h + 2 * k) * C + c) * 3;
+                            uint8_t* p = outw + (size_t)((8 * r + 4 * h + k) * C + c) * 3;
                             p[0] = (uint8_t)iv[k]; p[1] = (uint8_t)(iv[k] >> 8); p[2] = (uint8_t)(iv[k] >> 16);
                         }
                     }
                 }
             };
-            if (full) {
-                finish(acc0, c0, std::true_type{});
-                if (two) finish(acc1, c1, std::true_type{});
-            } else {
-                finish(acc0, c0, std::false_type{});
-                if (two) finish(acc1, c1, std::false_type{});
+            const bool reg_store = full && two && C == 2 && sb == 3 && !a.to_scratch;
+            if (m.dbg & 2) { if (acc0[0] == 0x12345 && acc1[5] == 77 && acc0[9] + acc1[13] + acc0[15] + acc1[2] == 99) outw[lane] = 1; }
+            else if (reg_store) {
+                // Stereo 24-bit, whole tile: no LDS round trip.  Lane (r, h) owns frames 4h .. 4h+3 of
+                // row r for both channels = 24 contiguous output bytes; a few byte permutes pack them
+                // and the wave stores 1536 contiguous bytes.
+                // (frame by frame, both channels together: two independent sample pipelines in flight
+                // and only the six packed output words stay live)
+                const uint32_t key0 = rngw[c0 * 4], st0 = rngw[c0 * 4 + 1], lo00 = rngw[c0 * 4 + 2];
+                const uint32_t key1 = rngw[c1 * 4], st1 = rngw[c1 * 4 + 1], lo01 = rngw[c1 * 4 + 2];
+                double pk0 = pkw[c0 * 64 + lane], pk1 = pkw[c1 * 64 + lane];
+                auto one = [&](const v16i& acc, int k, uint32_t key, uint32_t stp, uint32_t lo0, double& pk) -> uint32_t {
+                    double accd;
+                    if (m.wide) {
+                        accd = fma((double)acc[4 * k + 3], 16777216.0,
+                                   fma((double)acc[4 * k + 2], 65536.0, fma((double)acc[4 * k + 1], 256.0, (double)acc[4 * k])));
+                    } else {
+                        accd = fma((double)(acc[4 * k + 2] + (acc[4 * k + 3] << 8)), 65536.0, (double)(acc[4 * k] + (acc[4 * k + 1] << 8)));
+                    }
+                    const double x = fma(accd, m.c1, -m.c0);
+                    asm("v_max_f64 %0, %1, |%2|" : "=v"(pk) : "v"(pk), "v"(x));
+                    const uint32_t nlo = (uint32_t)j0.n0 + wt * 256u + (8 * r + 4 * h + k);
+                    uint32_t z = nlo + key + (nlo < lo0 ? stp : 0u);
+                    z ^= z >> 16; z *= 0x7feb352dU;
+                    z ^= z >> 15; z *= 0x846ca68bU;
+                    z ^= z >> 16;
+                    const uint32_t term = m.dsel ? (z & 0xFFFFu) + (z >> 16) + 1u : 2u * (z >> 16) + 1u;
+                    const double q = x + fma((double)term, m.dmul, m.dadd);
+                    const int32_t ri = (int32_t)trunc(q + copysign(0.5, q));
+                    return (uint32_t)(min(max(ri, m.qmin_i), m.qmax_i) << m.qsh);
+                };
+                // frames k, k+1 -> 12 bytes: [L0 L1 L2 R0 | R1 R2 L0' L1' | L2' R0' R1' R2']
+                uint32_t w0, w1, w2, w3, w4, w5;
+                {
+                    const uint32_t La = one(acc0, 0, key0, st0, lo00, pk0), Ra = one(acc1, 0, key1, st1, lo01, pk1);
+                    const uint32_t Lb = one(acc0, 1, key0, st0, lo00, pk0), Rb = one(acc1, 1, key1, st1, lo01, pk1);
+                    w0 = __builtin_amdgcn_perm(Ra, La, 0x04020100u);
+                    w1 = __builtin_amdgcn_perm(Lb, Ra, 0x05040201u);
+                    w2 = __builtin_amdgcn_perm(Rb, Lb, 0x06050402u);
+                }
+                {
+                    const uint32_t La = one(acc0, 2, key0, st0, lo00, pk0), Ra = one(acc1, 2, key1, st1, lo01, pk1);
+                    const uint32_t Lb = one(acc0, 3, key0, st0, lo00, pk0), Rb = one(acc1, 3, key1, st1, lo01, pk1);
+                    w3 = __builtin_amdgcn_perm(Ra, La, 0x04020100u);
+                    w4 = __builtin_amdgcn_perm(Lb, Ra, 0x05040201u);
+                    w5 = __builtin_amdgcn_perm(Rb, Lb, 0x06050402u);
+                }
+                pkw[c0 * 64 + lane] = pk0; pkw[c1 * 64 + lane] = pk1;
+                const u32x4 o4 = {w0, w1, w2, w3};
+                const u32x2 o2 = {w4, w5};
+                uint8_t* g = reinterpret_cast<uint8_t*>(j0.out) + (size_t)wt * 1536 + 48u * r + 24u * h;
+                *reinterpret_cast<D2D_GLOBAL u32x4*>(as_global(g)) = o4;
+                *reinterpret_cast<D2D_GLOBAL u32x2*>(as_global(g + 16)) = o2;
             }
+            else if (full) {
+                finish(acc0, c0, std::true_type{}, nullptr);
+                if (two) finish(acc1, c1, std::true_type{}, nullptr);
+            } else {
+                finish(acc0, c0, std::false_type{}, nullptr);
+                if (two) finish(acc1, c1, std::false_type{}, nullptr);
+            }
+            stored_from_regs = reg_store;
         }
-        if (!a.to_scratch) {
+        stamp(3);
+        if (!a.to_scratch && !(m.dbg & 4) && !stored_from_regs) {
             wave_sync();
             // the wave-tile's interleaved frames: LDS -> HBM, 16 bytes per lane per store
             const uint32_t left = j0.nout - wt * 256;
@@ -332,7 +442,10 @@ __global__ __launch_bounds__(MFMA_MAX_THREADS, 4) void d2d_fir_mfma_kernel(MfmaA
                 *reinterpret_cast<D2D_GLOBAL u32x4*>(as_global(g + i)) = *reinterpret_cast<const u32x4*>(outw + i);
             for (uint32_t i = nb16 + lane; i < nb; i += 64) as_global(g)[i] = outw[i];
         }
+        stamp(4);
     }
+    if ((m.dbg & 16) && lane == 0)
+        for (int i = 0; i < 5; ++i) atomicAdd(&d2d_stamp_acc[i], st_sum[i]);
     if (!a.to_scratch) {
         // peak meter: |x| was tracked in the scaled domain; undo the power-of-two part exactly
         const double unscale = a.epi.bits == 32 ? 1.0 : 1.0 / (double)(1u << (a.epi.bits - 1));
@@ -386,7 +499,10 @@ std::vector<int8_t> build_mfma_tables(const d2d_filter_def& f, const MfmaLayout&
     for (int sh = 0; sh < 4; ++sh)                                  // window starts `sh` bytes into its first dword
         for (int ks = 0; ks < g.ksteps; ++ks)
             for (int l = 0; l < 64; ++l) {
-                const int row = l & 31, h = l >> 5, ph = row >> 2, limb = row & 3;
+                const int row = l & 31, h = l >> 5, limb = row & 3;
+                // D row i lands in lane half (i >> 2) & 1, register group i >> 3: give that slot output
+                // phase 4*half + group, so lane (r, half) owns the four CONSECUTIVE outputs 8r + 4*half + k
+                const int ph = 4 * ((row >> 2) & 1) + (row >> 3);
                 for (int j = 0; j < 16; ++j) {
                     const int p = 4 * (ks & 1) + (j >> 2);                        // register v = j>>2 of step ks
                     const int wb = 32 * (h * U + (ks >> 1)) + 8 * (j & 3) + p;     // bit of the LDS row words
@@ -415,7 +531,8 @@ static void mfma_geometry(const FirArgs& a, const MfmaLayout& g, MfmaArgs& m, si
     m.dadd = a.epi.dither == 'T' ? -1.0 : (a.epi.dither == 'R' ? -0.5 : 0.0);
     const double lim = a.epi.bits == 32 ? 1.0 : (double)(1u << (a.epi.bits - 1));
     m.qmax = lim - 1.0; m.qmin = -lim;
-    m.qmul = a.epi.bits == 20 ? 16u : 1u;
+    m.qsh = a.epi.bits == 20 ? 4u : 0u;
+    m.qmin_i = a.epi.bits == 32 ? 0 : -(1 << (a.epi.bits - 1)); m.qmax_i = a.epi.bits == 32 ? 0 : (1 << (a.epi.bits - 1)) - 1;
     m.U = (uint32_t)g.ksteps / 2;
     // |limb sum| <= (bytes of row window) * 255 * 128; below 2^23 the pairs recombine in int32
     m.wide = (uint64_t)g.ksteps * 4u * 255u * 128u >= (1u << 23) ? 1u : 0u;
@@ -427,10 +544,12 @@ static void mfma_geometry(const FirArgs& a, const MfmaLayout& g, MfmaArgs& m, si
     m.span = (16u + 31u * 8u * MB + (2 * m.U + 5) * 4u + 16u + 15u) & ~15u;
     const uint32_t ldw = m.span / 4;
     m.ppair = ((2u * (ldw + (ldw >> ls) + 2u)) * 4u + 15u) & ~15u;
-    m.off_waves = ((uint32_t)g.ksteps + 6u) * 1024u;
+    m.off_waves = ((uint32_t)g.ksteps + 6u) * 1024u + 64u;   // + MFMA-phase tokens
     m.off_out = ((C + 1) / 2) * m.ppair;
     m.off_pk = m.off_out + ((256u * C * a.epi.sample_bytes + 15u) & ~15u);
     m.wave_lds = m.off_pk + C * 64u * 8u + ((C * 16u + 15u) & ~15u);   // peaks + per-channel dither keys
+    { static const char* e = getenv("D2D_DBG"); m.dbg = e ? (uint32_t)atoi(e) : 0u; }
+    { static const char* e = getenv("D2D_STAGGER"); m.stagger = e ? (uint32_t)atoi(e) : 0u; }
     static const char* wenv = getenv("D2D_MFMA_WAVES");   // diagnostic override
     m.nwaves = wenv ? (uint32_t)atoi(wenv) : 8u;
     if (m.nwaves < 1 || m.nwaves > 8) m.nwaves = 8;
@@ -494,6 +613,12 @@ hipError_t launch_fir_mfma(const FirArgs& a, const MfmaLayout& g, uint32_t max_n
         case 16: return launch_mfma_t<16>(m, smem, nwt, nfiles, s);
         default: return hipErrorInvalidValue;
     }
+}
+
+void mfma_debug_stamps(unsigned long long out[8]) {
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(d2d_stamp_acc), sizeof(unsigned long long) * 8);
+    unsigned long long z[8] = {0};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(d2d_stamp_acc), z, sizeof(z));
 }
 
 const char* mfma_kernel_name(const MfmaLayout& g) {

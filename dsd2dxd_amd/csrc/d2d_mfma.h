@@ -25,5 +25,6 @@ size_t mfma_smem_bytes(const MfmaLayout& g, uint32_t channels, uint32_t sample_b
 std::vector<int8_t> build_mfma_tables(const d2d_filter_def& f, const MfmaLayout& g, bool msb_first);
 hipError_t launch_fir_mfma(const FirArgs& a, const MfmaLayout& g, uint32_t max_nout, uint32_t nstreams, hipStream_t s);
 const char* mfma_kernel_name(const MfmaLayout& g);
+void mfma_debug_stamps(unsigned long long out[8]);   // diagnostic (D2D_DBG=16)
 
 }  // namespace d2d
