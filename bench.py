@@ -35,25 +35,27 @@ WORKLOADS = {
     "dsd64_to_352k8_f32_stereo": (1, 352800, 32, "X", 2, 8 / 8 + 4),
     "dsd128_to_88k2_s24_stereo": (2, 88200, 24, "T", 2, 64 / 8 + 3),
     "dsd64_to_96k_s24_stereo": (1, 96000, 24, "T", 2, 29.4 / 8 + 3),
-    "dsd512_to_96k_s24_8ch": (8, 96000, 24, "T", 8, 235.2 / 8 + 3),
+    "dsd512_to_96k_s24_8ch": (8, 96000, 24, "T", 8, 235.2 / 8 + 3),      # config 5: byte-interleaved MSB-first
 }
+LAYOUTS = {"dsd512_to_96k_s24_8ch": ("I", "M", 1)}                       # default: planar 4096 LSB-first
 
 
-def make_files(n_files, bytes_per_channel, dsd_rate, distinct, rank, threads):
+def make_files(n_files, bytes_per_channel, dsd_rate, distinct, rank, threads, channels=2, fmt="P", endian="L", block=4096):
     """Synthetic planar-4096 LSB-first stereo files: half 1 kHz-family sines at 0.352 FS, half pink
     noise at ~0.098 RMS.  `distinct` different files are generated and tiled."""
     from helpers import pack_layout, synth
     distinct = min(distinct, n_files)
 
+    msb = endian == "M"
+
     def one(i):
         seed = 1000 * rank + i
         if i % 2 == 0:
-            ch = [synth("sine", bytes_per_channel, seed=seed, freq=1000.0 + 7 * i, phase=0.1 * i, dsd_rate=dsd_rate),
-                  synth("sine", bytes_per_channel, seed=seed + 500, freq=1000.0 + 7 * i, phase=0.1 * i + 0.5, dsd_rate=dsd_rate)]
+            ch = [synth("sine", bytes_per_channel, seed=seed + 500 * c, freq=1000.0 + 7 * i, phase=0.1 * i + 0.5 * c, dsd_rate=dsd_rate, msb_first=msb)
+                  for c in range(channels)]
         else:
-            ch = [synth("pink", bytes_per_channel, seed=seed, amp=0.098, dsd_rate=dsd_rate),
-                  synth("pink", bytes_per_channel, seed=seed + 500, amp=0.098, dsd_rate=dsd_rate)]
-        return pack_layout(ch, "P", 4096)
+            ch = [synth("pink", bytes_per_channel, seed=seed + 500 * c, amp=0.098, dsd_rate=dsd_rate, msb_first=msb) for c in range(channels)]
+        return pack_layout(ch, fmt, block)
 
     with ThreadPoolExecutor(max_workers=threads) as ex:
         base = list(ex.map(one, range(distinct)))
@@ -70,7 +72,7 @@ def cpu_baseline(kw, files, threads, budget_s):
 
     def work(buf):
         o = O.Oracle(**kw)
-        step = 4096 * C_ * chunk_blocks
+        step = 4096 * C_ * chunk_blocks          # (a multiple of every layout's block group)
         n = 0
         t0 = time.perf_counter()
         while time.perf_counter() - t0 < budget_s:        # the file again and again until the budget is spent
@@ -132,17 +134,16 @@ def main():
     M = DSD64 * dsd_rate / out_rate
     blocks = max(1, int(round(args.seconds * DSD64 * dsd_rate / 8 / 4096)))
     bpc = blocks * 4096                                   # bytes per channel per file
-    kw = dict(dsd_rate=dsd_rate, output_rate=out_rate, channels=channels, fmt="P", endianness="L",
-              block_size=4096, filter="E", bit_depth=bits, dither=dither, seed=206)
-    if channels != 2:
-        raise SystemExit("bench.py generates stereo files; use tools/bench_extra.py for other channel counts")
+    fmt, endian, block = LAYOUTS.get(args.workload, ("P", "L", 4096))
+    kw = dict(dsd_rate=dsd_rate, output_rate=out_rate, channels=channels, fmt=fmt, endianness=endian,
+              block_size=block, filter="E", bit_depth=bits, dither=dither, seed=206)
     kernel = {"auto": d.KERNEL_AUTO, "lut": d.KERNEL_LUT, "mfma": d.KERNEL_MFMA}[args.kernel]
     ncpu = os.cpu_count() or 1
     gen_threads = max(1, min(32, ncpu // max(1, min(world, 8))))
 
     if args.distinct <= 0:
         args.distinct = args.files
-    files = make_files(args.files, bpc, dsd_rate, args.distinct, rank, gen_threads)
+    files = make_files(args.files, bpc, dsd_rate, args.distinct, rank, gen_threads, channels, fmt, endian, block)
     eng = d.Engine(n_files=args.files, kernel=kernel, device=local_dev, **kw)
     stream = torch.cuda.current_stream().cuda_stream
 
@@ -215,7 +216,7 @@ def main():
         "value": round(value, 3), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f64", "data": "synthetic (2nd-order 1-bit modulator: 1 kHz-family sines at 0.352 FS and pink noise at ~0.1 RMS; %d distinct files per rank%s)" % (min(args.distinct, args.files), "" if args.distinct >= args.files else " tiled to %d" % args.files),
-        "config": {"workload": f"{args.workload}: {args.files} files/GPU x {blocks * 4096 * 8 / (DSD64 * dsd_rate):.1f} s, planar 4096-B LSB-first -> {bits}-bit {out_rate} Hz, dither {dither}, filter E ({eng.info()['ntaps']} taps, M={M:g})",
+        "config": {"workload": f"{args.workload}: {args.files} files/GPU x {blocks * 4096 * 8 / (DSD64 * dsd_rate):.1f} s, {'planar 4096-B LSB-first' if fmt == 'P' else 'byte-interleaved MSB-first'} {channels} ch -> {bits}-bit {out_rate} Hz, dither {dither}, filter E ({eng.info()['ntaps']} taps, M={M:g})",
                    "files_per_gpu": args.files, "seconds_per_file": round(blocks * 4096 * 8 / (DSD64 * dsd_rate), 3),
                    "parallelism": f"files sharded over {world} GPU(s), no data-path collective", "kernel": eng.kernel_name()},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",

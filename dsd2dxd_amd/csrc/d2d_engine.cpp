@@ -66,6 +66,9 @@ struct d2d_engine {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_pool; size_t prof_used = 0;
     // staging for d2d_translate (host pointers)
     uint8_t* d_in = nullptr; size_t d_in_cap = 0;
+    // planar copies of byte-interleaved inputs (one slice per file), see d2d_deinterleave_kernel
+    uint8_t* d_planar = nullptr; size_t planar_stride = 0;
+    bool deinterleave = false;
     uint8_t* d_out = nullptr; size_t d_out_cap = 0;
 
     int fail(int code, const std::string& m) { err = m; return code; }
@@ -125,6 +128,7 @@ static void free_device(d2d_engine* e) {
     if (e->d_jobs) hipFree(e->d_jobs);
     if (e->h_jobs) hipHostFree(e->h_jobs);
     if (e->d_in) hipFree(e->d_in);
+    if (e->d_planar) hipFree(e->d_planar);
     if (e->d_out) hipFree(e->d_out);
     for (int i = 0; i < JOB_SLOTS; ++i)
         if (e->job_ev[i]) hipEventDestroy(e->job_ev[i]);
@@ -164,6 +168,10 @@ int d2d_create(const d2d_params* params, uint32_t n_files, d2d_engine** out) {
     e->M = f.M; e->Mb = f.M / 8; e->N = f.ntaps; e->Wb = f.ntaps / 8; e->S = f.S;
     e->C = e->p.channels;
     e->B = e->p.fmt == D2D_FMT_INTERLEAVED ? 1u : e->p.block_size;   // README.md:9
+    if (e->B == 1) {   // byte interleaved: mono is already planar; otherwise a planar copy is made per call
+        e->deinterleave = e->C > 1;
+        e->B = 4096;
+    }
     e->nstreams = n_files * e->C;
     e->files.resize(n_files);
     e->epi.gain = pow(10.0, e->p.level_db / 20.0);
@@ -305,6 +313,18 @@ int d2d_translate_batch_device(d2d_engine* e, d2d_file_io* io, uint32_t n_files,
         int rc = grow_scratch(e, (size_t)e->fc.resamp->P + max_nx, s);
         if (rc) return rc;
     }
+    uint32_t max_L = 0;
+    for (uint32_t f = 0; f < n_files; ++f) max_L = std::max<uint32_t>(max_L, (uint32_t)io[f].bytes_per_channel);
+    if (e->deinterleave) {
+        const size_t need = (((size_t)max_L * C) + 4095) & ~(size_t)4095;
+        if (need > e->planar_stride) {
+            HIPCHK(e, hipStreamSynchronize(s));
+            if (e->d_planar) HIPCHK(e, hipFree(e->d_planar));
+            e->d_planar = nullptr; e->planar_stride = 0;
+            HIPCHK(e, hipMalloc((void**)&e->d_planar, need * n_files));
+            e->planar_stride = need;
+        }
+    }
     // job table: pinned slot -> device
     const int slot = e->job_slot;
     e->job_slot = (slot + 1) % JOB_SLOTS;
@@ -316,7 +336,8 @@ int d2d_translate_batch_device(d2d_engine* e, d2d_file_io* io, uint32_t n_files,
         for (uint32_t c = 0; c < C; ++c) {
             const uint32_t sidx = f * C + c;
             StreamJob& j = hj[sidx];
-            j.in = (const uint8_t*)io[f].dsd;
+            j.in = e->deinterleave ? e->d_planar + (size_t)f * e->planar_stride : (const uint8_t*)io[f].dsd;
+            j.in_raw = e->deinterleave ? (const uint8_t*)io[f].dsd : nullptr;
             j.hist = e->d_hist[cur] + (size_t)sidx * e->keep;
             j.hist_next = e->d_hist[cur ^ 1] + (size_t)sidx * e->keep;
             j.out = io[f].pcm;
@@ -339,6 +360,8 @@ int d2d_translate_batch_device(d2d_engine* e, d2d_file_io* io, uint32_t n_files,
     HIPCHK(e, hipMemcpyAsync(e->d_jobs, hj, sizeof(StreamJob) * e->nstreams, hipMemcpyHostToDevice, s));
     HIPCHK(e, hipEventRecord(e->job_ev[slot], s));
     e->job_ev_used[slot] = true;
+
+    if (e->deinterleave) HIPCHK(e, launch_deinterleave(e->d_jobs, n_files, C, max_L, s));
 
     FirArgs a{};
     a.jobs = e->d_jobs;

@@ -13,7 +13,8 @@ constexpr int LUT_THREADS = 256;
 // One (file, channel) stream for one translate call.  All byte indices are "call-relative":
 // 0 = the first byte this call feeds for the channel; negative = carried history.
 struct StreamJob {
-    const uint8_t* in;      // device: the file's call buffer (all channels, reference layout)
+    const uint8_t* in;      // device: the file's call buffer (all channels) in the layout the FIR kernels read
+    const uint8_t* in_raw;  // device: the caller's byte-interleaved buffer when `in` is the engine's planar copy, else null
     const uint8_t* hist;    // device: this channel's `keep` history bytes (raw bit order)
     uint8_t*       hist_next; // device: where the updated history goes (ping-pong buffer)
     void*          out;     // device: the file's interleaved PCM frames for this call

@@ -160,6 +160,55 @@ __global__ __launch_bounds__(RS_THREADS) void d2d_resample_kernel(ResampArgs a, 
     block_peak_max(pk, job.peak, red);
 }
 
+// Byte-interleaved input (DFF, `-f I`: c0 c1 c0 c1 ...) -> the planar 4096-byte-block layout the FIR
+// kernels stream with 16-byte loads.  A block moves DI_TILE bytes per channel: the source range is
+// contiguous (coalesced 16-byte loads into LDS), each thread then gathers one channel's 16 bytes from
+// LDS and stores them as one 16-byte word.  The last (short) block group keeps the engine's layout
+// rule: channels packed back to back with the short length.
+constexpr uint32_t DI_TILE = 256;
+constexpr uint32_t DI_BLOCK = 4096;
+
+__global__ __launch_bounds__(256) void d2d_deinterleave_kernel(const StreamJob* jobs, uint32_t C) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const StreamJob job = jobs[blockIdx.y * C];
+    const uint32_t L = (uint32_t)job.L;
+    const D2D_GLOBAL uint8_t* src = as_global(job.in_raw);
+    D2D_GLOBAL uint8_t* dst = as_global(const_cast<uint8_t*>(job.in));
+    const uint32_t ntiles = (L + DI_TILE - 1) / DI_TILE;
+    for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const uint32_t j0 = tile * DI_TILE;
+        const uint32_t nj = min(DI_TILE, L - j0);                 // bytes per channel in this tile
+        const uint32_t nbytes = nj * C;
+        const uint64_t s0 = (uint64_t)j0 * C;
+        __syncthreads();
+        for (uint32_t i = threadIdx.x * 16; i < nbytes; i += 256 * 16) {
+            if (i + 16 <= nbytes && ((s0 + i) & 15) == 0) {
+                *reinterpret_cast<u32x4*>(smem + i) = *reinterpret_cast<const D2D_GLOBAL u32x4*>(src + s0 + i);
+            } else {
+                for (uint32_t b = i; b < min(i + 16, nbytes); ++b) smem[b] = src[s0 + b];
+            }
+        }
+        __syncthreads();
+        const uint32_t blk = j0 / DI_BLOCK, off0 = j0 - blk * DI_BLOCK;   // DI_TILE divides DI_BLOCK
+        const uint32_t blen = min(DI_BLOCK, L - blk * DI_BLOCK);
+        const uint32_t nq = (nj + 15) / 16;
+        for (uint32_t t = threadIdx.x; t < nq * C; t += 256) {
+            const uint32_t c = t / nq, q = t - c * nq;
+            const uint32_t n = min(16u, nj - q * 16);
+            uint32_t w[4] = {0, 0, 0, 0};
+#pragma unroll
+            for (uint32_t b = 0; b < 16; ++b)
+                if (b < n) w[b >> 2] |= (uint32_t)smem[(q * 16 + b) * C + c] << (8 * (b & 3));
+            const uint64_t d0 = (uint64_t)blk * DI_BLOCK * C + (uint64_t)c * blen + off0 + q * 16;
+            if (n == 16 && (d0 & 15) == 0) {
+                *reinterpret_cast<D2D_GLOBAL u32x4*>(dst + d0) = u32x4{w[0], w[1], w[2], w[3]};
+            } else {
+                for (uint32_t b = 0; b < n; ++b) dst[d0 + b] = (uint8_t)(w[b >> 2] >> (8 * (b & 3)));
+            }
+        }
+    }
+}
+
 // new_hist[j] = stream byte (L - keep + j), j in [0, keep)
 __global__ void d2d_history_kernel(const StreamJob* jobs, uint32_t C, uint32_t B, uint32_t keep) {
     const StreamJob job = jobs[blockIdx.x];
@@ -244,6 +293,15 @@ hipError_t launch_resample(const ResampArgs& a, uint32_t max_out, uint32_t nstre
     const uint32_t cap = (2048 + nstreams - 1) / nstreams;
     if (gx > cap) gx = cap;
     hipLaunchKernelGGL(d2d_resample_kernel, dim3(gx, nstreams), dim3(RS_THREADS), smem, s, a, xcap);
+    return hipGetLastError();
+}
+
+hipError_t launch_deinterleave(const StreamJob* jobs, uint32_t nfiles, uint32_t C, uint32_t max_L, hipStream_t s) {
+    if (nfiles == 0 || max_L == 0) return hipSuccess;
+    uint32_t gx = (max_L + DI_TILE - 1) / DI_TILE;
+    const uint32_t cap = (8192 + nfiles - 1) / nfiles;
+    if (gx > cap) gx = cap;
+    hipLaunchKernelGGL(d2d_deinterleave_kernel, dim3(gx, nfiles), dim3(256), (size_t)DI_TILE * C, s, jobs, C);
     return hipGetLastError();
 }
 

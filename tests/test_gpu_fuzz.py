@@ -1,0 +1,56 @@
+"""Seeded random configurations: every (rate, filter, depth, dither, layout, channel count, call
+pattern) the engine accepts must match the oracle bit for bit, with both kernels."""
+import numpy as np
+import pytest
+
+from helpers import pack_layout, random_bytes
+
+pytestmark = pytest.mark.gpu
+
+RATES = [(1, 88200), (1, 176400), (1, 352800), (2, 88200), (2, 176400), (2, 352800), (2, 705600), (4, 88200), (4, 352800),
+         (4, 1411200), (8, 352800), (1, 96000), (1, 192000), (1, 384000), (2, 96000), (4, 192000), (8, 96000)]
+
+
+def _case(seed):
+    rng = np.random.default_rng(seed)
+    dsd_rate, out_rate = RATES[rng.integers(len(RATES))]
+    filt = "E"
+    if out_rate % 44100 == 0 and out_rate <= 352800:
+        if dsd_rate == 1:
+            filt = rng.choice(["E", "X"] + (["D"] if out_rate == 352800 else []))
+        elif dsd_rate == 2:
+            filt = rng.choice(["E", "C"])
+    bits = int(rng.choice([16, 20, 24, 32]))
+    dither = str(rng.choice(["T", "R", "X", "F"]))
+    channels = int(rng.choice([1, 2, 2, 2, 3, 5, 6, 8]))
+    fmt = str(rng.choice(["P", "P", "I"]))
+    block = int(rng.choice([4096, 4096, 1024, 256, 48, 7])) if fmt == "P" else 1
+    endian = str(rng.choice(["L", "M"]))
+    level = float(rng.choice([0.0, 0.0, -3.0, 4.0, -0.5]))
+    kw = dict(dsd_rate=dsd_rate, output_rate=out_rate, channels=channels, fmt=fmt, endianness=endian, block_size=block,
+              filter=str(filt), bit_depth=bits, dither=dither, seed=int(rng.integers(1 << 30)), level_db=level)
+    total = int(rng.integers(2000, 30000))
+    ncuts = int(rng.integers(1, 6))
+    cuts = sorted(set([0, total] + [int(x) for x in rng.integers(0, total, ncuts)]))
+    if rng.random() < 0.3:
+        cuts.insert(1, cuts[1])            # a zero-length call
+    return kw, total, cuts
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_random_configuration(engine_lib, oracle_mod, seed):
+    kw, total, cuts = _case(seed)
+    chans = [random_bytes(total, 1000 * seed + c) for c in range(kw["channels"])]
+    bufs = [pack_layout([ch[a:b] for ch in chans], kw["fmt"], kw["block_size"]) if b > a else np.zeros(0, np.uint8)
+            for a, b in zip(cuts[:-1], cuts[1:])]
+    o = oracle_mod.Oracle(**kw)
+    want = []
+    for b in bufs:
+        r, rf = o.translate(b)
+        want.append(r[:rf * o.frame_bytes].copy())
+    want = np.concatenate(want) if want else np.zeros(0, np.uint8)
+    for kernel in (1, 2):
+        e = engine_lib.Engine(kernel=kernel, **kw)
+        got = np.concatenate([e.translate(b)[0] for b in bufs])
+        assert np.array_equal(got, want), (kernel, kw)
+        assert e.peak_dbfs() == o.peak_dbfs() or (np.isinf(e.peak_dbfs()) and np.isinf(o.peak_dbfs()))
