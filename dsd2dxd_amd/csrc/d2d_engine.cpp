@@ -224,9 +224,10 @@ int d2d_create(const d2d_params* params, uint32_t n_files, d2d_engine** out) {
         CK(hipMemcpy(e->d_fir_tables, t.data(), e->fir_table_bytes, hipMemcpyHostToDevice));
     }
     if (e->fc.resamp) {
-        e->resamp_bytes = sizeof(double) * (size_t)e->fc.resamp->L * e->fc.resamp->P;
+        const std::vector<double> rt = build_resamp_table(*e->fc.resamp);
+        e->resamp_bytes = sizeof(double) * rt.size();
         CK(hipMalloc((void**)&e->d_resamp, e->resamp_bytes));
-        CK(hipMemcpy(e->d_resamp, e->fc.resamp->coef, e->resamp_bytes, hipMemcpyHostToDevice));
+        CK(hipMemcpy(e->d_resamp, rt.data(), e->resamp_bytes, hipMemcpyHostToDevice));
         e->scratch_stride = (size_t)e->fc.resamp->P + 4096;
         CK(hipMalloc((void**)&e->d_scratch, sizeof(double) * e->scratch_stride * e->nstreams));
     }
@@ -397,6 +398,7 @@ int d2d_translate_batch_device(d2d_engine* e, d2d_file_io* io, uint32_t n_files,
         ResampArgs r{};
         r.jobs = e->d_jobs; r.coef = e->d_resamp;
         r.L = (uint32_t)e->fc.resamp->L; r.Mdn = (uint32_t)e->fc.resamp->Mdn; r.P = (uint32_t)e->fc.resamp->P;
+        r.nsteps = resamp_nsteps(*e->fc.resamp);
         r.epi = e->epi;
         HIPCHK(e, launch_resample(r, max_frames, e->nstreams, s));
         HIPCHK(e, launch_xhist(e->d_jobs, e->nstreams, r.P, s));

@@ -8,6 +8,7 @@
 #include <stdint.h>
 
 #include <string>
+#include <algorithm>
 #include <vector>
 
 #include "../../filters/filter_tables.inc"
@@ -77,6 +78,31 @@ inline LutLayout lut_layout(int MB, int Wb) {
     g.nq = (Wb + (g.R - 1) * MB + 7) / 8;
     g.ntab = g.pad + 16 * g.nq;
     return g;
+}
+
+// Stage-B coefficients packed for d2d_resample_kernel: task w serves the four residues r = 4w..4w+3 of
+// m = L*c + r; output r reads x[Mdn*c + b_r - k] with b_r = Mdn*r div L and phase Mdn*r mod L.  At step
+// s every output of the task is fed the same sample x[Mdn*c + b_max - s], so its coefficient is
+// g[phase_r][s - (b_max - b_r)], zero outside [0, P).  Layout [L/4][nsteps][4].
+inline uint32_t resamp_nsteps(const d2d_resamp_def& r) {
+    int dmax = 0;
+    for (int w = 0; w < r.L / 4; ++w) dmax = std::max(dmax, (r.Mdn * (4 * w + 3)) / r.L - (r.Mdn * 4 * w) / r.L);
+    return (uint32_t)(r.P + dmax);
+}
+inline std::vector<double> build_resamp_table(const d2d_resamp_def& r) {
+    const uint32_t nsteps = resamp_nsteps(r);
+    std::vector<double> t((size_t)(r.L / 4) * nsteps * 4, 0.0);
+    for (int w = 0; w < r.L / 4; ++w) {
+        const int bmax = (r.Mdn * (4 * w + 3)) / r.L;
+        for (int j = 0; j < 4; ++j) {
+            const int res = 4 * w + j, b = (r.Mdn * res) / r.L, phase = (r.Mdn * res) % r.L;
+            for (uint32_t s = 0; s < nsteps; ++s) {
+                const int k = (int)s - (bmax - b);
+                if (k >= 0 && k < r.P) t[((size_t)w * nsteps + s) * 4 + j] = r.coef[(size_t)phase * r.P + k];
+            }
+        }
+    }
+    return t;
 }
 
 // Nibble tables [ntab][16] of f64.  Table pad+2w serves the HIGH nibble of window byte w, table

@@ -62,9 +62,9 @@ struct FirArgs {
 
 struct ResampArgs {
     const StreamJob* jobs;
-    const double*    coef;     // [L][P] phase-major
+    const double*    coef;     // packed per task: [L/4][nsteps][4], see build_resamp_table()
     uint32_t L, Mdn, P;
-    uint32_t reserved;
+    uint32_t nsteps;           // P + widest spread of window starts inside a task
     Epilogue epi;
 };
 

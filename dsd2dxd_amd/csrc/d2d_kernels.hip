@@ -11,6 +11,8 @@
 // (/root/reference/src/main.rs:345,429; the rdsd2pcm crate itself is absent from the reference).
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+
 #include "d2d_device.h"
 #include "d2d_launch.h"
 
@@ -96,65 +98,114 @@ __global__ __launch_bounds__(LUT_THREADS) void d2d_fir_lut_kernel(FirArgs a) {
 
 // Stage B of the 48k cascade: y[m] = sum_k g[phi][k] * x[i_m - k],
 // t = Mdn*m, i_m = t div L, phi = t mod L; acc = fma(g, x, acc) for k ascending (the oracle's order,
-// so the f64 result is bit-identical).  A block converts RS_TILE consecutive outputs of one stream:
-// the coefficient table ([k][phase], so lanes with different phases hit different banks) and the
-// stretch of stage-A samples the tile needs sit in LDS; each thread carries four independent fma
-// chains (outputs t, t+256, t+512, t+768) so the dependent-fma latency is covered.
-constexpr int RS_THREADS = 256;
-constexpr int RS_PER_THREAD = 4;
-constexpr int RS_TILE = RS_THREADS * RS_PER_THREAD;
+// so the f64 result is bit-identical).
+//
+// Write m = L*c + r ("cycle" c, "residue" r).  Then i_m = Mdn*c + (Mdn*r div L) and phi = Mdn*r mod L:
+// the phase depends on r only and the window moves by exactly Mdn samples per cycle.  So
+//   * a wave takes RS_R consecutive residues and its 64 lanes take 64 consecutive cycles: every
+//     coefficient is wave-uniform (scalar loads from a table packed per task, no LDS traffic), and
+//     the lanes' x reads are Mdn doubles apart -- Mdn = 147 is odd, so the 64-bit LDS reads are
+//     bank-conflict free;
+//   * the RS_R outputs of a lane have windows that start within a few samples of each other, so one
+//     x read per step feeds all RS_R fma chains; an output whose window has not started / has ended
+//     gets a zero coefficient (fma(0, x, acc) == acc exactly: acc is never -0 and x is finite), each
+//     chain still sees its own taps in ascending k.
+// A tile = 64 cycles of one stream: its Mdn*64 + nsteps stage-A samples are staged in LDS, the
+// results go back through LDS so that the PCM stores run along consecutive frames.
+constexpr int RS_R = 4;
+constexpr int RS_WAVES = 10;                         // L/RS_R tasks per tile = RS_WAVES * NT
+constexpr int RS_THREADS = RS_WAVES * 64;
+constexpr int RS_SB = 8;                             // staging loads in flight per thread
+typedef const __attribute__((address_space(4))) double* rs_const_ptr;
 
-__global__ __launch_bounds__(RS_THREADS) void d2d_resample_kernel(ResampArgs a, uint32_t xcap) {
+__device__ __forceinline__ uint32_t quantise_bits(const Epilogue& ep, const StreamJob& job, double y, uint64_t n, double& pk) {
+    const uint32_t rnd = rng32(job, n);
+    pk = fmax(pk, fabs(y * ep.gain));
+    if (ep.bits == 32) return __float_as_uint(quantise_f32(ep, y, rnd));
+    return (uint32_t)quantise_int(ep, y, rnd);
+}
+
+template <int NT>
+__global__ __launch_bounds__(RS_THREADS, 2) void d2d_resample_kernel(ResampArgs a) {
     extern __shared__ __align__(16) unsigned char smem[];
-    double* gk = reinterpret_cast<double*>(smem);              // [P][L]
-    double* xt = gk + (size_t)a.P * a.L;                       // [xcap]
-    __shared__ double red[4];
+    double* xt = reinterpret_cast<double*>(smem);              // [Mdn*64 + nsteps], later the output tile
+    uint32_t* ot = reinterpret_cast<uint32_t*>(smem);          // [64][L]
+    __shared__ double red[RS_WAVES];
     const StreamJob job = a.jobs[blockIdx.y];
-    const uint32_t tid = threadIdx.x;
-    const uint32_t L = a.L, P = a.P, Mdn = a.Mdn;
-    for (uint32_t i = tid; i < L * P; i += RS_THREADS) {       // global [phase][k] -> LDS [k][phase]
-        const uint32_t phi = i / P, k = i - phi * P;
-        gk[k * L + phi] = a.coef[i];
-    }
+    const uint32_t tid = threadIdx.x, lane = tid & 63;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint32_t L = a.L, Mdn = a.Mdn, nsteps = a.nsteps;
     const D2D_GLOBAL double* xs = as_global(job.xs);
     uint8_t* pcm = reinterpret_cast<uint8_t*>(job.out);
     const uint32_t sample_bytes = a.epi.sample_bytes;
     const uint32_t frame_bytes = sample_bytes * a.epi.channels;
-    const uint32_t ntiles = (job.nres + RS_TILE - 1) / RS_TILE;
+    const uint64_t m_end = job.m0 + job.nres;
+    const uint64_t c_first = job.m0 / L, c_last = (m_end - 1) / L;
+    const uint32_t ntiles = job.nres ? (uint32_t)((c_last - c_first) / 64 + 1) : 0;
+    const uint32_t nx = Mdn * 64 + nsteps;
     double pk = 0.0;
     for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const uint32_t o0 = tile * RS_TILE;
-        const uint32_t o1 = min(o0 + RS_TILE, job.nres) - 1;   // last output of the tile
-        // stage-A samples the tile touches, as indices relative to job.n0 (history is negative)
-        const int64_t ifirst = (int64_t)(((job.m0 + o0) * (uint64_t)Mdn) / L) - (int64_t)job.n0 - (int64_t)(P - 1);
-        const int64_t ilast = (int64_t)(((job.m0 + o1) * (uint64_t)Mdn) / L) - (int64_t)job.n0;
-        const uint32_t nx = (uint32_t)(ilast - ifirst + 1);
+        const uint64_t cg0 = c_first + (uint64_t)tile * 64;
+        // xt[i] = stage-A sample (Mdn*cg0 - nsteps + 1 + i); outside what exists it is 0 (never used
+        // with a non-zero coefficient by an output that is stored)
+        const int64_t rel0 = (int64_t)(Mdn * cg0) - (int64_t)nsteps + 1 - (int64_t)job.n0;
         __syncthreads();
-        for (uint32_t i = tid; i < nx && i < xcap; i += RS_THREADS) xt[i] = xs[ifirst + (int64_t)i];
-        __syncthreads();
-        double acc[RS_PER_THREAD];
-        uint32_t xoff[RS_PER_THREAD], phi[RS_PER_THREAD];
+        // loads are issued RS_SB at a time from clamped (always valid) addresses, then masked
+        const int64_t jlo = -(int64_t)a.P, jhi = (int64_t)job.nout - 1;
+        for (uint32_t base = 0; base < nx; base += RS_THREADS * RS_SB) {
+            double v[RS_SB];
 #pragma unroll
-        for (int j = 0; j < RS_PER_THREAD; ++j) {
-            const uint32_t o = min(o0 + tid + j * RS_THREADS, o1);       // clamp: lanes past the end redo the last one
-            const uint64_t t = (job.m0 + o) * (uint64_t)Mdn;
-            const uint64_t im = t / L;
-            phi[j] = (uint32_t)(t - im * L);
-            xoff[j] = (uint32_t)((int64_t)im - (int64_t)job.n0 - ifirst);  // xt index of x[i_m]
-            acc[j] = 0.0;
-        }
-        for (uint32_t k = 0; k < P; ++k) {
-            const double* gr = gk + k * L;
-#pragma unroll
-            for (int j = 0; j < RS_PER_THREAD; ++j) acc[j] = fma(gr[phi[j]], xt[xoff[j] - k], acc[j]);
-        }
-#pragma unroll
-        for (int j = 0; j < RS_PER_THREAD; ++j) {
-            const uint32_t o = o0 + tid + j * RS_THREADS;
-            if (o <= o1) {
-                uint8_t* dst = pcm + (size_t)o * frame_bytes + job.ch * sample_bytes;
-                pk = fmax(pk, emit_sample(a.epi, job, acc[j], job.m0 + o, dst));
+            for (int u = 0; u < RS_SB; ++u) {
+                const int64_t j = rel0 + (int64_t)(base + u * RS_THREADS + tid);
+                v[u] = xs[min(max(j, jlo), jhi)];
             }
+#pragma unroll
+            for (int u = 0; u < RS_SB; ++u) {
+                const uint32_t i = base + u * RS_THREADS + tid;
+                const int64_t j = rel0 + (int64_t)i;
+                if (i < nx) xt[i] = (j >= jlo && j <= jhi) ? v[u] : 0.0;
+            }
+        }
+        __syncthreads();
+        double acc[NT][RS_R];
+#pragma unroll
+        for (int tix = 0; tix < NT; ++tix) {
+            const uint32_t task = wave + RS_WAVES * tix;
+            const uint32_t bmax = (Mdn * (RS_R * task + RS_R - 1)) / L;
+            rs_const_ptr tab = (rs_const_ptr)(a.coef) + (size_t)task * nsteps * RS_R;
+            const double* xp = xt + (Mdn * lane + bmax + nsteps - 1);
+#pragma unroll
+            for (int j = 0; j < RS_R; ++j) acc[tix][j] = 0.0;
+#pragma unroll 8
+            for (uint32_t s = 0; s < nsteps; ++s) {
+                const double x = xp[-(int32_t)s];
+#pragma unroll
+                for (int j = 0; j < RS_R; ++j) acc[tix][j] = fma(tab[s * RS_R + j], x, acc[tix][j]);
+            }
+        }
+        __syncthreads();                                       // all x reads done: reuse the tile for output
+#pragma unroll
+        for (int tix = 0; tix < NT; ++tix) {
+            const uint32_t task = wave + RS_WAVES * tix;
+#pragma unroll
+            for (int j = 0; j < RS_R; ++j) {
+                const uint32_t r = RS_R * task + j;
+                const uint64_t m = (cg0 + lane) * L + r;
+                uint32_t bits = 0;
+                if (m >= job.m0 && m < m_end) bits = quantise_bits(a.epi, job, acc[tix][j], m, pk);
+                ot[lane * L + r] = bits;
+            }
+        }
+        __syncthreads();
+        const uint64_t mb = cg0 * L;
+        for (uint32_t i = tid; i < 64 * L; i += RS_THREADS) {
+            const uint64_t m = mb + i;
+            if (m < job.m0 || m >= m_end) continue;
+            const uint32_t bits = ot[i];
+            uint8_t* dst = pcm + (size_t)(m - job.m0) * frame_bytes + job.ch * sample_bytes;
+            if (sample_bytes == 4) *reinterpret_cast<uint32_t*>(dst) = bits;
+            else if (sample_bytes == 2) *reinterpret_cast<uint16_t*>(dst) = (uint16_t)bits;
+            else { dst[0] = (uint8_t)bits; dst[1] = (uint8_t)(bits >> 8); dst[2] = (uint8_t)(bits >> 16); }
         }
     }
     block_peak_max(pk, job.peak, red);
@@ -277,23 +328,34 @@ const char* lut_kernel_name(int MB) {
     }
 }
 
-hipError_t launch_resample(const ResampArgs& a, uint32_t max_out, uint32_t nstreams, hipStream_t s) {
-    if (nstreams == 0 || max_out == 0) return hipSuccess;
-    // stage-A samples one tile can touch: RS_TILE * Mdn / L advance + P taps (+ rounding slack)
-    const uint32_t xcap = (uint32_t)(((uint64_t)RS_TILE * a.Mdn) / a.L) + a.P + 8;
-    const size_t smem = ((size_t)a.L * a.P + xcap) * sizeof(double);
+template <int NT>
+static hipError_t launch_resample_nt(const ResampArgs& a, uint32_t gx, uint32_t nstreams, size_t smem, hipStream_t s) {
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&d2d_resample_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);   // + 32 B static
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&d2d_resample_kernel<NT>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024 - 256);
         if (e != hipSuccess) return e;
         attr_done = true;
     }
-    uint32_t gx = (max_out + RS_TILE - 1) / RS_TILE;
-    const uint32_t cap = (2048 + nstreams - 1) / nstreams;
-    if (gx > cap) gx = cap;
-    hipLaunchKernelGGL(d2d_resample_kernel, dim3(gx, nstreams), dim3(RS_THREADS), smem, s, a, xcap);
+    hipLaunchKernelGGL(d2d_resample_kernel<NT>, dim3(gx, nstreams), dim3(RS_THREADS), smem, s, a);
     return hipGetLastError();
+}
+
+hipError_t launch_resample(const ResampArgs& a, uint32_t max_out, uint32_t nstreams, hipStream_t s) {
+    if (nstreams == 0 || max_out == 0) return hipSuccess;
+    const uint32_t ntask = a.L / RS_R;
+    if (a.L % RS_R || ntask % RS_WAVES) return hipErrorInvalidValue;
+    const size_t smem = std::max((size_t)(a.Mdn * 64 + a.nsteps) * sizeof(double), (size_t)64 * a.L * 4);
+    if (smem > 80 * 1024 - 256) return hipErrorInvalidValue;
+    uint32_t gx = max_out / (64 * a.L) + 2;                    // tiles follow absolute cycles: up to one extra
+    const uint32_t cap = (4096 + nstreams - 1) / nstreams;
+    if (gx > cap) gx = cap;
+    switch (ntask / RS_WAVES) {
+        case 1: return launch_resample_nt<1>(a, gx, nstreams, smem, s);
+        case 2: return launch_resample_nt<2>(a, gx, nstreams, smem, s);
+        case 4: return launch_resample_nt<4>(a, gx, nstreams, smem, s);
+        default: return hipErrorInvalidValue;
+    }
 }
 
 hipError_t launch_deinterleave(const StreamJob* jobs, uint32_t nfiles, uint32_t C, uint32_t max_L, hipStream_t s) {
