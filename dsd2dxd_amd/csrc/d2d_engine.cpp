@@ -55,7 +55,7 @@ struct d2d_engine {
     double* d_resamp = nullptr;   size_t resamp_bytes = 0;
     uint8_t* d_hist[2] = {nullptr, nullptr}; int hist_cur = 0;
     double* d_peak = nullptr;
-    double* d_scratch = nullptr; size_t scratch_stride = 0;   // doubles per stream
+    int32_t* d_scratch = nullptr; size_t scratch_stride = 0;  // stage-A integers per stream (multiple of 4)
     StreamJob* d_jobs = nullptr;
     StreamJob* h_jobs = nullptr;          // pinned, JOB_SLOTS x nstreams
     hipEvent_t job_ev[JOB_SLOTS]{}; bool job_ev_used[JOB_SLOTS]{}; int job_slot = 0;
@@ -143,7 +143,7 @@ static int reset_state(d2d_engine* e) {
     HIPCHK(e, hipMemset(e->d_hist[0], idle, hbytes));
     HIPCHK(e, hipMemset(e->d_hist[1], idle, hbytes));
     HIPCHK(e, hipMemset(e->d_peak, 0, sizeof(double) * e->nstreams));
-    if (e->d_scratch) HIPCHK(e, hipMemset(e->d_scratch, 0, sizeof(double) * e->scratch_stride * e->nstreams));
+    if (e->d_scratch) HIPCHK(e, hipMemset(e->d_scratch, 0, sizeof(int32_t) * e->scratch_stride * e->nstreams));
     for (auto& f : e->files) f = FileState{};
     e->hist_cur = 0;
     return D2D_OK;
@@ -224,12 +224,12 @@ int d2d_create(const d2d_params* params, uint32_t n_files, d2d_engine** out) {
         CK(hipMemcpy(e->d_fir_tables, t.data(), e->fir_table_bytes, hipMemcpyHostToDevice));
     }
     if (e->fc.resamp) {
-        const std::vector<double> rt = build_resamp_table(*e->fc.resamp);
+        const std::vector<double> rt = build_resamp_table(*e->fc.resamp, e->S);
         e->resamp_bytes = sizeof(double) * rt.size();
         CK(hipMalloc((void**)&e->d_resamp, e->resamp_bytes));
         CK(hipMemcpy(e->d_resamp, rt.data(), e->resamp_bytes, hipMemcpyHostToDevice));
         e->scratch_stride = (size_t)e->fc.resamp->P + 4096;
-        CK(hipMalloc((void**)&e->d_scratch, sizeof(double) * e->scratch_stride * e->nstreams));
+        CK(hipMalloc((void**)&e->d_scratch, sizeof(int32_t) * e->scratch_stride * e->nstreams));
     }
     const size_t hbytes = (size_t)e->nstreams * e->keep;
     CK(hipMalloc((void**)&e->d_hist[0], hbytes));
@@ -273,12 +273,12 @@ size_t d2d_next_frames(const d2d_engine* e, uint32_t file, size_t L) {
 
 static int grow_scratch(d2d_engine* e, size_t need_stride, hipStream_t s) {
     if (need_stride <= e->scratch_stride) return D2D_OK;
-    size_t ns = std::max(need_stride, e->scratch_stride * 2);
-    double* nb = nullptr;
-    HIPCHK(e, hipMalloc((void**)&nb, sizeof(double) * ns * e->nstreams));
+    size_t ns = (std::max(need_stride, e->scratch_stride * 2) + 3) & ~(size_t)3;
+    int32_t* nb = nullptr;
+    HIPCHK(e, hipMalloc((void**)&nb, sizeof(int32_t) * ns * e->nstreams));
     const size_t P = (size_t)e->fc.resamp->P;
-    HIPCHK(e, hipMemcpy2DAsync(nb, ns * sizeof(double), e->d_scratch, e->scratch_stride * sizeof(double),
-                               P * sizeof(double), e->nstreams, hipMemcpyDeviceToDevice, s));
+    HIPCHK(e, hipMemcpy2DAsync(nb, ns * sizeof(int32_t), e->d_scratch, e->scratch_stride * sizeof(int32_t),
+                               P * sizeof(int32_t), e->nstreams, hipMemcpyDeviceToDevice, s));
     HIPCHK(e, hipStreamSynchronize(s));
     HIPCHK(e, hipFree(e->d_scratch));
     e->d_scratch = nb; e->scratch_stride = ns;

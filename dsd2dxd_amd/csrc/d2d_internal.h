@@ -18,7 +18,8 @@ struct StreamJob {
     const uint8_t* hist;    // device: this channel's `keep` history bytes (raw bit order)
     uint8_t*       hist_next; // device: where the updated history goes (ping-pong buffer)
     void*          out;     // device: the file's interleaved PCM frames for this call
-    double*        xs;      // device: 48k cascade only -- xs[i] = stage-A output n0+i, xs[-P..-1] = carried
+    int32_t*       xs;      // device: 48k cascade only -- xs[i] = stage-A output n0+i as the integer y*2^S
+                            // (exact: |sum q s| < 2^31 for every table), xs[-P..-1] = carried
     double*        peak;    // device: this channel's running peak (as non-negative f64)
     uint64_t       L;       // bytes per channel fed by this call
     int64_t        e0;      // one past the newest byte of output n0's window (call-relative)
@@ -53,16 +54,16 @@ struct FirArgs {
     uint32_t nq;               // LUT: qwords each lane walks
     uint32_t B;                // effective block size (1 = byte interleaved)
     uint32_t keep;             // history bytes per channel
-    uint32_t to_scratch;       // 1: write raw f64 FIR outputs to job.out (stage A of the 48k cascade)
+    uint32_t to_scratch;       // 1: write the FIR outputs as integers y*2^S to job.xs (stage A of the 48k cascade)
     uint32_t ksteps;           // MFMA: K steps
-    int32_t  scale_bits;       // MFMA: S
+    int32_t  scale_bits;       // S of the tap table (h = q * 2^-S)
     uint32_t reserved;
     Epilogue epi;
 };
 
 struct ResampArgs {
     const StreamJob* jobs;
-    const double*    coef;     // packed per task: [L/4][nsteps][4], see build_resamp_table()
+    const double*    coef;     // packed per task: [L/4][nsteps][4] and pre-scaled by 2^-S, see build_resamp_table()
     uint32_t L, Mdn, P;
     uint32_t nsteps;           // P + widest spread of window starts inside a task
     Epilogue epi;

@@ -12,6 +12,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdlib>
 
 #include "d2d_device.h"
 #include "d2d_launch.h"
@@ -85,7 +86,7 @@ __global__ __launch_bounds__(LUT_THREADS) void d2d_fir_lut_kernel(FirArgs a) {
             const uint32_t nl = (tile * LUT_THREADS + tid) * R + r;
             if (nl < job.nout) {
                 if (a.to_scratch) {
-                    job.xs[nl] = acc[r];
+                    job.xs[nl] = (int32_t)ldexp(acc[r], a.scale_bits);      // exact integer, |.| < 2^31
                 } else {
                     uint8_t* dst = reinterpret_cast<uint8_t*>(job.out) + (size_t)nl * frame_bytes + job.ch * sample_bytes;
                     pk = fmax(pk, emit_sample(a.epi, job, acc[r], job.n0 + nl, dst));
@@ -115,101 +116,150 @@ __global__ __launch_bounds__(LUT_THREADS) void d2d_fir_lut_kernel(FirArgs a) {
 constexpr int RS_R = 4;
 constexpr int RS_WAVES = 10;                         // L/RS_R tasks per tile = RS_WAVES * NT
 constexpr int RS_THREADS = RS_WAVES * 64;
-constexpr int RS_SB = 8;                             // staging loads in flight per thread
-typedef const __attribute__((address_space(4))) double* rs_const_ptr;
+constexpr int RS_LD = 4;                             // a tile's samples: RS_LD 16-byte loads per thread
+typedef double rs_d8 __attribute__((ext_vector_type(8)));
+typedef const __attribute__((address_space(4))) rs_d8* rs_const8;
+constexpr int RS_XPAD = 4;                           // doubles in front of the x tile (look-ahead reads)
 
-__device__ __forceinline__ uint32_t quantise_bits(const Epilogue& ep, const StreamJob& job, double y, uint64_t n, double& pk) {
-    const uint32_t rnd = rng32(job, n);
+// rng32() for an output `o` of this call (index m0 + o; lo32 arithmetic wraps like the counter does)
+__device__ __forceinline__ uint32_t quantise_bits(const Epilogue& ep, const StreamJob& job, double y, uint32_t o, double& pk) {
+    const uint32_t rnd = rng32(job, (uint64_t)(job.rng_lo0 + o));
     pk = fmax(pk, fabs(y * ep.gain));
     if (ep.bits == 32) return __float_as_uint(quantise_f32(ep, y, rnd));
     return (uint32_t)quantise_int(ep, y, rnd);
 }
 
+// One trip = four steps of the four fma chains.  The coefficients (two scalar 64-byte loads) and the
+// samples (LDS) of the NEXT trip are requested first and consumed by an empty asm after the fmas: the
+// only wait of the trip then sits behind the arithmetic.  (Scalar loads return out of order, so any
+// wait placed while one is in flight is a wait for everything: it must not precede the fmas.)
+#define RS_TRIP(Q, CA, CB, X0, X1, X2, X3, NA, NB, Y0, Y1, Y2, Y3)                                   \
+    {                                                                                                 \
+        NA = t8[2 * (Q) + 2]; NB = t8[2 * (Q) + 3];                 /* past the end: table padding */ \
+        const double* xn = xp - 4 * (int32_t)((Q) + 1);             /* below the tile: RS_XPAD */     \
+        Y0 = xn[0]; Y1 = xn[-1]; Y2 = xn[-2]; Y3 = xn[-3];                                            \
+        __builtin_amdgcn_sched_barrier(0);                                                            \
+        _Pragma("unroll") for (int j = 0; j < RS_R; ++j) acc[j] = fma(CA[j], X0, acc[j]);             \
+        _Pragma("unroll") for (int j = 0; j < RS_R; ++j) acc[j] = fma(CA[4 + j], X1, acc[j]);         \
+        _Pragma("unroll") for (int j = 0; j < RS_R; ++j) acc[j] = fma(CB[j], X2, acc[j]);             \
+        _Pragma("unroll") for (int j = 0; j < RS_R; ++j) acc[j] = fma(CB[4 + j], X3, acc[j]);         \
+        __builtin_amdgcn_sched_barrier(0);                                                            \
+        asm volatile("" :: "s"(NA), "s"(NB), "v"(Y0), "v"(Y1), "v"(Y2), "v"(Y3));                     \
+    }
+
 template <int NT>
-__global__ __launch_bounds__(RS_THREADS, 2) void d2d_resample_kernel(ResampArgs a) {
+__global__ __launch_bounds__(RS_THREADS, 6) void d2d_resample_kernel(ResampArgs a, uint32_t dbg) {
     extern __shared__ __align__(16) unsigned char smem[];
-    double* xt = reinterpret_cast<double*>(smem);              // [Mdn*64 + nsteps], later the output tile
+    double* xt = reinterpret_cast<double*>(smem);              // [RS_XPAD + Mdn*64 + nsteps], later the output tile
     uint32_t* ot = reinterpret_cast<uint32_t*>(smem);          // [64][L]
     __shared__ double red[RS_WAVES];
-    const StreamJob job = a.jobs[blockIdx.y];
+    const StreamJob& job = a.jobs[blockIdx.y];
     const uint32_t tid = threadIdx.x, lane = tid & 63;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const uint32_t L = a.L, Mdn = a.Mdn, nsteps = a.nsteps;
-    const D2D_GLOBAL double* xs = as_global(job.xs);
-    uint8_t* pcm = reinterpret_cast<uint8_t*>(job.out);
-    const uint32_t sample_bytes = a.epi.sample_bytes;
-    const uint32_t frame_bytes = sample_bytes * a.epi.channels;
-    const uint64_t m_end = job.m0 + job.nres;
-    const uint64_t c_first = job.m0 / L, c_last = (m_end - 1) / L;
-    const uint32_t ntiles = job.nres ? (uint32_t)((c_last - c_first) / 64 + 1) : 0;
-    const uint32_t nx = Mdn * 64 + nsteps;
+    const uint64_t m0 = job.m0;
+    const uint32_t nres = job.nres;
+    const uint64_t c_first = m0 / L;
+    const uint32_t ntiles = nres ? (uint32_t)(((m0 + nres - 1) / L - c_first) / 64 + 1) : 0;
+    // everything below is 32-bit and relative to this call: stage-A indices to job.n0, outputs to m0
+    const int32_t rel_c0 = (int32_t)((int64_t)(Mdn * c_first) - (int64_t)job.n0) - (int32_t)nsteps + 1;
+    const int32_t o_c0 = (int32_t)((int64_t)(c_first * L) - (int64_t)m0);        // in (-L, 0]
+    const int32_t jlo = -(int32_t)a.P, jhi = (int32_t)job.nout - 1;
+    const D2D_GLOBAL int32_t* xs = as_global(job.xs);
+    const uint32_t nxa = (Mdn * 64 + nsteps + 3 + 3) & ~3u;     // tile samples incl. up to 3 of alignment slack
     double pk = 0.0;
+    // The tile's stage-A integers start at rel0 (relative to job.n0); they are fetched from rel0a =
+    // rel0 rounded down to a multiple of 4 so that a thread moves 16 aligned bytes per load, and land
+    // converted to f64 (exact) at xt[RS_XPAD + i] for sample rel0a + i.  Samples that do not exist are
+    // 0: they only ever meet a zero coefficient or an output that is not stored.  The NEXT tile is
+    // fetched into registers before this tile's fma loop starts, so the HBM reads run under the
+    // arithmetic instead of in a phase of their own.
+    typedef int32_t i32x4 __attribute__((ext_vector_type(4)));
+    i32x4 v[RS_LD];
+    auto prefetch = [&](uint32_t tile) {
+        const int32_t rel0a = (rel_c0 + (int32_t)(tile * 64 * Mdn)) & ~3;
+        if (rel0a >= jlo && rel0a + (int32_t)(4 * RS_LD * RS_THREADS) - 1 <= jhi) {       // interior tile
+#pragma unroll
+            for (int u = 0; u < RS_LD; ++u)
+                v[u] = *reinterpret_cast<const D2D_GLOBAL i32x4*>(xs + (rel0a + (int32_t)(4 * (u * RS_THREADS + tid))));
+        } else {
+#pragma unroll
+            for (int u = 0; u < RS_LD; ++u)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int32_t j = rel0a + (int32_t)(4 * (u * RS_THREADS + tid) + e);
+                    const int32_t x = xs[min(max(j, jlo), jhi)];                          // always a valid address
+                    v[u][e] = (j >= jlo && j <= jhi) ? x : 0;
+                }
+        }
+    };
+    if (blockIdx.x < ntiles && !(dbg & 256)) prefetch(blockIdx.x);
     for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const uint64_t cg0 = c_first + (uint64_t)tile * 64;
-        // xt[i] = stage-A sample (Mdn*cg0 - nsteps + 1 + i); outside what exists it is 0 (never used
-        // with a non-zero coefficient by an output that is stored)
-        const int64_t rel0 = (int64_t)(Mdn * cg0) - (int64_t)nsteps + 1 - (int64_t)job.n0;
+        const int32_t rel0 = rel_c0 + (int32_t)(tile * 64 * Mdn);
         __syncthreads();
-        // loads are issued RS_SB at a time from clamped (always valid) addresses, then masked
-        const int64_t jlo = -(int64_t)a.P, jhi = (int64_t)job.nout - 1;
-        for (uint32_t base = 0; base < nx; base += RS_THREADS * RS_SB) {
-            double v[RS_SB];
 #pragma unroll
-            for (int u = 0; u < RS_SB; ++u) {
-                const int64_t j = rel0 + (int64_t)(base + u * RS_THREADS + tid);
-                v[u] = xs[min(max(j, jlo), jhi)];
-            }
-#pragma unroll
-            for (int u = 0; u < RS_SB; ++u) {
-                const uint32_t i = base + u * RS_THREADS + tid;
-                const int64_t j = rel0 + (int64_t)i;
-                if (i < nx) xt[i] = (j >= jlo && j <= jhi) ? v[u] : 0.0;
+        for (int u = 0; u < RS_LD; ++u) {
+            const uint32_t i = 4 * (u * RS_THREADS + tid);
+            if (i < nxa) {
+                typedef double f64x2 __attribute__((ext_vector_type(2)));
+                f64x2* dst = reinterpret_cast<f64x2*>(xt + RS_XPAD + i);
+                dst[0] = f64x2{(double)v[u][0], (double)v[u][1]};
+                dst[1] = f64x2{(double)v[u][2], (double)v[u][3]};
             }
         }
         __syncthreads();
-        double acc[NT][RS_R];
+        if (tile + gridDim.x < ntiles && !(dbg & 256)) prefetch(tile + gridDim.x);
+
+        const int32_t o_lane = o_c0 + (int32_t)((tile * 64 + lane) * L);         // output of residue 0 in this lane's cycle
+        uint32_t bits[NT][RS_R];
 #pragma unroll
         for (int tix = 0; tix < NT; ++tix) {
             const uint32_t task = wave + RS_WAVES * tix;
             const uint32_t bmax = (Mdn * (RS_R * task + RS_R - 1)) / L;
-            rs_const_ptr tab = (rs_const_ptr)(a.coef) + (size_t)task * nsteps * RS_R;
-            const double* xp = xt + (Mdn * lane + bmax + nsteps - 1);
+            rs_const8 t8 = (rs_const8)(a.coef) + (size_t)task * (nsteps / 2);     // 2 steps per rs_d8
+            const double* xp = xt + RS_XPAD + (rel0 & 3) + (Mdn * lane + bmax + nsteps - 1);
+            double acc[RS_R];
 #pragma unroll
-            for (int j = 0; j < RS_R; ++j) acc[tix][j] = 0.0;
-#pragma unroll 8
-            for (uint32_t s = 0; s < nsteps; ++s) {
-                const double x = xp[-(int32_t)s];
+            for (int j = 0; j < RS_R; ++j) acc[j] = 0.0;
+            rs_d8 ca = t8[0], cb = t8[1], da, db;
+            double x0 = xp[0], x1 = xp[-1], x2 = xp[-2], x3 = xp[-3], y0, y1, y2, y3;
+            asm volatile("" :: "s"(ca), "s"(cb), "v"(x0), "v"(x1), "v"(x2), "v"(x3));   // enter the loop with nothing in flight
+            const uint32_t ntrips = (dbg & 512) ? 2u : nsteps / 4;
+            uint32_t q = 0;
+            for (; q + 2 <= ntrips; q += 2) {
+                RS_TRIP(q, ca, cb, x0, x1, x2, x3, da, db, y0, y1, y2, y3)
+                RS_TRIP(q + 1, da, db, y0, y1, y2, y3, ca, cb, x0, x1, x2, x3)
+            }
+            if (q < ntrips) RS_TRIP(q, ca, cb, x0, x1, x2, x3, da, db, y0, y1, y2, y3)
 #pragma unroll
-                for (int j = 0; j < RS_R; ++j) acc[tix][j] = fma(tab[s * RS_R + j], x, acc[tix][j]);
+            for (int j = 0; j < RS_R; ++j) {
+                const int32_t o = o_lane + (int32_t)(RS_R * task + j);
+                bits[tix][j] = ((uint32_t)o < nres && !(dbg & 1024)) ? quantise_bits(a.epi, job, acc[j], (uint32_t)o, pk) : 0u;
             }
         }
         __syncthreads();                                       // all x reads done: reuse the tile for output
 #pragma unroll
-        for (int tix = 0; tix < NT; ++tix) {
-            const uint32_t task = wave + RS_WAVES * tix;
+        for (int tix = 0; tix < NT; ++tix)
 #pragma unroll
-            for (int j = 0; j < RS_R; ++j) {
-                const uint32_t r = RS_R * task + j;
-                const uint64_t m = (cg0 + lane) * L + r;
-                uint32_t bits = 0;
-                if (m >= job.m0 && m < m_end) bits = quantise_bits(a.epi, job, acc[tix][j], m, pk);
-                ot[lane * L + r] = bits;
-            }
-        }
+            for (int j = 0; j < RS_R; ++j) ot[lane * L + RS_R * (wave + RS_WAVES * tix) + j] = bits[tix][j];
         __syncthreads();
-        const uint64_t mb = cg0 * L;
+        const uint32_t sample_bytes = a.epi.sample_bytes;
+        const uint32_t frame_bytes = sample_bytes * a.epi.channels;
+        uint8_t* pcm = reinterpret_cast<uint8_t*>(job.out) + job.ch * sample_bytes;
+        const int32_t o_tile = o_c0 + (int32_t)(tile * 64 * L);
         for (uint32_t i = tid; i < 64 * L; i += RS_THREADS) {
-            const uint64_t m = mb + i;
-            if (m < job.m0 || m >= m_end) continue;
-            const uint32_t bits = ot[i];
-            uint8_t* dst = pcm + (size_t)(m - job.m0) * frame_bytes + job.ch * sample_bytes;
-            if (sample_bytes == 4) *reinterpret_cast<uint32_t*>(dst) = bits;
-            else if (sample_bytes == 2) *reinterpret_cast<uint16_t*>(dst) = (uint16_t)bits;
-            else { dst[0] = (uint8_t)bits; dst[1] = (uint8_t)(bits >> 8); dst[2] = (uint8_t)(bits >> 16); }
+            const int32_t o = o_tile + (int32_t)i;
+            if ((uint32_t)o >= nres || (dbg & 2048)) continue;
+            const uint32_t w = ot[i];
+            uint8_t* dst = pcm + (size_t)(uint32_t)o * frame_bytes;
+            if (sample_bytes == 4) *reinterpret_cast<uint32_t*>(dst) = w;
+            else if (sample_bytes == 2) *reinterpret_cast<uint16_t*>(dst) = (uint16_t)w;
+            else { dst[0] = (uint8_t)w; dst[1] = (uint8_t)(w >> 8); dst[2] = (uint8_t)(w >> 16); }
         }
     }
     block_peak_max(pk, job.peak, red);
 }
+#undef RS_TRIP
 
 // Byte-interleaved input (DFF, `-f I`: c0 c1 c0 c1 ...) -> the planar 4096-byte-block layout the FIR
 // kernels stream with 16-byte loads.  A block moves DI_TILE bytes per channel: the source range is
@@ -270,8 +320,8 @@ __global__ void d2d_history_kernel(const StreamJob* jobs, uint32_t C, uint32_t B
 // scratch layout per stream: [P history][nout new]; move the last P to the front (regions may overlap)
 __global__ void d2d_xhist_kernel(const StreamJob* jobs, uint32_t P) {
     const StreamJob job = jobs[blockIdx.x];
-    double* s = job.xs - P;
-    double v = 0.0;
+    int32_t* s = job.xs - P;
+    int32_t v = 0;
     if (threadIdx.x < P) v = s[job.nout + threadIdx.x];
     __syncthreads();
     if (threadIdx.x < P) s[threadIdx.x] = v;
@@ -330,6 +380,8 @@ const char* lut_kernel_name(int MB) {
 
 template <int NT>
 static hipError_t launch_resample_nt(const ResampArgs& a, uint32_t gx, uint32_t nstreams, size_t smem, hipStream_t s) {
+    static const char* env = getenv("D2D_DBG");
+    const uint32_t dbg = env ? (uint32_t)atoi(env) : 0u;   // diagnostic ablation mask, 0 in production
     static bool attr_done = false;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&d2d_resample_kernel<NT>),
@@ -337,16 +389,16 @@ static hipError_t launch_resample_nt(const ResampArgs& a, uint32_t gx, uint32_t 
         if (e != hipSuccess) return e;
         attr_done = true;
     }
-    hipLaunchKernelGGL(d2d_resample_kernel<NT>, dim3(gx, nstreams), dim3(RS_THREADS), smem, s, a);
+    hipLaunchKernelGGL(d2d_resample_kernel<NT>, dim3(gx, nstreams), dim3(RS_THREADS), smem, s, a, dbg);
     return hipGetLastError();
 }
 
 hipError_t launch_resample(const ResampArgs& a, uint32_t max_out, uint32_t nstreams, hipStream_t s) {
     if (nstreams == 0 || max_out == 0) return hipSuccess;
     const uint32_t ntask = a.L / RS_R;
-    if (a.L % RS_R || ntask % RS_WAVES) return hipErrorInvalidValue;
-    const size_t smem = std::max((size_t)(a.Mdn * 64 + a.nsteps) * sizeof(double), (size_t)64 * a.L * 4);
-    if (smem > 80 * 1024 - 256) return hipErrorInvalidValue;
+    if (a.L % RS_R || ntask % RS_WAVES || a.nsteps % 4) return hipErrorInvalidValue;
+    const size_t smem = std::max((size_t)(RS_XPAD + ((a.Mdn * 64 + a.nsteps + 6) & ~3u)) * sizeof(double), (size_t)64 * a.L * 4);
+    if (smem > 80 * 1024 - 256 || a.Mdn * 64 + a.nsteps + 6 > 4 * RS_LD * RS_THREADS) return hipErrorInvalidValue;
     uint32_t gx = max_out / (64 * a.L) + 2;                    // tiles follow absolute cycles: up to one extra
     const uint32_t cap = (4096 + nstreams - 1) / nstreams;
     if (gx > cap) gx = cap;

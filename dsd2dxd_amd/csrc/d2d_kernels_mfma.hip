@@ -321,7 +321,7 @@ __global__ __launch_bounds__(MFMA_MAX_THREADS, 3) void d2d_fir_mfma_kernel(MfmaA
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
                         const uint32_t nl = wt * 256u + (8 * r + 4 * h + k);
-                        if (FULL || nl < j0.nout) as_global(jobs[c].xs)[nl] = xv[k];
+                        if (FULL || nl < j0.nout) as_global(jobs[c].xs)[nl] = (int32_t)xv[k];
                     }
                     return;
                 }
@@ -524,7 +524,7 @@ static void mfma_geometry(const FirArgs& a, const MfmaLayout& g, MfmaArgs& m, si
     const uint32_t C = a.epi.channels;
     const int MB = g.M / 8;
     m.f = a;
-    m.c0 = a.to_scratch ? 1.0 : (a.epi.bits == 32 ? a.epi.gain : a.epi.scale);
+    m.c0 = a.to_scratch ? ldexp(1.0, a.scale_bits) : (a.epi.bits == 32 ? a.epi.gain : a.epi.scale);   // scratch: the integer y*2^S
     m.c1 = ldexp(m.c0, 1 - a.scale_bits - 7);     // exact: a power-of-two multiple of c0
     m.dsel = a.epi.dither == 'T' ? 1u : 0u;
     m.dmul = a.epi.dither == 'T' ? 0x1p-16 : (a.epi.dither == 'R' ? 0x1p-17 : 0.0);
