@@ -2,6 +2,8 @@
 // (/root/reference/src/main.rs:40-133) for the conversion-relevant subset, plus:
 //   probe  <file>...      print what the container readers see, as JSON (no GPU needed)
 //   levels [opts] files   peak dBFS per file and overall (src/bin/dsd_levels/main.rs)
+//   tags [-a RATE] <file>...   the source's ID3v2 tag as the converted file would carry it, as JSON
+//                         (text frames under their Vorbis names; -a applies the album suffix; no GPU needed)
 // It is not the reference's CLI (logging, progress bars, Rayon pool are out of scope).
 #include <stdio.h>
 #include <stdlib.h>
@@ -14,6 +16,7 @@
 
 #include "../../../include/rdsd2pcm.hpp"
 #include "dsd_reader.h"
+#include "id3_tag.h"
 
 using namespace rdsd2pcm;
 static std::atomic<bool> CANCEL_FLAG{false};
@@ -35,8 +38,45 @@ static int probe_main(int argc, char** argv) {
     return 0;
 }
 
+static std::string json_escape(const std::string& s) {
+    std::string o;
+    for (unsigned char c : s) {
+        if (c == '"' || c == '\\') { o += '\\'; o += (char)c; }
+        else if (c < 0x20) { char b[8]; snprintf(b, sizeof(b), "\\u%04x", c); o += b; }
+        else o += (char)c;
+    }
+    return o;
+}
+
+static int tags_main(int argc, char** argv) {
+    uint32_t append_rate = 0;
+    int i = 0;
+    if (argc >= 2 && !strcmp(argv[0], "-a")) { append_rate = (uint32_t)strtoul(argv[1], 0, 10); i = 2; }
+    printf("[");
+    for (bool first = true; i < argc; ++i, first = false) {
+        d2dhost::DsdInfo o;
+        std::string err = d2dhost::probe(argv[i], o), warn;
+        std::vector<uint8_t> tag;
+        if (err.empty()) err = d2dhost::read_source_tag(argv[i], o, tag, warn);
+        bool album_edited = false;
+        if (!tag.empty() && append_rate) album_edited = d2dhost::append_to_album(tag, d2dhost::album_rate_suffix(append_rate));
+        std::vector<std::pair<std::string, std::string>> fields;
+        std::vector<d2dhost::TagPicture> pics;
+        d2dhost::tag_to_vorbis(tag, fields, pics);
+        printf("%s{\"path\": \"%s\", \"error\": \"%s\", \"warning\": \"%s\", \"tag_bytes\": %zu, \"album_edited\": %s, \"pictures\": %zu, \"fields\": {",
+               first ? "" : ", ", json_escape(argv[i]).c_str(), json_escape(err).c_str(), json_escape(warn).c_str(), tag.size(),
+               album_edited ? "true" : "false", pics.size());
+        for (size_t k = 0; k < fields.size(); ++k)
+            printf("%s\"%s\": \"%s\"", k ? ", " : "", json_escape(fields[k].first).c_str(), json_escape(fields[k].second).c_str());
+        printf("}}");
+    }
+    printf("]\n");
+    return 0;
+}
+
 int main(int argc, char** argv) {
     if (argc >= 2 && !strcmp(argv[1], "probe")) return probe_main(argc - 2, argv + 2);
+    if (argc >= 2 && !strcmp(argv[1], "tags")) return tags_main(argc - 2, argv + 2);
     bool levels = false;
     int ai = 1;
     if (argc >= 2 && !strcmp(argv[1], "levels")) { levels = true; ai = 2; }
@@ -108,6 +148,7 @@ int main(int argc, char** argv) {
                                : Rdsd2Pcm::create(bit_depth, ot, level, rate, od, dt, ft, en, inrate, block, channels, fl, append, ".", ip);
             lib.set_device(device); lib.set_seed(seed);
             lib.do_conversion(CANCEL_FLAG);
+            if (!quiet && !lib.warnings().empty()) fprintf(stderr, "WARNING: %s: %s\n", lib.file_name().c_str(), lib.warnings().c_str());
             if (!quiet && lib.audio_seconds() > 0)
                 fprintf(stderr, "DSP speed for %s: %.2fx\n", lib.file_name().c_str(), lib.audio_seconds() / std::max(lib.dsp_seconds(), 1e-9));
         }

@@ -1,5 +1,7 @@
 #include "pcm_sink.h"
 
+#include "id3_tag.h"
+
 #include <math.h>
 #include <string.h>
 
@@ -31,6 +33,7 @@ struct RawSink : PcmSink {
 
 struct WavSink : PcmSink {
     FILE* f; uint32_t ch, rate, bits; uint64_t data = 0; size_t hdr = 0;
+    std::vector<uint8_t> id3;
     std::string begin() {
         const uint32_t cont = bits == 16 ? 16 : (bits == 32 ? 32 : 24);
         const bool ext = bits == 20 || ch > 2;                      // valid-bits / channel mask need EXTENSIBLE
@@ -55,9 +58,16 @@ struct WavSink : PcmSink {
     std::string write(const uint8_t* p, size_t n) override { data += n; return fwrite(p, 1, n, f) == n ? "" : "short write"; }
     std::string close() override {
         if (data & 1) fputc(0, f);
-        if (data + hdr > 0xFFFFFFFFull) { fclose(f); return "WAV output exceeds 4 GiB"; }
+        uint64_t tail = 0;
+        if (!id3.empty()) {                                          // 'id3 ' chunk behind the audio
+            uint8_t c[8]; memcpy(c, "id3 ", 4); put_le32(c + 4, (uint32_t)id3.size());
+            fwrite(c, 1, 8, f); fwrite(id3.data(), 1, id3.size(), f);
+            if (id3.size() & 1) fputc(0, f);
+            tail = 8 + id3.size() + (id3.size() & 1);
+        }
+        if (data + hdr + tail > 0xFFFFFFFFull) { fclose(f); return "WAV output exceeds 4 GiB"; }
         uint8_t v[4];
-        put_le32(v, (uint32_t)(hdr - 8 + data + (data & 1))); fseek(f, 4, SEEK_SET); fwrite(v, 1, 4, f);
+        put_le32(v, (uint32_t)(hdr - 8 + data + (data & 1) + tail)); fseek(f, 4, SEEK_SET); fwrite(v, 1, 4, f);
         put_le32(v, (uint32_t)data); fseek(f, (long)hdr - 4, SEEK_SET); fwrite(v, 1, 4, f);
         return fclose(f) == 0 ? "" : "close failed";
     }
@@ -76,7 +86,7 @@ static void put_ext80(uint8_t* p, double v) {
 
 struct AiffSink : PcmSink {
     FILE* f; uint32_t ch, rate, bits; bool aifc; uint64_t data = 0; size_t comm_frames_at = 0, ssnd_size_at = 0;
-    std::vector<uint8_t> tmp;
+    std::vector<uint8_t> tmp, id3;
     std::string begin() {
         const uint32_t cont = bits == 16 ? 16 : (bits == 32 ? 32 : 24);
         std::vector<uint8_t> h;
@@ -107,6 +117,11 @@ struct AiffSink : PcmSink {
     }
     std::string close() override {
         if (data & 1) fputc(0, f);
+        if (!id3.empty()) {                                          // 'ID3 ' chunk behind the audio
+            uint8_t c[8]; memcpy(c, "ID3 ", 4); put_be32(c + 4, (uint32_t)id3.size());
+            fwrite(c, 1, 8, f); fwrite(id3.data(), 1, id3.size(), f);
+            if (id3.size() & 1) fputc(0, f);
+        }
         const size_t sb = bits == 16 ? 2 : (bits == 32 ? 4 : 3);
         long end = ftell(f);
         if ((uint64_t)end > 0xFFFFFFFFull) { fclose(f); return "AIFF output exceeds 4 GiB"; }
@@ -126,6 +141,7 @@ struct FlacSink : PcmSink {
     std::vector<int32_t> buf;      // interleaved pending samples
     std::vector<uint8_t> out;
     uint32_t min_fs = 0xFFFFFF, max_fs = 0;
+    std::vector<uint8_t> id3;
     uint64_t bitacc = 0; int bitn = 0;
     static uint8_t crc8(const uint8_t* p, size_t n) { uint8_t c = 0; for (size_t i = 0; i < n; ++i) { c ^= p[i]; for (int k = 0; k < 8; ++k) c = (uint8_t)((c & 0x80) ? (c << 1) ^ 0x07 : (c << 1)); } return c; }
     static uint16_t crc16(const uint8_t* p, size_t n) { uint16_t c = 0; for (size_t i = 0; i < n; ++i) { c ^= (uint16_t)(p[i] << 8); for (int k = 0; k < 8; ++k) c = (uint16_t)((c & 0x8000) ? (c << 1) ^ 0x8005 : (c << 1)); } return c; }
@@ -146,9 +162,42 @@ struct FlacSink : PcmSink {
     }
     uint32_t depth() const { return bits == 20 ? 20 : bits; }
     std::string begin() {
+        // metadata: STREAMINFO (filled in at close), then the source's tag as VORBIS_COMMENT and PICTURE
+        // blocks; the last block carries the 0x80 flag
+        std::vector<std::pair<std::string, std::string>> fields;
+        std::vector<TagPicture> pics;
+        tag_to_vorbis(id3, fields, pics);
+        std::vector<std::vector<uint8_t>> blocks;
+        if (!fields.empty()) {
+            std::vector<uint8_t> b;
+            auto le32 = [&](uint32_t v) { uint8_t t[4]; put_le32(t, v); b.insert(b.end(), t, t + 4); };
+            const std::string vendor = "dsd2dxd_amd";
+            le32((uint32_t)vendor.size()); b.insert(b.end(), vendor.begin(), vendor.end());
+            le32((uint32_t)fields.size());
+            for (const auto& kv : fields) {
+                const std::string e = kv.first + "=" + kv.second;
+                le32((uint32_t)e.size()); b.insert(b.end(), e.begin(), e.end());
+            }
+            b.insert(b.begin(), {4, 0, 0, 0});
+            blocks.push_back(std::move(b));
+        }
+        for (const TagPicture& p : pics) {
+            std::vector<uint8_t> b = {6, 0, 0, 0};
+            auto be32v = [&](uint32_t v) { uint8_t t[4]; put_be32(t, v); b.insert(b.end(), t, t + 4); };
+            be32v(p.type);
+            be32v((uint32_t)p.mime.size()); b.insert(b.end(), p.mime.begin(), p.mime.end());
+            be32v((uint32_t)p.description.size()); b.insert(b.end(), p.description.begin(), p.description.end());
+            be32v(0); be32v(0); be32v(0); be32v(0);                   // width, height, depth, colours: not parsed
+            be32v((uint32_t)p.data.size()); b.insert(b.end(), p.data.begin(), p.data.end());
+            if (b.size() - 4 < (1u << 24)) blocks.push_back(std::move(b));
+        }
+        for (auto& b : blocks) { const uint32_t n = (uint32_t)b.size() - 4; b[1] = (uint8_t)(n >> 16); b[2] = (uint8_t)(n >> 8); b[3] = (uint8_t)n; }
+        if (!blocks.empty()) blocks.back()[0] |= 0x80;
         uint8_t h[4 + 4 + 34]; memset(h, 0, sizeof(h));
-        memcpy(h, "fLaC", 4); h[4] = 0x80; h[7] = 34;                 // last metadata block: STREAMINFO
-        return fwrite(h, 1, sizeof(h), f) == sizeof(h) ? "" : "short write";
+        memcpy(h, "fLaC", 4); h[4] = blocks.empty() ? 0x80 : 0x00; h[7] = 34;   // STREAMINFO
+        if (fwrite(h, 1, sizeof(h), f) != sizeof(h)) return "short write";
+        for (const auto& b : blocks) if (fwrite(b.data(), 1, b.size(), f) != b.size()) return "short write";
+        return "";
     }
     void encode_frame(uint32_t n) {
         out.clear(); bitn = 0; bitacc = 0;
@@ -228,7 +277,8 @@ struct FlacSink : PcmSink {
 
 }  // namespace
 
-std::string open_sink(OutputType type, const std::string& path, uint32_t channels, uint32_t rate, uint32_t bit_depth, PcmSink** out) {
+std::string open_sink(OutputType type, const std::string& path, uint32_t channels, uint32_t rate, uint32_t bit_depth, PcmSink** out,
+                      const std::vector<uint8_t>* id3) {
     *out = nullptr;
     if (type == OutputType::Stdout) { *out = new RawSink(stdout); return ""; }
     if (type == OutputType::Flac && bit_depth == 32) return "FLAC cannot hold 32-bit float; choose 16, 20 or 24 bits";
@@ -237,9 +287,9 @@ std::string open_sink(OutputType type, const std::string& path, uint32_t channel
     FILE* f = fopen(path.c_str(), "wb");
     if (!f) return "cannot create " + path;
     std::string err;
-    if (type == OutputType::Wav) { auto* s = new WavSink(); s->f = f; s->ch = channels; s->rate = rate; s->bits = bit_depth; err = s->begin(); *out = s; }
-    else if (type == OutputType::Flac) { auto* s = new FlacSink(); s->f = f; s->ch = channels; s->rate = rate; s->bits = bit_depth; err = s->begin(); *out = s; }
-    else { auto* s = new AiffSink(); s->f = f; s->ch = channels; s->rate = rate; s->bits = bit_depth; s->aifc = type == OutputType::Aifc; err = s->begin(); *out = s; }
+    if (type == OutputType::Wav) { auto* s = new WavSink(); if (id3) s->id3 = *id3; s->f = f; s->ch = channels; s->rate = rate; s->bits = bit_depth; err = s->begin(); *out = s; }
+    else if (type == OutputType::Flac) { auto* s = new FlacSink(); if (id3) s->id3 = *id3; s->f = f; s->ch = channels; s->rate = rate; s->bits = bit_depth; err = s->begin(); *out = s; }
+    else { auto* s = new AiffSink(); if (id3) s->id3 = *id3; s->f = f; s->ch = channels; s->rate = rate; s->bits = bit_depth; s->aifc = type == OutputType::Aifc; err = s->begin(); *out = s; }
     return err;
 }
 

@@ -19,9 +19,11 @@ class PcmSink {
     virtual std::string close() = 0;
 };
 
-// bit_depth 16/20/24 (integer, 20 in a 24-bit container) or 32 (float)
+// bit_depth 16/20/24 (integer, 20 in a 24-bit container) or 32 (float).  `id3` = the source's ID3v2
+// tag to carry over (may be null or empty): WAV 'id3 ' chunk, AIFF/AIFC 'ID3 ' chunk, FLAC
+// VORBIS_COMMENT + PICTURE blocks (id3_tag.h); the raw stdout stream has no place for it.
 std::string open_sink(OutputType type, const std::string& path, uint32_t channels, uint32_t rate, uint32_t bit_depth,
-                      PcmSink** out);
+                      PcmSink** out, const std::vector<uint8_t>* id3 = nullptr);
 const char* output_extension(OutputType t);
 
 }  // namespace d2dhost

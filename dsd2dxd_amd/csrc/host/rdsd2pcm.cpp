@@ -8,6 +8,7 @@
 #include "../../../include/dsd2dxd_amd.h"
 #include "dsd_reader.h"
 #include "pcm_sink.h"
+#include "id3_tag.h"
 
 namespace rdsd2pcm {
 
@@ -42,6 +43,8 @@ struct Rdsd2Pcm::Impl {
     size_t chunk = 4u << 20;
     std::string out_path;
     double dsp_s = 0.0, audio_s = 0.0;
+    std::string tag_warning;
+    int artwork_copied = 0;
 };
 
 static uint32_t dither_code(DitherType d) { return d == DitherType::TPDF ? 'T' : d == DitherType::Rectangular ? 'R' : d == DitherType::FPD ? 'F' : 'X'; }
@@ -134,6 +137,7 @@ std::string Rdsd2Pcm::file_name() const { return p_->in_path ? basename_of(*p_->
 std::string Rdsd2Pcm::output_path() const { return p_->out_path; }
 double Rdsd2Pcm::dsp_seconds() const { return p_->dsp_s; }
 double Rdsd2Pcm::audio_seconds() const { return p_->audio_s; }
+std::string Rdsd2Pcm::warnings() const { return p_->tag_warning; }
 void Rdsd2Pcm::set_device(int device) { p_->prm.device = device; }
 void Rdsd2Pcm::set_seed(uint64_t seed) { p_->prm.seed = seed; }
 void Rdsd2Pcm::set_chunk_bytes(size_t b) { if (b) p_->chunk = b; }
@@ -190,7 +194,18 @@ static float run(Rdsd2Pcm::Impl& im, const std::atomic<bool>& cancel, ProgressSe
             if (im.append_rate) stem += rate_suffix(im.prm.output_rate);
             im.out_path = dir + "/" + stem + "." + output_extension((d2dhost::OutputType)(int)im.output);
         }
-        err = open_sink((d2dhost::OutputType)(int)im.output, im.out_path, im.prm.channels, im.prm.output_rate, im.prm.bit_depth, &sink);
+        // the source's ID3v2 tag travels with the audio (README.md:7); -a also marks the album (README.md:170-173)
+        std::vector<uint8_t> tag;
+        if (im.output != OutputType::Stdout && im.in_path) {
+            std::string twarn;
+            err = d2dhost::read_source_tag(*im.in_path, info, tag, twarn);
+            if (!err.empty()) throw std::runtime_error(err);
+            im.tag_warning = twarn;
+            if (!tag.empty() && im.append_rate) d2dhost::append_to_album(tag, d2dhost::album_rate_suffix(im.prm.output_rate));
+            // -p: artwork next to the sources follows them into the output tree (README.md:115-119)
+            if (im.out_dir) im.artwork_copied = d2dhost::copy_artwork(dirname_of(*im.in_path), dirname_of(im.out_path));
+        }
+        err = open_sink((d2dhost::OutputType)(int)im.output, im.out_path, im.prm.channels, im.prm.output_rate, im.prm.bit_depth, &sink, &tag);
         if (!err.empty()) throw std::runtime_error(err);
     }
     std::unique_ptr<PcmSink> sink_guard(sink);

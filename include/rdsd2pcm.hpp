@@ -61,6 +61,7 @@ class Rdsd2Pcm {
     std::string output_path() const;          // where do_conversion writes ("" for stdout)
     double dsp_seconds() const;               // time inside the engine during the last run (the "DSP speed" figure)
     double audio_seconds() const;
+    std::string warnings() const;             // non-fatal findings of the last run (e.g. a damaged ID3 tag that was not copied)
     // engine knobs a driver may set before the run
     void set_device(int device);
     void set_seed(uint64_t seed);

@@ -43,6 +43,72 @@ def test_probe_synthetic_containers(cli, tmp_path):
     assert "bad 'DSD ' chunk" in probe(cli, bad)[0]["error"]
 
 
+def _syncsafe(n):
+    return bytes([(n >> 21) & 0x7F, (n >> 14) & 0x7F, (n >> 7) & 0x7F, n & 0x7F])
+
+
+def make_id3(ver, frames, padding=0):
+    """frames: [(id, payload bytes)]; v2.3 sizes are plain big-endian, v2.4 sizes are syncsafe"""
+    body = b""
+    for fid, pay in frames:
+        body += fid + (struct.pack(">I", len(pay)) if ver == 3 else _syncsafe(len(pay))) + b"\x00\x00" + pay
+    body += bytes(padding)
+    return b"ID3" + bytes([ver, 0, 0]) + _syncsafe(len(body)) + body
+
+
+def tags(cli, *args):
+    return json.loads(subprocess.check_output([cli, "tags", *args]))
+
+
+PNG = b"\x89PNG\r\n\x1a\n" + bytes(range(64))
+
+
+def test_tags_are_read_decoded_and_album_marked(cli, tmp_path):
+    """README.md:7 (tags are copied where possible) and README.md:170-173 (-a marks the album)"""
+    chans = [random_bytes(4096, 1), random_bytes(4096, 2)]
+    t23 = make_id3(3, [(b"TIT2", b"\x00Caf\xe9 tone"), (b"TALB", b"\x01\xff\xfe" + "Hits ♫".encode("utf-16-le") + b"\x00\x00"),
+                       (b"TRCK", b"\x003/12"), (b"TYER", b"\x002024"), (b"COMM", b"\x00engshort\x00made by a test"),
+                       (b"APIC", b"\x00image/png\x00\x03cover\x00" + PNG)], padding=300)
+    t24 = make_id3(4, [(b"TIT2", b"\x03" + "Sinus ♪".encode()), (b"TPE1", b"\x03someone\x00"), (b"TALB", b"\x03Album\x00"),
+                       (b"TDRC", b"\x032025-01-02")], padding=130)
+    p1, p2, p3 = str(tmp_path / "a.dsf"), str(tmp_path / "b.dff"), str(tmp_path / "c.dsf")
+    write_dsf(p1, chans, id3=t23)
+    write_dff(p2, chans, tail=b"ID3 " + struct.pack(">Q", len(t24)) + t24 + (b"\x00" if len(t24) & 1 else b""))
+    write_dsf(p3, chans)
+    a, b, c = tags(cli, p1, p2, p3)
+    assert a["error"] == "" and a["warning"] == "" and a["pictures"] == 1 and a["tag_bytes"] == len(t23) - 300   # padding dropped
+    assert a["fields"] == {"TITLE": "Café tone", "ALBUM": "Hits ♫", "TRACKNUMBER": "3", "TRACKTOTAL": "12", "DATE": "2024",
+                           "COMMENT": "made by a test"}
+    assert b["fields"] == {"TITLE": "Sinus ♪", "ARTIST": "someone", "ALBUM": "Album", "DATE": "2025-01-02"} and b["tag_bytes"] == len(t24) - 130
+    assert c["tag_bytes"] == 0 and c["fields"] == {} and c["warning"] == ""
+    a, b, c = tags(cli, "-a", "88200", p1, p2, p3)
+    assert a["album_edited"] and a["fields"]["ALBUM"] == "Hits ♫ [88.2K]" and a["fields"]["TITLE"] == "Café tone" and a["pictures"] == 1
+    assert b["album_edited"] and b["fields"]["ALBUM"] == "Album [88.2K]" and b["fields"]["DATE"] == "2025-01-02"
+    assert not c["album_edited"]
+    assert tags(cli, "-a", "96000", p2)[0]["fields"]["ALBUM"] == "Album [96K]"
+    # a tag without an album frame, and one this editor must not rewrite (unsynchronised): copied untouched
+    t_noalb = make_id3(3, [(b"TIT2", b"\x00x")])
+    t_unsync = bytearray(make_id3(3, [(b"TALB", b"\x00y")])); t_unsync[5] = 0x80
+    write_dsf(p1, chans, id3=t_noalb)
+    write_dsf(p3, chans, id3=bytes(t_unsync))
+    a, c = tags(cli, "-a", "88200", p1, p3)
+    assert not a["album_edited"] and a["tag_bytes"] == len(t_noalb) and not c["album_edited"] and c["tag_bytes"] == len(t_unsync)
+    # a tag that claims more than the file holds is dropped with a warning, the audio stays convertible
+    write_dsf(p1, chans, id3=t23[:60])
+    a = tags(cli, p1)[0]
+    assert a["error"] == "" and a["tag_bytes"] == 0 and "damaged" in a["warning"]
+
+
+@pytest.mark.skipif(not os.path.isdir(REF + "/id3_test"), reason="reference fixtures not present")
+def test_tags_of_reference_fixtures(cli):
+    good, bad_dff, bad_dsf = tags(cli, "-a", "176400", REF + "/id3_test/dff/1kHz_stereo_i.dff",
+                                  REF + "/id3_test/dff/1kHz_stereo_i_brokenid3.dff", REF + "/id3_test/1kHz_mono_brokenid3.dsf")
+    assert good["fields"] == {"TITLE": "1kHz Test Tone DSD64", "ARTIST": "clone206",
+                              "ALBUM": "clone206's Greatest Test Tone Hits [176.4K]"} and good["album_edited"]
+    for t in (bad_dff, bad_dsf):
+        assert t["error"] == "" and t["tag_bytes"] == 0 and "damaged" in t["warning"]
+
+
 @pytest.mark.skipif(not os.path.isdir(REF + "/test"), reason="reference fixtures not present")
 def test_probe_reference_fixtures(cli):
     """the facts SURVEY.md 4.3 measured from the fixture files, including the damaged-ID3 ones"""
@@ -104,7 +170,14 @@ def _flac_decode(path):
     si = b[8:42]
     v = int.from_bytes(si[10:18], "big")
     rate, ch, bps, total = v >> 44, ((v >> 41) & 7) + 1, ((v >> 36) & 31) + 1, v & ((1 << 36) - 1)
-    bits = "".join(f"{x:08b}" for x in b[42:])
+    mpos, last = 4, False
+    _flac_decode.blocks = []
+    while not last:                                   # metadata blocks: STREAMINFO first, tags may follow
+        last, btype, blen = bool(b[mpos] & 0x80), b[mpos] & 0x7F, int.from_bytes(b[mpos + 1:mpos + 4], "big")
+        _flac_decode.blocks.append((btype, b[mpos + 4:mpos + 4 + blen]))
+        mpos += 4 + blen
+    assert _flac_decode.blocks[0][0] == 0
+    bits = "".join(f"{x:08b}" for x in b[mpos:])
     pos = 0
 
     def rd(n):
@@ -235,3 +308,72 @@ def test_levels_tool_and_error_exit(cli, oracle_mod, tmp_path):
     assert p.returncode == 1 and b"705600 output needs DSD128 or DSD256 input" in p.stderr
     p = subprocess.run([cli, "-d", "N", pa], stderr=subprocess.PIPE)
     assert p.returncode == 1 and b"Invalid dither type; must be T, R, F, or X" in p.stderr
+
+
+def _chunks(path, big_endian):
+    b = open(path, "rb").read()
+    pos, out = 12, {}
+    while pos + 8 <= len(b):
+        cid, sz = b[pos:pos + 4], struct.unpack(">I" if big_endian else "<I", b[pos + 4:pos + 8])[0]
+        out[cid] = b[pos + 8:pos + 8 + sz]
+        pos += 8 + sz + (sz & 1)
+    assert pos == len(b) and struct.unpack(">I" if big_endian else "<I", b[4:8])[0] == len(b) - 8
+    return out
+
+
+@pytest.mark.gpu
+def test_tags_and_artwork_travel_with_the_audio(cli, oracle_mod, tmp_path):
+    """README.md:7 (ID3v2 copied to the destination), :115-119 (-p copies artwork), :170-173 (-a marks the album)"""
+    n = 4096 * 4
+    chans = [synth("sine", n, seed=21), synth("pink", n, seed=22, amp=0.098)]
+    tag = make_id3(3, [(b"TIT2", b"\x00tone"), (b"TPE1", b"\x00me"), (b"TALB", b"\x00Hits"), (b"TRCK", b"\x002"),
+                       (b"APIC", b"\x00image/png\x00\x03\x00" + PNG)], padding=50)
+    src_dir = tmp_path / "in" / "album"
+    src_dir.mkdir(parents=True)
+    src = str(src_dir / "t.dsf")
+    write_dsf(src, chans, id3=tag)
+    (src_dir / "folder.JPG").write_bytes(b"\xff\xd8 not really a jpeg")
+    (src_dir / "notes.txt").write_bytes(b"not artwork")
+    out_dir = tmp_path / "out"
+    out_dir.mkdir()
+    o = oracle_mod.Oracle(dsd_rate=1, output_rate=88200, channels=2, fmt="P", endianness="L", block_size=4096,
+                          bit_depth=24, dither="T", seed=0)
+    r, rf = o.translate(pack_layout(chans, "P", 4096))
+    plain = tag[:-50]
+    plain = plain[:6] + _syncsafe(len(plain) - 10) + plain[10:]
+    marked = make_id3(3, [(b"TIT2", b"\x00tone"), (b"TPE1", b"\x00me"), (b"TALB", b"\x00Hits [88.2K]"), (b"TRCK", b"\x002"),
+                          (b"APIC", b"\x00image/png\x00\x03\x00" + PNG)])
+    # WAV with -a and -p: tag chunk with the marked album, artwork copied, audio untouched
+    subprocess.check_call([cli, "-o", "w", "-r", "88200", "-b", "24", "-d", "T", "-a", "-p", str(out_dir), "-q", src])
+    wav = str(out_dir / "t_88_2K.wav")
+    ck = _chunks(wav, False)
+    assert ck[b"id3 "] == marked and np.array_equal(np.frombuffer(ck[b"data"], dtype=np.uint8), r[:rf * 6])
+    assert (out_dir / "folder.JPG").read_bytes() == b"\xff\xd8 not really a jpeg" and not (out_dir / "notes.txt").exists()
+    # AIFF without -a: the tag as it was (padding dropped)
+    subprocess.check_call([cli, "-o", "a", "-r", "88200", "-b", "24", "-d", "T", "-q", src])
+    ck = _chunks(str(src_dir / "t.aif"), True)
+    assert ck[b"ID3 "] == plain
+    assert np.array_equal(np.frombuffer(ck[b"SSND"][8:], dtype=np.uint8).reshape(-1, 3)[:, ::-1].reshape(-1), r[:rf * 6])
+    # FLAC: Vorbis comments + picture, and the audio frames still decode to the same samples
+    subprocess.check_call([cli, "-o", "f", "-r", "88200", "-b", "24", "-d", "T", "-a", "-q", src])
+    rate, ch, bps, pcm = _flac_decode(str(src_dir / "t_88_2K.flac"))
+    assert np.array_equal(pcm, decode_pcm(r[:rf * 6], 24, 2))
+    blocks = dict(_flac_decode.blocks)
+    vc = blocks[4]
+    vlen = struct.unpack("<I", vc[:4])[0]
+    cnt = struct.unpack("<I", vc[4 + vlen:8 + vlen])[0]
+    pos, got = 8 + vlen, []
+    for _ in range(cnt):
+        ln = struct.unpack("<I", vc[pos:pos + 4])[0]
+        got.append(vc[pos + 4:pos + 4 + ln].decode())
+        pos += 4 + ln
+    assert got == ["TITLE=tone", "ARTIST=me", "ALBUM=Hits [88.2K]", "TRACKNUMBER=2"] and pos == len(vc)
+    pic = blocks[6]
+    assert pic[:4] == struct.pack(">I", 3) and pic[8:17] == b"image/png" and pic.endswith(PNG)
+    # a damaged tag: warning on stderr, conversion succeeds, no tag chunk
+    bad = str(src_dir / "bad.dsf")
+    write_dsf(bad, chans, id3=tag[:40])
+    p = subprocess.run([cli, "-o", "w", "-r", "88200", "-b", "24", "-d", "T", bad], stderr=subprocess.PIPE, check=True)
+    assert b"damaged" in p.stderr
+    ck = _chunks(str(src_dir / "bad.wav"), False)
+    assert b"id3 " not in ck and np.array_equal(np.frombuffer(ck[b"data"], dtype=np.uint8), r[:rf * 6])
