@@ -3,6 +3,8 @@
 #include "id3_tag.h"
 
 #include <math.h>
+
+#include <algorithm>
 #include <string.h>
 
 namespace d2dhost {
@@ -133,6 +135,54 @@ struct AiffSink : PcmSink {
     }
 };
 
+// MD5 (RFC 1321) of the unencoded audio for STREAMINFO
+struct Md5 {
+    uint32_t a = 0x67452301, b = 0xefcdab89, c = 0x98badcfe, d = 0x10325476;
+    uint64_t len = 0; uint8_t buf[64]; size_t fill = 0;
+    static uint32_t rol(uint32_t x, int s) { return (x << s) | (x >> (32 - s)); }
+    void block(const uint8_t* p) {
+        static const uint32_t K[64] = {
+            0xd76aa478, 0xe8c7b756, 0x242070db, 0xc1bdceee, 0xf57c0faf, 0x4787c62a, 0xa8304613, 0xfd469501, 0x698098d8, 0x8b44f7af, 0xffff5bb1,
+            0x895cd7be, 0x6b901122, 0xfd987193, 0xa679438e, 0x49b40821, 0xf61e2562, 0xc040b340, 0x265e5a51, 0xe9b6c7aa, 0xd62f105d, 0x02441453,
+            0xd8a1e681, 0xe7d3fbc8, 0x21e1cde6, 0xc33707d6, 0xf4d50d87, 0x455a14ed, 0xa9e3e905, 0xfcefa3f8, 0x676f02d9, 0x8d2a4c8a, 0xfffa3942,
+            0x8771f681, 0x6d9d6122, 0xfde5380c, 0xa4beea44, 0x4bdecfa9, 0xf6bb4b60, 0xbebfbc70, 0x289b7ec6, 0xeaa127fa, 0xd4ef3085, 0x04881d05,
+            0xd9d4d039, 0xe6db99e5, 0x1fa27cf8, 0xc4ac5665, 0xf4292244, 0x432aff97, 0xab9423a7, 0xfc93a039, 0x655b59c3, 0x8f0ccc92, 0xffeff47d,
+            0x85845dd1, 0x6fa87e4f, 0xfe2ce6e0, 0xa3014314, 0x4e0811a1, 0xf7537e82, 0xbd3af235, 0x2ad7d2bb, 0xeb86d391};
+        static const int S[64] = {7, 12, 17, 22, 7, 12, 17, 22, 7, 12, 17, 22, 7, 12, 17, 22, 5, 9, 14, 20, 5, 9, 14, 20, 5, 9, 14, 20, 5, 9, 14, 20,
+                                  4, 11, 16, 23, 4, 11, 16, 23, 4, 11, 16, 23, 4, 11, 16, 23, 6, 10, 15, 21, 6, 10, 15, 21, 6, 10, 15, 21, 6, 10, 15, 21};
+        uint32_t m[16];
+        for (int i = 0; i < 16; ++i) m[i] = p[4 * i] | (p[4 * i + 1] << 8) | (p[4 * i + 2] << 16) | ((uint32_t)p[4 * i + 3] << 24);
+        uint32_t A = a, B = b, C = c, D = d;
+        for (int i = 0; i < 64; ++i) {
+            uint32_t f; int g;
+            if (i < 16) { f = (B & C) | (~B & D); g = i; }
+            else if (i < 32) { f = (D & B) | (~D & C); g = (5 * i + 1) & 15; }
+            else if (i < 48) { f = B ^ C ^ D; g = (3 * i + 5) & 15; }
+            else { f = C ^ (B | ~D); g = (7 * i) & 15; }
+            const uint32_t t = D; D = C; C = B; B = B + rol(A + f + K[i] + m[g], S[i]); A = t;
+        }
+        a += A; b += B; c += C; d += D;
+    }
+    void update(const uint8_t* p, size_t n) {
+        len += n;
+        while (n) {
+            const size_t take = std::min(n, 64 - fill);
+            memcpy(buf + fill, p, take); fill += take; p += take; n -= take;
+            if (fill == 64) { block(buf); fill = 0; }
+        }
+    }
+    void finish(uint8_t out[16]) {
+        const uint64_t bits = len * 8;
+        const uint8_t one = 0x80, zero = 0;
+        update(&one, 1);
+        while (fill != 56) update(&zero, 1);
+        uint8_t l[8]; for (int i = 0; i < 8; ++i) l[i] = (uint8_t)(bits >> (8 * i));
+        update(l, 8);
+        const uint32_t v[4] = {a, b, c, d};
+        for (int i = 0; i < 4; ++i) for (int k = 0; k < 4; ++k) out[4 * i + k] = (uint8_t)(v[i] >> (8 * k));
+    }
+};
+
 // FLAC with fixed-order-2 prediction and one Rice partition per subframe (valid, modest compression;
 // the reference uses the flac-codec crate, Cargo.lock:299-307).  Integer depths only.
 struct FlacSink : PcmSink {
@@ -142,6 +192,7 @@ struct FlacSink : PcmSink {
     std::vector<uint8_t> out;
     uint32_t min_fs = 0xFFFFFF, max_fs = 0;
     std::vector<uint8_t> id3;
+    Md5 md5;                       // of the samples as little-endian whole-byte integers, interleaved (FLAC format, STREAMINFO)
     uint64_t bitacc = 0; int bitn = 0;
     static uint8_t crc8(const uint8_t* p, size_t n) { uint8_t c = 0; for (size_t i = 0; i < n; ++i) { c ^= p[i]; for (int k = 0; k < 8; ++k) c = (uint8_t)((c & 0x80) ? (c << 1) ^ 0x07 : (c << 1)); } return c; }
     static uint16_t crc16(const uint8_t* p, size_t n) { uint16_t c = 0; for (size_t i = 0; i < n; ++i) { c ^= (uint16_t)(p[i] << 8); for (int k = 0; k < 8; ++k) c = (uint16_t)((c & 0x8000) ? (c << 1) ^ 0x8005 : (c << 1)); } return c; }
@@ -255,6 +306,8 @@ struct FlacSink : PcmSink {
         for (size_t i = 0; i + sb <= nbytes; i += sb) {
             int32_t v = sb == 2 ? (int16_t)(p[i] | (p[i + 1] << 8)) : (int32_t)((p[i] | (p[i + 1] << 8) | (p[i + 2] << 16)) << 8) >> 8;
             if (bits == 20) v >>= 4;
+            const uint8_t le[3] = {(uint8_t)v, (uint8_t)(v >> 8), (uint8_t)(v >> 16)};
+            md5.update(le, sb);
             buf.push_back(v);
         }
         while (buf.size() >= (size_t)BS * ch) {
@@ -269,7 +322,8 @@ struct FlacSink : PcmSink {
         put_be16(si, BS); put_be16(si + 2, BS);
         si[4] = min_fs >> 16; si[5] = min_fs >> 8; si[6] = (uint8_t)min_fs; si[7] = max_fs >> 16; si[8] = max_fs >> 8; si[9] = (uint8_t)max_fs;
         const uint64_t v = ((uint64_t)rate << 44) | ((uint64_t)(ch - 1) << 41) | ((uint64_t)(depth() - 1) << 36) | (frames & 0xFFFFFFFFFull);
-        for (int i = 0; i < 8; ++i) si[10 + i] = (uint8_t)(v >> (56 - 8 * i));   // MD5 left zero = "not computed"
+        for (int i = 0; i < 8; ++i) si[10 + i] = (uint8_t)(v >> (56 - 8 * i));
+        md5.finish(si + 18);
         fseek(f, 8, SEEK_SET); fwrite(si, 1, 34, f);
         return fclose(f) == 0 ? "" : "close failed";
     }

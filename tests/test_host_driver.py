@@ -1,6 +1,7 @@
 """The host side above the C ABI: container readers, PCM sinks, the Rdsd2Pcm mirror and
 its small CLI (dsd2dxd_amd/dsd2dxd_amd_cli).  CPU tests cover what needs no GPU (the readers, found
 through `probe`); GPU tests convert whole files and compare the written audio with the oracle."""
+import hashlib
 import json
 import os
 import struct
@@ -277,6 +278,7 @@ def test_flac_and_wav20_sinks(cli, oracle_mod, tmp_path):
     r, rf = o.translate(pack_layout(chans, "P", 4096))
     assert (rate, ch, bps, len(pcm)) == (88200, 2, 24, rf)
     assert np.array_equal(pcm, decode_pcm(r[:rf * 6], 24, 2))
+    assert open(str(tmp_path / "y.flac"), "rb").read()[26:42] == hashlib.md5(r[:rf * 6].tobytes()).digest()   # STREAMINFO MD5
     assert os.path.getsize(str(tmp_path / "y.flac")) < rf * 6           # the fixed predictor + Rice coding do compress
     subprocess.check_call([cli, "-o", "w", "-r", "88200", "-b", "20", "-d", "X", "-q", src])
     fmt, pay = _wav_payload(str(tmp_path / "y.wav"))
