@@ -38,7 +38,7 @@ typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v16i __attribute__((ext_vector_type(16)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 
-constexpr int MFMA_MAX_THREADS = 512;
+constexpr int MFMA_MAX_THREADS = 768;   // 12 waves = 3 per SIMD, what 168 VGPRs allow
 constexpr int MFMA_PF = 3;   // 16-byte chunks per lane fetched one wave-tile ahead
 
 // diagnostic build only (D2D_DBG bit 4): wave-cycles per phase, summed over all waves
@@ -551,9 +551,11 @@ static void mfma_geometry(const FirArgs& a, const MfmaLayout& g, MfmaArgs& m, si
     { static const char* e = getenv("D2D_DBG"); m.dbg = e ? (uint32_t)atoi(e) : 0u; }
     { static const char* e = getenv("D2D_STAGGER"); m.stagger = e ? (uint32_t)atoi(e) : 0u; }
     static const char* wenv = getenv("D2D_MFMA_WAVES");   // diagnostic override
-    m.nwaves = wenv ? (uint32_t)atoi(wenv) : 8u;
-    if (m.nwaves < 1 || m.nwaves > 8) m.nwaves = 8;
-    while (m.nwaves > 1 && (size_t)m.off_waves + (size_t)m.nwaves * m.wave_lds > 160 * 1024) m.nwaves >>= 1;
+    m.nwaves = wenv ? (uint32_t)atoi(wenv) : 12u;
+    if (m.nwaves < 1 || m.nwaves > 12) m.nwaves = 12;
+    // largest block that fits the CU's LDS, keeping the waves evenly spread over the four SIMDs
+    while (m.nwaves > 1 && (size_t)m.off_waves + (size_t)m.nwaves * m.wave_lds > 160 * 1024)
+        m.nwaves = m.nwaves > 8 ? 8 : m.nwaves > 4 ? 4 : m.nwaves >> 1;
     smem = (size_t)m.off_waves + (size_t)m.nwaves * m.wave_lds;
 }
 
