@@ -67,6 +67,11 @@ struct ResampArgs {
     uint32_t L, Mdn, P;
     uint32_t nsteps;           // P + widest spread of window starts inside a task
     Epilogue epi;
+    // integer-depth epilogue as data (filled by launch_resample): d = fma(term, dmul, dadd), clamp, shift
+    double   dmul, dadd;
+    uint32_t dsel;             // 1: triangular term, 0: rectangular term (dmul = 0: no dither)
+    uint32_t qsh;              // 4 for 20-bit samples in a 24-bit container, else 0
+    int32_t  qmin_i, qmax_i;
 };
 
 // blob header for d2d_tables_export/import

@@ -122,11 +122,21 @@ typedef const __attribute__((address_space(4))) rs_d8* rs_const8;
 constexpr int RS_XPAD = 4;                           // doubles in front of the x tile (look-ahead reads)
 
 // rng32() for an output `o` of this call (index m0 + o; lo32 arithmetic wraps like the counter does)
-__device__ __forceinline__ uint32_t quantise_bits(const Epilogue& ep, const StreamJob& job, double y, uint32_t o, double& pk) {
-    const uint32_t rnd = rng32(job, (uint64_t)(job.rng_lo0 + o));
-    pk = fmax(pk, fabs(y * ep.gain));
-    if (ep.bits == 32) return __float_as_uint(quantise_f32(ep, y, rnd));
-    return (uint32_t)quantise_int(ep, y, rnd);
+// Integer depths track the peak in the scaled domain (|y*scale|, scale = gain*2^(bits-1): an exact
+// power-of-two multiple of |y*gain|, undone once at the end) and run the branch-free form of
+// quantise_int() that the MFMA kernel uses; float output takes quantise_f32().
+__device__ __forceinline__ uint32_t quantise_bits(const ResampArgs& a, const StreamJob& job, double y, uint32_t o, double& pk) {
+    const uint32_t z = rng32(job, (uint64_t)(job.rng_lo0 + o));
+    if (a.epi.bits == 32) {
+        pk = fmax(pk, fabs(y * a.epi.gain));
+        return __float_as_uint(quantise_f32(a.epi, y, z));
+    }
+    const double x = y * a.epi.scale;
+    asm("v_max_f64 %0, %1, |%2|" : "=v"(pk) : "v"(pk), "v"(x));      // plain max with the |.| source modifier
+    const uint32_t term = a.dsel ? (z & 0xFFFFu) + (z >> 16) + 1u : 2u * (z >> 16) + 1u;
+    const double q = x + fma((double)term, a.dmul, a.dadd);
+    const int32_t ri = (int32_t)trunc(q + copysign(0.5, q));
+    return (uint32_t)(min(max(ri, a.qmin_i), a.qmax_i) << a.qsh);
 }
 
 // One trip = four steps of the four fma chains.  The coefficients (two scalar 64-byte loads) and the
@@ -151,7 +161,7 @@ template <int NT>
 __global__ __launch_bounds__(RS_THREADS, 6) void d2d_resample_kernel(ResampArgs a, uint32_t dbg) {
     extern __shared__ __align__(16) unsigned char smem[];
     double* xt = reinterpret_cast<double*>(smem);              // [RS_XPAD + Mdn*64 + nsteps], later the output tile
-    uint32_t* ot = reinterpret_cast<uint32_t*>(smem);          // [64][L]
+    uint32_t* ot = reinterpret_cast<uint32_t*>(smem);          // [64][L + 1]: the odd row stride keeps the lanes' writes on distinct banks
     __shared__ double red[RS_WAVES];
     const StreamJob& job = a.jobs[blockIdx.y];
     const uint32_t tid = threadIdx.x, lane = tid & 63;
@@ -166,6 +176,7 @@ __global__ __launch_bounds__(RS_THREADS, 6) void d2d_resample_kernel(ResampArgs 
     const int32_t o_c0 = (int32_t)((int64_t)(c_first * L) - (int64_t)m0);        // in (-L, 0]
     const int32_t jlo = -(int32_t)a.P, jhi = (int32_t)job.nout - 1;
     const D2D_GLOBAL int32_t* xs = as_global(job.xs);
+    const uint32_t inv_L = (uint32_t)(((1ull << 32) + L - 1) / L);   // i / L == umulhi(i, inv_L) for i < 64 * L
     const uint32_t nxa = (Mdn * 64 + nsteps + 3 + 3) & ~3u;     // tile samples incl. up to 3 of alignment slack
     double pk = 0.0;
     // The tile's stage-A integers start at rel0 (relative to job.n0); they are fetched from rel0a =
@@ -234,14 +245,14 @@ __global__ __launch_bounds__(RS_THREADS, 6) void d2d_resample_kernel(ResampArgs 
 #pragma unroll
             for (int j = 0; j < RS_R; ++j) {
                 const int32_t o = o_lane + (int32_t)(RS_R * task + j);
-                bits[tix][j] = ((uint32_t)o < nres && !(dbg & 1024)) ? quantise_bits(a.epi, job, acc[j], (uint32_t)o, pk) : 0u;
+                bits[tix][j] = ((uint32_t)o < nres && !(dbg & 1024)) ? quantise_bits(a, job, acc[j], (uint32_t)o, pk) : 0u;
             }
         }
         __syncthreads();                                       // all x reads done: reuse the tile for output
 #pragma unroll
         for (int tix = 0; tix < NT; ++tix)
 #pragma unroll
-            for (int j = 0; j < RS_R; ++j) ot[lane * L + RS_R * (wave + RS_WAVES * tix) + j] = bits[tix][j];
+            for (int j = 0; j < RS_R; ++j) ot[lane * (L + 1) + RS_R * (wave + RS_WAVES * tix) + j] = bits[tix][j];
         __syncthreads();
         const uint32_t sample_bytes = a.epi.sample_bytes;
         const uint32_t frame_bytes = sample_bytes * a.epi.channels;
@@ -250,13 +261,14 @@ __global__ __launch_bounds__(RS_THREADS, 6) void d2d_resample_kernel(ResampArgs 
         for (uint32_t i = tid; i < 64 * L; i += RS_THREADS) {
             const int32_t o = o_tile + (int32_t)i;
             if ((uint32_t)o >= nres || (dbg & 2048)) continue;
-            const uint32_t w = ot[i];
+            const uint32_t w = ot[i + __umulhi(i, inv_L)];      // row i / L, one pad word per row
             uint8_t* dst = pcm + (size_t)(uint32_t)o * frame_bytes;
             if (sample_bytes == 4) *reinterpret_cast<uint32_t*>(dst) = w;
             else if (sample_bytes == 2) *reinterpret_cast<uint16_t*>(dst) = (uint16_t)w;
             else { dst[0] = (uint8_t)w; dst[1] = (uint8_t)(w >> 8); dst[2] = (uint8_t)(w >> 16); }
         }
     }
+    if (a.epi.bits != 32) pk *= 1.0 / (double)(1u << (a.epi.bits - 1));   // exact: back to |y*gain|
     block_peak_max(pk, job.peak, red);
 }
 #undef RS_TRIP
@@ -393,11 +405,18 @@ static hipError_t launch_resample_nt(const ResampArgs& a, uint32_t gx, uint32_t 
     return hipGetLastError();
 }
 
-hipError_t launch_resample(const ResampArgs& a, uint32_t max_out, uint32_t nstreams, hipStream_t s) {
+hipError_t launch_resample(const ResampArgs& a_in, uint32_t max_out, uint32_t nstreams, hipStream_t s) {
     if (nstreams == 0 || max_out == 0) return hipSuccess;
+    ResampArgs a = a_in;
+    a.dsel = a.epi.dither == 'T' ? 1u : 0u;
+    a.dmul = a.epi.dither == 'T' ? 0x1p-16 : (a.epi.dither == 'R' ? 0x1p-17 : 0.0);
+    a.dadd = a.epi.dither == 'T' ? -1.0 : (a.epi.dither == 'R' ? -0.5 : 0.0);
+    a.qsh = a.epi.bits == 20 ? 4u : 0u;
+    a.qmin_i = a.epi.bits == 32 ? 0 : -(1 << (a.epi.bits - 1));
+    a.qmax_i = a.epi.bits == 32 ? 0 : (1 << (a.epi.bits - 1)) - 1;
     const uint32_t ntask = a.L / RS_R;
     if (a.L % RS_R || ntask % RS_WAVES || a.nsteps % 4) return hipErrorInvalidValue;
-    const size_t smem = std::max((size_t)(RS_XPAD + ((a.Mdn * 64 + a.nsteps + 6) & ~3u)) * sizeof(double), (size_t)64 * a.L * 4);
+    const size_t smem = std::max((size_t)(RS_XPAD + ((a.Mdn * 64 + a.nsteps + 6) & ~3u)) * sizeof(double), (size_t)64 * (a.L + 1) * 4);
     if (smem > 80 * 1024 - 256 || a.Mdn * 64 + a.nsteps + 6 > 4 * RS_LD * RS_THREADS) return hipErrorInvalidValue;
     uint32_t gx = max_out / (64 * a.L) + 2;                    // tiles follow absolute cycles: up to one extra
     const uint32_t cap = (4096 + nstreams - 1) / nstreams;

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Condense a tools/prof.sh output directory: kernel stats + per-dispatch PMC means for the FIR kernel."""
+"""Condense a tools/prof.sh output directory: kernel stats + per-dispatch PMC means for the engine's kernels."""
 import csv
 import glob
 import os
@@ -21,7 +21,7 @@ for i in (1, 2, 3, 4):
                 acc[row["Kernel_Name"]][row["Counter_Name"]].append(float(row["Counter_Value"]))
         print("== PMC pass", i)
         for k, cs in acc.items():
-            if "d2d_fir" not in k:
+            if "d2d_fir" not in k and "d2d_resample" not in k and "d2d_deinterleave" not in k:
                 continue
             for c, v in sorted(cs.items()):
                 print("  %-50s %-28s n=%4d mean=%.6g" % (k[:50], c, len(v), sum(v) / len(v)))
