@@ -350,13 +350,9 @@ size_t lut_smem_bytes(const FirArgs& a, int MB) {
 template <int MB>
 static hipError_t launch_lut_t(const FirArgs& a, dim3 grid, hipStream_t s) {
     const size_t smem = lut_smem_bytes(a, MB);
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&d2d_fir_lut_kernel<MB>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return e;
-        attr_done = true;
-    }
+    static KernelPrep prep;
+    hipError_t e = prep.max_dynamic_lds(reinterpret_cast<const void*>(&d2d_fir_lut_kernel<MB>), 160 * 1024);
+    if (e != hipSuccess) return e;
     hipLaunchKernelGGL(d2d_fir_lut_kernel<MB>, grid, dim3(LUT_THREADS), smem, s, a);
     return hipGetLastError();
 }
@@ -394,13 +390,9 @@ template <int NT>
 static hipError_t launch_resample_nt(const ResampArgs& a, uint32_t gx, uint32_t nstreams, size_t smem, hipStream_t s) {
     static const char* env = getenv("D2D_DBG");
     const uint32_t dbg = env ? (uint32_t)atoi(env) : 0u;   // diagnostic ablation mask, 0 in production
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&d2d_resample_kernel<NT>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024 - 256);
-        if (e != hipSuccess) return e;
-        attr_done = true;
-    }
+    static KernelPrep prep;
+    hipError_t e = prep.max_dynamic_lds(reinterpret_cast<const void*>(&d2d_resample_kernel<NT>), 80 * 1024 - 256);
+    if (e != hipSuccess) return e;
     hipLaunchKernelGGL(d2d_resample_kernel<NT>, dim3(gx, nstreams), dim3(RS_THREADS), smem, s, a, dbg);
     return hipGetLastError();
 }

@@ -30,6 +30,7 @@
 #include <type_traits>
 
 #include "d2d_device.h"
+#include "d2d_launch.h"
 #include "d2d_mfma.h"
 
 namespace d2d {
@@ -570,23 +571,24 @@ size_t mfma_smem_bytes(const MfmaLayout& g, uint32_t channels, uint32_t sample_b
 
 template <int MB>
 static hipError_t launch_mfma_t(const MfmaArgs& m, size_t smem, uint32_t nwt_max, uint32_t nfiles, hipStream_t s) {
-    static int blocks_per_cu = 0, ncu = 0;
-    static size_t smem_seen = 0;
-    static uint32_t nwaves_seen = 0;
-    if (blocks_per_cu == 0 || smem != smem_seen || m.nwaves != nwaves_seen) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&d2d_fir_mfma_kernel<MB>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return e;
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if ((e = hipGetDevice(&dev)) != hipSuccess) return e;
-        if ((e = hipGetDeviceProperties(&prop, dev)) != hipSuccess) return e;
-        ncu = prop.multiProcessorCount;
-        int nb = 0;
-        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, d2d_fir_mfma_kernel<MB>, (int)(64 * m.nwaves), smem);
-        if (e != hipSuccess) return e;
-        blocks_per_cu = nb < 1 ? 1 : nb;
-        smem_seen = smem; nwaves_seen = m.nwaves;
+    static KernelPrep prep;
+    int dev = 0;
+    hipError_t e = prep.max_dynamic_lds(reinterpret_cast<const void*>(&d2d_fir_mfma_kernel<MB>), 160 * 1024, &dev);
+    if (e != hipSuccess) return e;
+    int blocks_per_cu, ncu;
+    {
+        std::lock_guard<std::mutex> g(prep.mu);
+        if (prep.blocks_per_cu[dev] == 0 || smem != prep.smem_seen[dev] || m.nwaves != prep.nwaves_seen[dev]) {
+            hipDeviceProp_t prop;
+            if ((e = hipGetDeviceProperties(&prop, dev)) != hipSuccess) return e;
+            int nb = 0;
+            e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, d2d_fir_mfma_kernel<MB>, (int)(64 * m.nwaves), smem);
+            if (e != hipSuccess) return e;
+            prep.ncu[dev] = prop.multiProcessorCount;
+            prep.blocks_per_cu[dev] = nb < 1 ? 1 : nb;
+            prep.smem_seen[dev] = smem; prep.nwaves_seen[dev] = m.nwaves;
+        }
+        blocks_per_cu = prep.blocks_per_cu[dev]; ncu = prep.ncu[dev];
     }
     // every wave loops over its share of the wave-tiles: launch what is resident at once
     uint32_t gx = (uint32_t)(ncu * blocks_per_cu) / nfiles;

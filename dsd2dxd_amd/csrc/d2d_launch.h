@@ -2,9 +2,37 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <mutex>
+
 #include "d2d_internal.h"
 
 namespace d2d {
+
+// Per-kernel launch preparation.  hipFuncSetAttribute acts on the CURRENT device and engines of one
+// process may sit on different GPUs and be driven from different threads (one Rdsd2Pcm per Rayon
+// worker, src/main.rs:361-394), so the "already done" state is kept per device under a lock.
+struct KernelPrep {
+    static constexpr int MAX_DEV = 64;
+    std::mutex mu;
+    bool attr_done[MAX_DEV] = {};
+    // occupancy cache of the persistent MFMA launch
+    int blocks_per_cu[MAX_DEV] = {}, ncu[MAX_DEV] = {};
+    size_t smem_seen[MAX_DEV] = {};
+    uint32_t nwaves_seen[MAX_DEV] = {};
+
+    hipError_t max_dynamic_lds(const void* fn, int bytes, int* dev_out = nullptr) {
+        int dev = 0;
+        hipError_t e = hipGetDevice(&dev);
+        if (e != hipSuccess) return e;
+        if (dev < 0 || dev >= MAX_DEV) return hipErrorInvalidDevice;
+        if (dev_out) *dev_out = dev;
+        std::lock_guard<std::mutex> g(mu);
+        if (attr_done[dev]) return hipSuccess;
+        e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        if (e == hipSuccess) attr_done[dev] = true;
+        return e;
+    }
+};
 
 size_t lut_smem_bytes(const FirArgs& a, int MB);
 uint32_t lut_outputs_per_tile(int MB);

@@ -120,3 +120,44 @@ def test_runtime_errors(engine_lib):
     e.reset()
     g2, _ = e.translate(buf)
     assert np.array_equal(g1, g2)
+
+
+def test_engines_on_concurrent_threads(engine_lib, oracle_mod):
+    """one engine per worker thread, created, used and dropped there (src/main.rs:361-394,429): different
+    configurations at the same time must not disturb each other (launch preparation is shared state)"""
+    import threading
+    configs = [dict(KW, output_rate=88200, kernel=2), dict(KW, output_rate=96000, kernel=2), dict(KW, output_rate=176400, kernel=1),
+               dict(KW, output_rate=88200, channels=1, kernel=2), dict(KW, output_rate=192000, kernel=2), dict(KW, output_rate=352800, bit_depth=32, dither="F", kernel=2)]
+    n = 4096 * 6
+    data, want = [], []
+    for i, kw in enumerate(configs):
+        chans = [synth("sine", n, seed=40 + i), synth("pink", n, seed=50 + i, amp=0.098)][:kw["channels"]]
+        buf = pack_layout(chans, "P", 4096)
+        data.append(buf)
+        okw = {k: v for k, v in kw.items() if k != "kernel"}
+        want.append(oracle_mod.Oracle(**okw).translate(buf))
+    got, errs = [None] * len(configs), []
+
+    def work(i):
+        try:
+            for _ in range(3):                                   # fresh engine each time: creation races too
+                e = engine_lib.Engine(n_files=1, **configs[i])
+                pieces, total = [], 0
+                for part in np.array_split(data[i].reshape(-1, 4096 * configs[i]["channels"]), 3):   # whole block groups per call
+                    out, fr = e.translate(part.reshape(-1))
+                    pieces.append(out.copy()); total += fr
+                got[i] = (np.concatenate(pieces), total)
+                del e
+        except Exception as ex:                                  # noqa: BLE001
+            errs.append((i, repr(ex)))
+
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(len(configs))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errs, errs
+    for i in range(len(configs)):
+        r, rf = want[i]
+        fb = {16: 2, 32: 4}.get(configs[i]["bit_depth"], 3) * configs[i]["channels"]
+        assert got[i][1] == rf and np.array_equal(got[i][0], r[:rf * fb]), i
