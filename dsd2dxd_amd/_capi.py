@@ -46,6 +46,7 @@ PROGRESS_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_float)
 
 EXPORTS = ["d2d_create", "d2d_create_error", "d2d_destroy", "d2d_reset", "d2d_last_error",
            "d2d_frame_bytes", "d2d_next_frames", "d2d_translate", "d2d_translate_batch_device",
+           "d2d_translate_batch_host",
            "d2d_peak", "d2d_peak_dbfs", "d2d_convert_stream", "d2d_tables_bytes",
            "d2d_tables_export_device", "d2d_tables_import_device", "d2d_get_info", "d2d_kernel_name",
            "d2d_profile_enable", "d2d_profile_read"]
@@ -84,6 +85,8 @@ def lib():
     L.d2d_next_frames.restype = C.c_size_t
     L.d2d_translate.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
     L.d2d_translate_batch_device.argtypes = [C.c_void_p, C.POINTER(FileIO), C.c_uint32, C.c_void_p]
+    L.d2d_translate_batch_host.argtypes = [C.c_void_p, C.POINTER(FileIO), C.c_uint32, C.c_size_t]
+    L.d2d_translate_batch_host.restype = C.c_int
     L.d2d_peak.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_double)]
     L.d2d_peak_dbfs.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_float)]
     L.d2d_convert_stream.argtypes = [C.c_void_p, READ_FN, C.c_void_p, WRITE_FN, C.c_void_p,
@@ -177,6 +180,10 @@ class Engine:
     def translate_batch_device(self, ios, stream=None):
         """ios: ctypes array of FileIO with DEVICE pointers; asynchronous on `stream` (hipStream_t int)."""
         self._check(lib().d2d_translate_batch_device(self._h, ios, len(ios), C.c_void_p(stream or 0)))
+
+    def translate_batch_host(self, ios, slice_bytes_per_channel=0):
+        """ios: ctypes array of FileIO with HOST pointers (pinned for overlap); synchronous."""
+        self._check(lib().d2d_translate_batch_host(self._h, ios, len(ios), slice_bytes_per_channel))
 
     def peak(self, channel, file=0):
         v = C.c_double()

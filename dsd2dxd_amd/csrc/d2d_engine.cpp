@@ -60,6 +60,11 @@ struct d2d_engine {
     StreamJob* h_jobs = nullptr;          // pinned, JOB_SLOTS x nstreams
     hipEvent_t job_ev[JOB_SLOTS]{}; bool job_ev_used[JOB_SLOTS]{}; int job_slot = 0;
     hipStream_t own_stream = nullptr;     // used by the host-pointer entry points
+    // d2d_translate_batch_host: upload / convert / download streams, their events, double-buffered staging
+    hipStream_t hb_stream[3] = {nullptr, nullptr, nullptr};
+    hipEvent_t hb_ev[6] = {};
+    uint8_t* hb_in[2] = {nullptr, nullptr}; uint8_t* hb_out[2] = {nullptr, nullptr};
+    size_t hb_in_stride = 0, hb_out_stride = 0;
     hipStream_t last_stream = nullptr;
     // measurement
     bool profiling = false;
@@ -133,6 +138,9 @@ static void free_device(d2d_engine* e) {
     for (int i = 0; i < JOB_SLOTS; ++i)
         if (e->job_ev[i]) hipEventDestroy(e->job_ev[i]);
     if (e->own_stream) hipStreamDestroy(e->own_stream);
+    for (int i = 0; i < 3; ++i) if (e->hb_stream[i]) hipStreamDestroy(e->hb_stream[i]);
+    for (int i = 0; i < 6; ++i) if (e->hb_ev[i]) hipEventDestroy(e->hb_ev[i]);
+    for (int b = 0; b < 2; ++b) { if (e->hb_in[b]) hipFree(e->hb_in[b]); if (e->hb_out[b]) hipFree(e->hb_out[b]); }
     for (auto& pr : e->prof_pool) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
 }
 
@@ -451,6 +459,86 @@ int d2d_translate(d2d_engine* e, const uint8_t* dsd, size_t L, void* pcm, size_t
     if (out_bytes) HIPCHK(e, hipMemcpyAsync(pcm, e->d_out, out_bytes, hipMemcpyDeviceToHost, s));
     HIPCHK(e, hipStreamSynchronize(s));
     if (frames_out) *frames_out = io.frames_out;
+    return D2D_OK;
+}
+
+int d2d_translate_batch_host(d2d_engine* e, d2d_file_io* io, uint32_t n_files, size_t slice) {
+    if (!e) return D2D_ERR_PARAM;
+    if (!io || n_files != e->n_files) return e->fail(D2D_ERR_PARAM, "file count does not match the engine");
+    HIPCHK(e, hipSetDevice(e->p.device));
+    const uint32_t C = e->C;
+    const size_t fb = d2d_frame_bytes(e);
+    if (slice == 0) slice = 4u << 20;
+    if (e->B > 1) slice = std::max<size_t>(e->B, slice / e->B * e->B);       // whole planar blocks per slice
+    slice = (slice + 15) & ~(size_t)15;
+    size_t max_L = 0;
+    for (uint32_t f = 0; f < n_files; ++f) {
+        if (io[f].bytes_per_channel && !io[f].dsd) return e->fail(D2D_ERR_PARAM, "null dsd pointer");
+        max_L = std::max(max_L, io[f].bytes_per_channel);
+        io[f].frames_out = 0;
+    }
+    if (max_L == 0) return D2D_OK;
+    // capacity of one slice's output: the engine never emits more than ceil(bytes*8/M)+1 frames per call
+    const double ratio = e->fc.resamp ? (double)e->fc.resamp->L / (double)e->fc.resamp->Mdn / (double)e->M : 1.0 / (double)e->M;
+    const size_t in_stride = (slice * C + 255) & ~(size_t)255;
+    const size_t out_stride = (((size_t)((double)slice * 8.0 * ratio) + 4) * fb + 255) & ~(size_t)255;
+    if (!e->hb_in[0] || e->hb_in_stride < in_stride || e->hb_out_stride < out_stride) {
+        HIPCHK(e, hipDeviceSynchronize());
+        for (int b = 0; b < 2; ++b) {
+            if (e->hb_in[b]) hipFree(e->hb_in[b]);
+            if (e->hb_out[b]) hipFree(e->hb_out[b]);
+            e->hb_in[b] = e->hb_out[b] = nullptr;
+            HIPCHK(e, hipMalloc((void**)&e->hb_in[b], in_stride * n_files));
+            HIPCHK(e, hipMalloc((void**)&e->hb_out[b], out_stride * n_files));
+        }
+        e->hb_in_stride = in_stride; e->hb_out_stride = out_stride;
+    }
+    if (!e->hb_stream[0]) {
+        for (int i = 0; i < 3; ++i) HIPCHK(e, hipStreamCreateWithFlags(&e->hb_stream[i], hipStreamNonBlocking));
+        for (int i = 0; i < 6; ++i) HIPCHK(e, hipEventCreateWithFlags(&e->hb_ev[i], hipEventDisableTiming));
+    }
+    hipStream_t s_in = e->hb_stream[0], s_c = e->hb_stream[1], s_out = e->hb_stream[2];
+    hipEvent_t* in_done = e->hb_ev; hipEvent_t* comp_done = e->hb_ev + 2; hipEvent_t* out_done = e->hb_ev + 4;
+    std::vector<size_t> done(n_files, 0);
+    std::vector<d2d_file_io> dio(n_files);
+    const size_t nslices = (max_L + slice - 1) / slice;
+    for (size_t k = 0; k < nslices; ++k) {
+        const int b = (int)(k & 1);
+        // upload: the staging buffer is free once the conversion of slice k-2 has read it
+        if (k >= 2) HIPCHK(e, hipStreamWaitEvent(s_in, comp_done[b], 0));
+        for (uint32_t f = 0; f < n_files; ++f) {
+            const size_t L = std::min(slice, io[f].bytes_per_channel - done[f]);
+            dio[f].dsd = e->hb_in[b] + in_stride * f;
+            dio[f].bytes_per_channel = L;
+            dio[f].pcm = e->hb_out[b] + out_stride * f;
+            dio[f].pcm_capacity_bytes = out_stride;
+            if (L) HIPCHK(e, hipMemcpyAsync(e->hb_in[b] + in_stride * f, (const uint8_t*)io[f].dsd + done[f] * C, L * C, hipMemcpyHostToDevice, s_in));
+            done[f] += L;
+        }
+        HIPCHK(e, hipEventRecord(in_done[b], s_in));
+        // conversion: after its upload, and after the download of slice k-2 has drained the output buffer
+        HIPCHK(e, hipStreamWaitEvent(s_c, in_done[b], 0));
+        if (k >= 2) HIPCHK(e, hipStreamWaitEvent(s_c, out_done[b], 0));
+        int rc = d2d_translate_batch_device(e, dio.data(), n_files, s_c);
+        if (rc) { hipDeviceSynchronize(); return rc; }
+        HIPCHK(e, hipEventRecord(comp_done[b], s_c));
+        // download
+        HIPCHK(e, hipStreamWaitEvent(s_out, comp_done[b], 0));
+        for (uint32_t f = 0; f < n_files; ++f) {
+            const size_t bytes = dio[f].frames_out * fb;
+            if (!bytes) continue;
+            if ((io[f].frames_out + dio[f].frames_out) * fb > io[f].pcm_capacity_bytes || !io[f].pcm) {
+                hipDeviceSynchronize();
+                return e->fail(D2D_ERR_CAPACITY, "pcm buffer too small");
+            }
+            HIPCHK(e, hipMemcpyAsync((uint8_t*)io[f].pcm + io[f].frames_out * fb, e->hb_out[b] + out_stride * f, bytes, hipMemcpyDeviceToHost, s_out));
+            io[f].frames_out += dio[f].frames_out;
+        }
+        HIPCHK(e, hipEventRecord(out_done[b], s_out));
+    }
+    HIPCHK(e, hipStreamSynchronize(s_out));
+    HIPCHK(e, hipStreamSynchronize(s_c));
+    e->last_stream = s_c;
     return D2D_OK;
 }
 

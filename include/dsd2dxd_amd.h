@@ -116,6 +116,17 @@ typedef struct d2d_file_io {
  * (src/main.rs:280-300) turned into a grid dimension. */
 int d2d_translate_batch_device(d2d_engine* e, d2d_file_io* io, uint32_t n_files, void* hip_stream);
 
+/* The same batch with HOST-resident buffers: `dsd` and `pcm` of every d2d_file_io are host pointers
+ * (pinned memory -- hipHostMalloc / hipHostRegister -- lets the three stages overlap; pageable memory
+ * works but serialises).  The engine cuts the batch along time into slices of about
+ * `slice_bytes_per_channel` (0 = 4 MiB; whole planar blocks), and runs upload, conversion and download
+ * of consecutive slices on three streams over double-buffered device staging, so that the PCIe link
+ * and the kernels work at the same time.  Synchronous: returns when every `pcm` is filled;
+ * io[i].frames_out is the total.  What the many-file path of a host that holds its files in RAM
+ * calls; the reference's analogue is one Rayon worker per file reading,
+ * converting and writing block by block (src/main.rs:280-300,345). */
+int d2d_translate_batch_host(d2d_engine* e, d2d_file_io* io, uint32_t n_files, size_t slice_bytes_per_channel);
+
 /* Rdsd2Pcm::check_level's result (src/bin/dsd_levels/main.rs:252-262): peak of |sample * gain|
  * seen so far.  Synchronises with the engine's pending work. */
 int d2d_peak(d2d_engine* e, uint32_t file, uint32_t channel, double* peak_out);

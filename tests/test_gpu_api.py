@@ -161,3 +161,36 @@ def test_engines_on_concurrent_threads(engine_lib, oracle_mod):
         r, rf = want[i]
         fb = {16: 2, 32: 4}.get(configs[i]["bit_depth"], 3) * configs[i]["channels"]
         assert got[i][1] == rf and np.array_equal(got[i][0], r[:rf * fb]), i
+
+
+@pytest.mark.parametrize("out_rate,fmt,pinned", [(88200, "P", True), (96000, "I", False), (176400, "P", False)])
+def test_host_resident_batch_pipeline(engine_lib, oracle_mod, out_rate, fmt, pinned):
+    """d2d_translate_batch_host: ragged files, many slices (upload / convert / download overlapped), state
+    carried from slice to slice; the bytes equal the oracle's one-shot conversion of each file"""
+    import torch
+    kw = dict(KW, output_rate=out_rate, fmt=fmt, endianness="L" if fmt == "P" else "M")
+    lens = [4096 * 7 + 123, 4096 * 3, 0, 4096 * 12 + 4000]
+    files = [pack_layout([random_bytes(n, 60 + i), random_bytes(n, 70 + i)], fmt, 4096 if fmt == "P" else 1) for i, n in enumerate(lens)]
+    e = engine_lib.Engine(n_files=len(lens), kernel=2, **kw)
+    fb = e.frame_bytes
+    want = [oracle_mod.Oracle(**kw).translate(f) for f in files]
+    ins, outs = [], []
+    for f, (r, rf) in zip(files, want):
+        ti = torch.from_numpy(f.copy()) if f.size else torch.zeros(16, dtype=torch.uint8)
+        to = torch.zeros(rf * fb + 64, dtype=torch.uint8)
+        if pinned:
+            ti, to = ti.pin_memory(), to.pin_memory()
+        ins.append(ti); outs.append(to)
+    ios = (engine_lib.FileIO * len(lens))()
+    for i, n in enumerate(lens):
+        ios[i].dsd = ins[i].data_ptr(); ios[i].bytes_per_channel = n
+        ios[i].pcm = outs[i].data_ptr(); ios[i].pcm_capacity_bytes = outs[i].numel()
+    e.translate_batch_host(ios, 8192)                            # 2-block slices: up to 7 of them
+    for i, (r, rf) in enumerate(want):
+        assert ios[i].frames_out == rf, (i, ios[i].frames_out, rf)
+        assert np.array_equal(outs[i][:rf * fb].numpy(), r[:rf * fb]), i
+    # too small an output buffer is reported, not overrun
+    e2 = engine_lib.Engine(n_files=len(lens), kernel=2, **kw)
+    ios[3].pcm_capacity_bytes = 64
+    with pytest.raises(Exception, match="pcm buffer too small"):
+        e2.translate_batch_host(ios, 8192)
