@@ -62,6 +62,7 @@ struct MfmaArgs {
     uint32_t wave_lds;    // LDS bytes per wave
     uint32_t off_out, off_pk;   // inside a wave's region
     uint32_t nwaves;      // waves per block
+    uint32_t ngroups;     // channel groups per file: 1 for mono/stereo, else one block column per channel PAIR
     uint32_t dbg;         // diagnostic ablation mask (env D2D_DBG), 0 in production
     uint32_t stagger;     // start offset between wave slots, in units of 1024 cycles
 };
@@ -74,7 +75,8 @@ __device__ __forceinline__ void wave_sync() {
 }
 
 // 16 bytes of channel c's stream starting at call-relative byte j (j % 16 == 0).
-__device__ __forceinline__ u32x4 load_chunk(const StreamJob* jobs, const StreamJob& j0, uint32_t c, int32_t j,
+// (jobs[c] is the job of channel cbase + c of a file with C channels)
+__device__ __forceinline__ u32x4 load_chunk(const StreamJob* jobs, const StreamJob& j0, uint32_t c, uint32_t cbase, int32_t j,
                                             uint32_t C, uint32_t B, uint32_t keep) {
     const uint32_t L = (uint32_t)j0.L;
     if ((B & 15u) == 0 && j >= 0 && (uint32_t)j + 16 <= L) {
@@ -84,7 +86,7 @@ __device__ __forceinline__ u32x4 load_chunk(const StreamJob* jobs, const StreamJ
         uint32_t blen = L - blk * B;
         if (blen > B) blen = B;
         if ((blen & 15u) == 0) {
-            const uint8_t* p = j0.in + (uint64_t)blk * B * C + (uint64_t)c * blen + off;
+            const uint8_t* p = j0.in + (uint64_t)blk * B * C + (uint64_t)(cbase + c) * blen + off;
             return *reinterpret_cast<D2D_GLOBAL const u32x4*>(as_global(p));
         }
     }
@@ -101,13 +103,20 @@ template <int MB>
 __global__ __launch_bounds__(MFMA_MAX_THREADS, 3) void d2d_fir_mfma_kernel(MfmaArgs m) {
     const FirArgs& a = m.f;
     extern __shared__ __align__(16) unsigned char smem[];
-    const uint32_t C = a.epi.channels, sb = a.epi.sample_bytes, fbytes = sb * C;
+    // A block serves one channel group of one file: all channels for mono/stereo, one channel PAIR
+    // otherwise (many channels would not leave LDS for more than a few waves, and staging them all
+    // at once overruns the register prefetch).  Ct = channels of the file (input layout, output frame
+    // stride), C = channels of this group, cbase = its first channel.
+    const uint32_t Ct = a.epi.channels, sb = a.epi.sample_bytes;
+    const uint32_t fidx = blockIdx.y / m.ngroups, cbase = (blockIdx.y - fidx * m.ngroups) * 2u;
+    const uint32_t C = m.ngroups == 1 ? Ct : (Ct - cbase < 2u ? Ct - cbase : 2u);
+    const uint32_t fbytes = sb * C;                        // frame bytes inside the wave's LDS out-slice
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     uint8_t* wbase = smem + m.off_waves + wave * m.wave_lds;
     uint8_t* outw = wbase + m.off_out;
     double* pkw = reinterpret_cast<double*>(wbase + m.off_pk);
     uint32_t* rngw = reinterpret_cast<uint32_t*>(pkw + C * 64);
-    const StreamJob* jobs = a.jobs + (size_t)blockIdx.y * C;
+    const StreamJob* jobs = a.jobs + (size_t)fidx * Ct + cbase;   // jobs[c]: channel cbase + c
     const StreamJob j0 = jobs[0];          // in, L, e0, n0, nout are common to a file's channels
 
     const int64_t first0 = j0.e0 - (int64_t)a.Wb;          // first byte of output 0's window
@@ -164,14 +173,14 @@ __global__ __launch_bounds__(MFMA_MAX_THREADS, 3) void d2d_fir_mfma_kernel(MfmaA
             for (int i = 0; i < MFMA_PF; ++i)
                 if (lane + 64 * i < nch) {
                     const uint32_t j = (uint32_t)ab + pf_q[i] * 16;
-                    const uint64_t off = (uint64_t)((j >> bshift) * C) << bshift;   // start of the block group
-                    const uint8_t* p = j0.in + off + ((pf_c[i] << bshift) + (j & (Bsz - 1)));
+                    const uint64_t off = (uint64_t)((j >> bshift) * Ct) << bshift;   // start of the block group
+                    const uint8_t* p = j0.in + off + (((cbase + pf_c[i]) << bshift) + (j & (Bsz - 1)));
                     pf[i] = *reinterpret_cast<D2D_GLOBAL const u32x4*>(as_global(p));
                 }
         } else {
 #pragma unroll
             for (int i = 0; i < MFMA_PF; ++i)
-                if (lane + 64 * i < nch) pf[i] = load_chunk(jobs, j0, pf_c[i], ab + (int32_t)(pf_q[i] * 16), C, a.B, a.keep);
+                if (lane + 64 * i < nch) pf[i] = load_chunk(jobs, j0, pf_c[i], cbase, ab + (int32_t)(pf_q[i] * 16), Ct, a.B, a.keep);
         }
     };
     if (wt < nwt) prefetch(wt);
@@ -211,7 +220,7 @@ __global__ __launch_bounds__(MFMA_MAX_THREADS, 3) void d2d_fir_mfma_kernel(MfmaA
             }
         for (uint32_t ch = lane + 64 * MFMA_PF; ch < nch; ch += 64) {   // many channels / long windows
             const uint32_t c = ch / cpc, q = ch - c * cpc;
-            const u32x4 v = load_chunk(jobs, j0, c, tile_abeg(wt) + (int32_t)(q * 16), C, a.B, a.keep);
+            const u32x4 v = load_chunk(jobs, j0, c, cbase, tile_abeg(wt) + (int32_t)(q * 16), Ct, a.B, a.keep);
             *reinterpret_cast<uint32_t*>(wbase + lds_word_addr(c, q * 4 + 0)) = v.x;
             *reinterpret_cast<uint32_t*>(wbase + lds_word_addr(c, q * 4 + 1)) = v.y;
             *reinterpret_cast<uint32_t*>(wbase + lds_word_addr(c, q * 4 + 2)) = v.z;
@@ -368,7 +377,7 @@ __global__ __launch_bounds__(MFMA_MAX_THREADS, 3) void d2d_fir_mfma_kernel(MfmaA
                     }
                 }
             };
-            const bool reg_store = full && two && C == 2 && sb == 3 && !a.to_scratch;
+            const bool reg_store = full && two && Ct == 2 && sb == 3 && !a.to_scratch;
             if (m.dbg & 2) { if (acc0[0] == 0x12345 && acc1[5] == 77 && acc0[9] + acc1[13] + acc0[15] + acc1[2] == 99) outw[lane] = 1; }
             else if (reg_store) {
                 // Stereo 24-bit, whole tile: no LDS round trip.  Lane (r, h) owns frames 4h .. 4h+3 of
@@ -436,12 +445,21 @@ __global__ __launch_bounds__(MFMA_MAX_THREADS, 3) void d2d_fir_mfma_kernel(MfmaA
             wave_sync();
             // the wave-tile's interleaved frames: LDS -> HBM, 16 bytes per lane per store
             const uint32_t left = j0.nout - wt * 256;
-            const uint32_t nb = (left < 256u ? left : 256u) * fbytes;
-            uint8_t* g = reinterpret_cast<uint8_t*>(j0.out) + (size_t)wt * 256 * fbytes;
-            const uint32_t nb16 = nb & ~15u;
-            for (uint32_t i = lane * 16; i < nb16; i += 64 * 16)
-                *reinterpret_cast<D2D_GLOBAL u32x4*>(as_global(g + i)) = *reinterpret_cast<const u32x4*>(outw + i);
-            for (uint32_t i = nb16 + lane; i < nb; i += 64) as_global(g)[i] = outw[i];
+            const uint32_t nfr = left < 256u ? left : 256u;
+            if (m.ngroups == 1) {
+                const uint32_t nb = nfr * fbytes;
+                uint8_t* g = reinterpret_cast<uint8_t*>(j0.out) + (size_t)wt * 256 * fbytes;
+                const uint32_t nb16 = nb & ~15u;
+                for (uint32_t i = lane * 16; i < nb16; i += 64 * 16)
+                    *reinterpret_cast<D2D_GLOBAL u32x4*>(as_global(g + i)) = *reinterpret_cast<const u32x4*>(outw + i);
+                for (uint32_t i = nb16 + lane; i < nb; i += 64) as_global(g)[i] = outw[i];
+            } else {
+                // this group's `fbytes` bytes of every frame sit sb*cbase bytes into the file's frame
+                const uint32_t gstride = sb * Ct;
+                uint8_t* g = reinterpret_cast<uint8_t*>(j0.out) + (size_t)wt * 256 * gstride + sb * cbase;
+                for (uint32_t fr = lane; fr < nfr; fr += 64)
+                    for (uint32_t b = 0; b < fbytes; ++b) as_global(g)[(size_t)fr * gstride + b] = outw[fr * fbytes + b];
+            }
         }
         stamp(4);
     }
@@ -522,7 +540,9 @@ std::vector<int8_t> build_mfma_tables(const d2d_filter_def& f, const MfmaLayout&
 }
 
 static void mfma_geometry(const FirArgs& a, const MfmaLayout& g, MfmaArgs& m, size_t& smem) {
-    const uint32_t C = a.epi.channels;
+    // channels per block: all of a mono/stereo file, one pair of a multichannel one
+    m.ngroups = a.epi.channels <= 2 ? 1u : (a.epi.channels + 1u) / 2u;
+    const uint32_t C = a.epi.channels <= 2 ? a.epi.channels : 2u;
     const int MB = g.M / 8;
     m.f = a;
     m.c0 = a.to_scratch ? ldexp(1.0, a.scale_bits) : (a.epi.bits == 32 ? a.epi.gain : a.epi.scale);   // scratch: the integer y*2^S
@@ -602,11 +622,11 @@ static hipError_t launch_mfma_t(const MfmaArgs& m, size_t smem, uint32_t nwt_max
 hipError_t launch_fir_mfma(const FirArgs& a, const MfmaLayout& g, uint32_t max_nout, uint32_t nstreams, hipStream_t s) {
     if (nstreams == 0 || max_nout == 0) return hipSuccess;
     const uint32_t C = a.epi.channels;
-    const uint32_t nfiles = nstreams / C;
     const int MB = g.M / 8;
     MfmaArgs m{};
     size_t smem = 0;
     mfma_geometry(a, g, m, smem);
+    const uint32_t nfiles = (nstreams / C) * m.ngroups;       // grid rows: one per (file, channel group)
     if (smem > 160 * 1024) return hipErrorInvalidValue;
     const uint32_t nwt = (max_nout + 255u) / 256u;
     switch (MB) {
