@@ -276,10 +276,14 @@ __global__ __launch_bounds__(RS_THREADS, 6) void d2d_resample_kernel(ResampArgs 
 // Byte-interleaved input (DFF, `-f I`: c0 c1 c0 c1 ...) -> the planar 4096-byte-block layout the FIR
 // kernels stream with 16-byte loads.  A block moves DI_TILE bytes per channel: the source range is
 // contiguous (coalesced 16-byte loads into LDS), each thread then gathers one channel's 16 bytes from
-// LDS and stores them as one 16-byte word.  The last (short) block group keeps the engine's layout
-// rule: channels packed back to back with the short length.
-constexpr uint32_t DI_TILE = 256;
+// LDS and stores them as one 16-byte word (a wave writes 1 KiB contiguous per channel).  In LDS every
+// group of 16 frames (16*C bytes) is followed by one pad dword: the threads of a wave gather from
+// consecutive groups, 4C+1 dwords apart -- an odd stride, so their byte reads fall on distinct banks.
+// The last (short) block group keeps the engine's layout rule: channels packed back to back with the
+// short length.
+constexpr uint32_t DI_TILE = 1024;
 constexpr uint32_t DI_BLOCK = 4096;
+__host__ __device__ constexpr uint32_t di_lds_bytes(uint32_t C) { return DI_TILE * C + (DI_TILE / 16) * 4; }
 
 __global__ __launch_bounds__(256) void d2d_deinterleave_kernel(const StreamJob* jobs, uint32_t C) {
     extern __shared__ __align__(16) unsigned char smem[];
@@ -288,17 +292,21 @@ __global__ __launch_bounds__(256) void d2d_deinterleave_kernel(const StreamJob* 
     const D2D_GLOBAL uint8_t* src = as_global(job.in_raw);
     D2D_GLOBAL uint8_t* dst = as_global(const_cast<uint8_t*>(job.in));
     const uint32_t ntiles = (L + DI_TILE - 1) / DI_TILE;
+    const uint32_t gpitch = 16 * C + 4;                               // LDS bytes per group of 16 frames
     for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const uint32_t j0 = tile * DI_TILE;
         const uint32_t nj = min(DI_TILE, L - j0);                 // bytes per channel in this tile
         const uint32_t nbytes = nj * C;
-        const uint64_t s0 = (uint64_t)j0 * C;
+        const uint64_t s0 = (uint64_t)j0 * C;                     // a multiple of 16 (DI_TILE is)
         __syncthreads();
         for (uint32_t i = threadIdx.x * 16; i < nbytes; i += 256 * 16) {
-            if (i + 16 <= nbytes && ((s0 + i) & 15) == 0) {
-                *reinterpret_cast<u32x4*>(smem + i) = *reinterpret_cast<const D2D_GLOBAL u32x4*>(src + s0 + i);
+            uint8_t* d = smem + i + 4 * (i / (16 * C));           // a 16-byte chunk never straddles a pad
+            if (i + 16 <= nbytes && ((uintptr_t)(src + s0 + i) & 15) == 0) {
+                const u32x4 v = *reinterpret_cast<const D2D_GLOBAL u32x4*>(src + s0 + i);
+                uint32_t* dw = reinterpret_cast<uint32_t*>(d);
+                dw[0] = v.x; dw[1] = v.y; dw[2] = v.z; dw[3] = v.w;
             } else {
-                for (uint32_t b = i; b < min(i + 16, nbytes); ++b) smem[b] = src[s0 + b];
+                for (uint32_t b = i; b < min(i + 16, nbytes); ++b) d[b - i] = src[s0 + b];
             }
         }
         __syncthreads();
@@ -308,12 +316,13 @@ __global__ __launch_bounds__(256) void d2d_deinterleave_kernel(const StreamJob* 
         for (uint32_t t = threadIdx.x; t < nq * C; t += 256) {
             const uint32_t c = t / nq, q = t - c * nq;
             const uint32_t n = min(16u, nj - q * 16);
+            const uint8_t* g = smem + q * gpitch + c;
             uint32_t w[4] = {0, 0, 0, 0};
 #pragma unroll
             for (uint32_t b = 0; b < 16; ++b)
-                if (b < n) w[b >> 2] |= (uint32_t)smem[(q * 16 + b) * C + c] << (8 * (b & 3));
+                if (b < n) w[b >> 2] |= (uint32_t)g[b * C] << (8 * (b & 3));
             const uint64_t d0 = (uint64_t)blk * DI_BLOCK * C + (uint64_t)c * blen + off0 + q * 16;
-            if (n == 16 && (d0 & 15) == 0) {
+            if (n == 16 && ((uintptr_t)(dst + d0) & 15) == 0) {
                 *reinterpret_cast<D2D_GLOBAL u32x4*>(dst + d0) = u32x4{w[0], w[1], w[2], w[3]};
             } else {
                 for (uint32_t b = 0; b < n; ++b) dst[d0 + b] = (uint8_t)(w[b >> 2] >> (8 * (b & 3)));
@@ -426,7 +435,10 @@ hipError_t launch_deinterleave(const StreamJob* jobs, uint32_t nfiles, uint32_t 
     uint32_t gx = (max_L + DI_TILE - 1) / DI_TILE;
     const uint32_t cap = (8192 + nfiles - 1) / nfiles;
     if (gx > cap) gx = cap;
-    hipLaunchKernelGGL(d2d_deinterleave_kernel, dim3(gx, nfiles), dim3(256), (size_t)DI_TILE * C, s, jobs, C);
+    static KernelPrep prep;                                            // 64 channels need 66 KB of LDS
+    hipError_t e = prep.max_dynamic_lds(reinterpret_cast<const void*>(&d2d_deinterleave_kernel), 80 * 1024);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(d2d_deinterleave_kernel, dim3(gx, nfiles), dim3(256), (size_t)di_lds_bytes(C), s, jobs, C);
     return hipGetLastError();
 }
 

@@ -79,9 +79,29 @@ def test_depths_and_dithers(engine_lib, oracle_mod, bits, dither, out_rate, kern
         assert np.sqrt(np.mean((a - b) ** 2)) <= FLOAT_RMS_TOL
 
 
+@pytest.mark.parametrize("bits,dither,out_rate", [(16, "T", 88200), (20, "R", 176400), (32, "F", 352800), (24, "T", 96000), (32, "X", 192000)])
+@pytest.mark.parametrize("channels,fmt", [(5, "P"), (6, "I")])
+def test_multichannel_depths(engine_lib, oracle_mod, bits, dither, out_rate, channels, fmt):
+    """every sample format through the per-pair output path of the MFMA kernel (frames of one pair land
+    inside the file's wider frames), with a ragged tail"""
+    nbytes = 4096 * 3 + 700
+    chans = [random_bytes(nbytes, 300 + c) for c in range(channels)]
+    endian = "L" if fmt == "P" else "M"
+    cuts = [0, 4096 * 2, nbytes]
+    bufs = [pack_layout([ch[a:b] for ch in chans], fmt, 4096 if fmt == "P" else 1) for a, b in zip(cuts[:-1], cuts[1:])]
+    kw = dict(dsd_rate=1, output_rate=out_rate, channels=channels, fmt=fmt, endianness=endian, block_size=4096 if fmt == "P" else 1,
+              filter="E", bit_depth=bits, dither=dither, seed=9, level_db=-1.5)
+    g, r, e, o = run_pair(engine_lib, oracle_mod, bufs, kw, 2)
+    assert np.array_equal(g, r)
+    assert e.peak_dbfs() == o.peak_dbfs()
+
+
 @pytest.mark.parametrize("fmt,endian,block,channels", [
     ("P", "L", 4096, 1), ("P", "L", 4096, 2), ("P", "M", 4096, 2), ("I", "M", 4096, 2), ("I", "L", 1, 2),
     ("P", "L", 512, 2), ("P", "M", 24, 3), ("I", "M", 1, 6), ("P", "L", 4096, 8), ("P", "L", 100, 2),
+    # multichannel files run one block column per channel PAIR (odd counts leave a single), and
+    # byte-interleaved ones pass through the de-interleave kernel first
+    ("I", "M", 1, 3), ("I", "M", 1, 5), ("I", "L", 1, 8), ("P", "L", 4096, 5), ("P", "M", 4096, 6),
 ])
 @pytest.mark.parametrize("kernel", KERNELS)
 def test_layouts_and_ragged_calls(engine_lib, oracle_mod, fmt, endian, block, channels, kernel):
