@@ -5,6 +5,7 @@
 #include <math.h>
 
 #include <algorithm>
+#include <thread>
 #include <string.h>
 
 namespace d2dhost {
@@ -184,22 +185,28 @@ struct Md5 {
 };
 
 // FLAC with fixed-order-2 prediction and one Rice partition per subframe (valid, modest compression;
-// the reference uses the flac-codec crate, Cargo.lock:299-307).  Integer depths only.
-struct FlacSink : PcmSink {
-    FILE* f; uint32_t ch, rate, bits; uint64_t frames = 0; uint32_t frame_no = 0;
-    static constexpr uint32_t BS = 4096;
-    std::vector<int32_t> buf;      // interleaved pending samples
+// the reference uses the flac-codec crate, Cargo.lock:299-307).  Integer depths only.  Frames are
+// independent of each other, so a batch of them is encoded on as many threads and written in order.
+struct FlacFrameEnc {
     std::vector<uint8_t> out;
-    uint32_t min_fs = 0xFFFFFF, max_fs = 0;
-    std::vector<uint8_t> id3;
-    Md5 md5;                       // of the samples as little-endian whole-byte integers, interleaved (FLAC format, STREAMINFO)
+    std::vector<int32_t> res;
     uint64_t bitacc = 0; int bitn = 0;
-    static uint8_t crc8(const uint8_t* p, size_t n) { uint8_t c = 0; for (size_t i = 0; i < n; ++i) { c ^= p[i]; for (int k = 0; k < 8; ++k) c = (uint8_t)((c & 0x80) ? (c << 1) ^ 0x07 : (c << 1)); } return c; }
-    static uint16_t crc16(const uint8_t* p, size_t n) { uint16_t c = 0; for (size_t i = 0; i < n; ++i) { c ^= (uint16_t)(p[i] << 8); for (int k = 0; k < 8; ++k) c = (uint16_t)((c & 0x8000) ? (c << 1) ^ 0x8005 : (c << 1)); } return c; }
+    static const uint8_t* crc8_table() {
+        static uint8_t t[256]; static bool done = false;
+        if (!done) { for (int i = 0; i < 256; ++i) { uint8_t c = (uint8_t)i; for (int k = 0; k < 8; ++k) c = (uint8_t)((c & 0x80) ? (c << 1) ^ 0x07 : (c << 1)); t[i] = c; } done = true; }
+        return t;
+    }
+    static const uint16_t* crc16_table() {
+        static uint16_t t[256]; static bool done = false;
+        if (!done) { for (int i = 0; i < 256; ++i) { uint16_t c = (uint16_t)(i << 8); for (int k = 0; k < 8; ++k) c = (uint16_t)((c & 0x8000) ? (c << 1) ^ 0x8005 : (c << 1)); t[i] = c; } done = true; }
+        return t;
+    }
+    static uint8_t crc8(const uint8_t* p, size_t n) { const uint8_t* t = crc8_table(); uint8_t c = 0; for (size_t i = 0; i < n; ++i) c = t[c ^ p[i]]; return c; }
+    static uint16_t crc16(const uint8_t* p, size_t n) { const uint16_t* t = crc16_table(); uint16_t c = 0; for (size_t i = 0; i < n; ++i) c = (uint16_t)((c << 8) ^ t[(c >> 8) ^ p[i]]); return c; }
     void bits_put(uint64_t v, int n) {
         while (n > 0) {
             int take = n > 32 ? 32 : n;
-            uint64_t part = (v >> (n - take)) & ((take == 64) ? ~0ull : ((1ull << take) - 1));
+            uint64_t part = (v >> (n - take)) & ((1ull << take) - 1);
             bitacc = (bitacc << take) | part; bitn += take; n -= take;
             while (bitn >= 8) { out.push_back((uint8_t)(bitacc >> (bitn - 8))); bitn -= 8; }
         }
@@ -211,6 +218,65 @@ struct FlacSink : PcmSink {
         bits_put(((0xFF00 >> (n + 1)) & 0xFF) | (v >> (6 * n)), 8);
         for (int i = n - 1; i >= 0; --i) bits_put(0x80 | ((v >> (6 * i)) & 0x3F), 8);
     }
+    // one frame of `n` interleaved samples starting at `buf`
+    void encode(const int32_t* buf, uint32_t n, uint32_t ch, uint32_t depth, uint32_t frame_no, uint32_t BS) {
+        out.clear(); bitn = 0; bitacc = 0;
+        bits_put(0xFFF8, 16);                                          // sync, fixed block size
+        bits_put(n == BS ? 0xC : 0x7, 4);                              // 4096, or 16-bit (n-1) at the end of the header
+        bits_put(0x0, 4);                                              // sample rate from STREAMINFO
+        bits_put(ch - 1, 4);                                           // independent channels
+        bits_put(depth == 16 ? 4 : depth == 20 ? 5 : 6, 3); bits_put(0, 1);
+        put_utf8(frame_no);
+        if (n != BS) bits_put(n - 1, 16);
+        bits_flush();
+        out.push_back(crc8(out.data(), out.size()));
+        res.resize(n);
+        for (uint32_t c = 0; c < ch; ++c) {
+            auto s = [&](uint32_t i) -> int64_t { return buf[(size_t)i * ch + c]; };
+            const uint32_t order = n > 2 ? 2 : 0;
+            uint64_t sum = 0;
+            bool fits = true;
+            for (uint32_t i = order; i < n; ++i) {
+                int64_t r = order == 2 ? s(i) - 2 * s(i - 1) + s(i - 2) : s(i);
+                if (r > 0x3FFFFFFF || r < -0x3FFFFFFF) fits = false;
+                res[i] = (int32_t)r; sum += (uint64_t)(r < 0 ? -r : r);
+            }
+            if (!fits || order == 0) {                                   // verbatim subframe
+                bits_put(0, 1); bits_put(1, 6); bits_put(0, 1);
+                for (uint32_t i = 0; i < n; ++i) bits_put((uint64_t)s(i) & ((1ull << depth) - 1), (int)depth);
+                continue;
+            }
+            bits_put(0, 1); bits_put(8 + order, 6); bits_put(0, 1);    // fixed predictor, no wasted bits
+            for (uint32_t i = 0; i < order; ++i) bits_put((uint64_t)s(i) & ((1ull << depth) - 1), (int)depth);
+            uint32_t k = 0;
+            const uint64_t mean = sum / (n - order ? n - order : 1);
+            while (k < 30 && (1ull << k) < mean) ++k;
+            bits_put(1, 2);                                             // residual coding method 1: 5-bit Rice parameters
+            bits_put(0, 4);                                             // partition order 0
+            bits_put(k, 5);
+            for (uint32_t i = order; i < n; ++i) {
+                uint32_t u = res[i] >= 0 ? (uint32_t)res[i] << 1 : (((uint32_t)(-(int64_t)res[i])) << 1) - 1;
+                uint32_t q = u >> k;
+                while (q >= 32) { bits_put(0, 32); q -= 32; }
+                bits_put(1, (int)q + 1);
+                if (k) bits_put(u & ((1u << k) - 1), (int)k);
+            }
+        }
+        bits_flush();
+        uint16_t c16 = crc16(out.data(), out.size());
+        out.push_back((uint8_t)(c16 >> 8)); out.push_back((uint8_t)c16);
+    }
+};
+
+struct FlacSink : PcmSink {
+    FILE* f; uint32_t ch, rate, bits; uint64_t frames = 0; uint32_t frame_no = 0;
+    static constexpr uint32_t BS = 4096;
+    std::vector<int32_t> buf;      // interleaved pending samples
+    uint32_t min_fs = 0xFFFFFF, max_fs = 0;
+    std::vector<uint8_t> id3;
+    Md5 md5;                       // of the samples as little-endian whole-byte integers, interleaved (FLAC format, STREAMINFO)
+    std::vector<FlacFrameEnc> encs;
+    bool io_failed = false;
     uint32_t depth() const { return bits == 20 ? 20 : bits; }
     std::string begin() {
         // metadata: STREAMINFO (filled in at close), then the source's tag as VORBIS_COMMENT and PICTURE
@@ -250,74 +316,53 @@ struct FlacSink : PcmSink {
         for (const auto& b : blocks) if (fwrite(b.data(), 1, b.size(), f) != b.size()) return "short write";
         return "";
     }
-    void encode_frame(uint32_t n) {
-        out.clear(); bitn = 0; bitacc = 0;
-        bits_put(0xFFF8, 16);                                          // sync, fixed block size
-        bits_put(n == BS ? 0xC : 0x7, 4);                              // 4096, or 16-bit (n-1) at the end of the header
-        bits_put(0x0, 4);                                              // sample rate from STREAMINFO
-        bits_put(ch - 1, 4);                                           // independent channels
-        bits_put(depth() == 16 ? 4 : depth() == 20 ? 5 : 6, 3); bits_put(0, 1);
-        put_utf8(frame_no);
-        if (n != BS) bits_put(n - 1, 16);
-        bits_flush();
-        out.push_back(crc8(out.data(), out.size()));
-        std::vector<int32_t> res(n);
-        for (uint32_t c = 0; c < ch; ++c) {
-            auto s = [&](uint32_t i) -> int64_t { return buf[(size_t)i * ch + c]; };
-            const uint32_t order = n > 2 ? 2 : 0;
-            uint64_t sum = 0;
-            for (uint32_t i = order; i < n; ++i) {
-                int64_t r = order == 2 ? s(i) - 2 * s(i - 1) + s(i - 2) : s(i);
-                res[i] = (int32_t)r; sum += (uint64_t)(r < 0 ? -r : r);
-            }
-            bool fits = true;
-            for (uint32_t i = order; i < n && fits; ++i) { int64_t r = order == 2 ? s(i) - 2 * s(i - 1) + s(i - 2) : s(i); if (r > 0x3FFFFFFF || r < -0x3FFFFFFF) fits = false; }
-            if (!fits || order == 0) {                                   // verbatim subframe
-                bits_put(0, 1); bits_put(1, 6); bits_put(0, 1);
-                for (uint32_t i = 0; i < n; ++i) bits_put((uint64_t)s(i) & ((1ull << depth()) - 1), (int)depth());
-                continue;
-            }
-            bits_put(0, 1); bits_put(8 + order, 6); bits_put(0, 1);    // fixed predictor, no wasted bits
-            for (uint32_t i = 0; i < order; ++i) bits_put((uint64_t)s(i) & ((1ull << depth()) - 1), (int)depth());
-            uint32_t k = 0;
-            const uint64_t mean = sum / (n - order ? n - order : 1);
-            while (k < 30 && (1ull << k) < mean) ++k;
-            bits_put(1, 2);                                             // residual coding method 1: 5-bit Rice parameters
-            bits_put(0, 4);                                             // partition order 0
-            bits_put(k, 5);
-            for (uint32_t i = order; i < n; ++i) {
-                uint32_t u = res[i] >= 0 ? (uint32_t)res[i] << 1 : (((uint32_t)(-(int64_t)res[i])) << 1) - 1;
-                uint32_t q = u >> k;
-                while (q >= 32) { bits_put(0, 32); q -= 32; }
-                bits_put(1, (int)q + 1);
-                if (k) bits_put(u & ((1u << k) - 1), (int)k);
-            }
+    // encodes the pending whole frames (and, at the end, the short last one) in batches, one thread per
+    // frame of a batch, and writes them in order
+    void drain(bool final) {
+        if (encs.empty()) {
+            (void)FlacFrameEnc::crc8_table(); (void)FlacFrameEnc::crc16_table();        // built before any thread runs
+            unsigned hw = std::thread::hardware_concurrency();
+            encs.resize(std::max(1u, std::min(16u, hw ? hw : 1u)));
         }
-        bits_flush();
-        uint16_t c16 = crc16(out.data(), out.size());
-        out.push_back((uint8_t)(c16 >> 8)); out.push_back((uint8_t)c16);
-        fwrite(out.data(), 1, out.size(), f);
-        if (out.size() < min_fs) min_fs = (uint32_t)out.size();
-        if (out.size() > max_fs) max_fs = (uint32_t)out.size();
-        ++frame_no; frames += n;
+        const size_t per = (size_t)BS * ch;
+        const size_t nfull = buf.size() / per, rem = buf.size() - nfull * per;
+        std::vector<std::pair<size_t, uint32_t>> jobs;                   // (first sample, frames) of each FLAC frame
+        for (size_t i = 0; i < nfull; ++i) jobs.push_back({i * per, BS});
+        if (final && rem) jobs.push_back({nfull * per, (uint32_t)(rem / ch)});
+        for (size_t j0 = 0; j0 < jobs.size(); j0 += encs.size()) {
+            const size_t nb = std::min(encs.size(), jobs.size() - j0);
+            std::vector<std::thread> th;
+            for (size_t j = 1; j < nb; ++j)
+                th.emplace_back([&, j] { encs[j].encode(buf.data() + jobs[j0 + j].first, jobs[j0 + j].second, ch, depth(), frame_no + (uint32_t)j, BS); });
+            encs[0].encode(buf.data() + jobs[j0].first, jobs[j0].second, ch, depth(), frame_no, BS);
+            for (auto& t : th) t.join();
+            for (size_t j = 0; j < nb; ++j) {
+                const std::vector<uint8_t>& o = encs[j].out;
+                if (fwrite(o.data(), 1, o.size(), f) != o.size()) io_failed = true;
+                if (o.size() < min_fs) min_fs = (uint32_t)o.size();
+                if (o.size() > max_fs) max_fs = (uint32_t)o.size();
+                frames += jobs[j0 + j].second;
+            }
+            frame_no += (uint32_t)nb;
+        }
+        buf.erase(buf.begin(), buf.begin() + (final ? buf.size() : nfull * per));
     }
     std::string write(const uint8_t* p, size_t nbytes) override {
         const size_t sb = bits == 16 ? 2 : 3;
+        buf.reserve(buf.size() + nbytes / sb);
         for (size_t i = 0; i + sb <= nbytes; i += sb) {
             int32_t v = sb == 2 ? (int16_t)(p[i] | (p[i + 1] << 8)) : (int32_t)((p[i] | (p[i + 1] << 8) | (p[i + 2] << 16)) << 8) >> 8;
             if (bits == 20) v >>= 4;
-            const uint8_t le[3] = {(uint8_t)v, (uint8_t)(v >> 8), (uint8_t)(v >> 16)};
-            md5.update(le, sb);
             buf.push_back(v);
         }
-        while (buf.size() >= (size_t)BS * ch) {
-            encode_frame(BS);
-            buf.erase(buf.begin(), buf.begin() + (size_t)BS * ch);
-        }
-        return "";
+        if (bits == 20) {                                                // MD5 runs over the 20-bit values as 3-byte integers
+            for (size_t i = buf.size() - nbytes / sb; i < buf.size(); ++i) { const int32_t v = buf[i]; const uint8_t le[3] = {(uint8_t)v, (uint8_t)(v >> 8), (uint8_t)(v >> 16)}; md5.update(le, 3); }
+        } else md5.update(p, nbytes / sb * sb);                          // 16/24-bit: the little-endian input as it is
+        if (buf.size() >= (size_t)BS * ch * 8) drain(false);
+        return io_failed ? "short write" : "";
     }
     std::string close() override {
-        if (!buf.empty()) encode_frame((uint32_t)(buf.size() / ch));
+        drain(true);
         uint8_t si[34]; memset(si, 0, sizeof(si));
         put_be16(si, BS); put_be16(si + 2, BS);
         si[4] = min_fs >> 16; si[5] = min_fs >> 8; si[6] = (uint8_t)min_fs; si[7] = max_fs >> 16; si[8] = max_fs >> 8; si[9] = (uint8_t)max_fs;
@@ -325,7 +370,8 @@ struct FlacSink : PcmSink {
         for (int i = 0; i < 8; ++i) si[10 + i] = (uint8_t)(v >> (56 - 8 * i));
         md5.finish(si + 18);
         fseek(f, 8, SEEK_SET); fwrite(si, 1, 34, f);
-        return fclose(f) == 0 ? "" : "close failed";
+        if (fclose(f) != 0 || io_failed) return "close failed";
+        return "";
     }
 };
 
