@@ -113,6 +113,9 @@ __global__ __launch_bounds__(LUT_THREADS) void d2d_fir_lut_kernel(FirArgs a) {
 //     chain still sees its own taps in ascending k.
 // A tile = 64 cycles of one stream: its Mdn*64 + nsteps stage-A samples are staged in LDS, the
 // results go back through LDS so that the PCM stores run along consecutive frames.
+#ifndef D2D_DIAG
+#define D2D_DIAG 0
+#endif
 constexpr int RS_R = 4;
 constexpr int RS_WAVES = 10;                         // L/RS_R tasks per tile = RS_WAVES * NT
 constexpr int RS_THREADS = RS_WAVES * 64;
@@ -158,7 +161,8 @@ __device__ __forceinline__ uint32_t quantise_bits(const ResampArgs& a, const Str
     }
 
 template <int NT>
-__global__ __launch_bounds__(RS_THREADS, 6) void d2d_resample_kernel(ResampArgs a, uint32_t dbg) {
+__global__ __launch_bounds__(RS_THREADS, 6) void d2d_resample_kernel(ResampArgs a, uint32_t dbg_arg) {
+    const uint32_t dbg = D2D_DIAG ? dbg_arg : 0u;            // ablation switches exist in a -DD2D_DIAG=1 build only
     extern __shared__ __align__(16) unsigned char smem[];
     double* xt = reinterpret_cast<double*>(smem);              // [RS_XPAD + Mdn*64 + nsteps], later the output tile
     uint32_t* ot = reinterpret_cast<uint32_t*>(smem);          // [64][L + 1]: the odd row stride keeps the lanes' writes on distinct banks

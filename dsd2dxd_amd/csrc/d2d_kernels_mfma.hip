@@ -42,6 +42,12 @@ typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 constexpr int MFMA_MAX_THREADS = 768;   // 12 waves = 3 per SIMD, what 168 VGPRs allow
 constexpr int MFMA_PF = 3;   // 16-byte chunks per lane fetched one wave-tile ahead
 
+// Diagnostics (phase ablations, in-kernel cycle stamps, start staggering, the MFMA-phase token) exist
+// only in a build with -DD2D_DIAG=1 (make DIAG=1); the production kernel carries none of their state.
+#ifndef D2D_DIAG
+#define D2D_DIAG 0
+#endif
+
 // diagnostic build only (D2D_DBG bit 4): wave-cycles per phase, summed over all waves
 __device__ unsigned long long d2d_stamp_acc[8];
 
@@ -102,6 +108,7 @@ __device__ __forceinline__ u32x4 load_chunk(const StreamJob* jobs, const StreamJ
 template <int MB>
 __global__ __launch_bounds__(MFMA_MAX_THREADS, 3) void d2d_fir_mfma_kernel(MfmaArgs m) {
     const FirArgs& a = m.f;
+    const uint32_t dbg = D2D_DIAG ? m.dbg : 0u;
     extern __shared__ __align__(16) unsigned char smem[];
     // A block serves one channel group of one file: all channels for mono/stereo, one channel PAIR
     // otherwise (many channels would not leave LDS for more than a few waves, and staging them all
@@ -128,8 +135,10 @@ __global__ __launch_bounds__(MFMA_MAX_THREADS, 3) void d2d_fir_mfma_kernel(MfmaA
         uint4* dl = reinterpret_cast<uint4*>(smem);
         for (uint32_t i = tid; i < (a.ksteps + 6) * 64; i += blockDim.x) dl[i] = s[i];
     }
+#if D2D_DIAG
     uint32_t* tokens = reinterpret_cast<uint32_t*>(smem + (a.ksteps + 6) * 1024);
     if (tid < 16) tokens[tid] = 0;
+#endif
     for (uint32_t c = 0; c < C; ++c) pkw[c * 64 + lane] = 0.0;
     if (lane < C) {   // per-channel dither keys: global -> this wave's LDS once
         rngw[lane * 4 + 0] = jobs[lane].rng_key;
@@ -184,22 +193,28 @@ __global__ __launch_bounds__(MFMA_MAX_THREADS, 3) void d2d_fir_mfma_kernel(MfmaA
         }
     };
     if (wt < nwt) prefetch(wt);
+#if D2D_DIAG
     {   // Waves that run the same program fall into lockstep (all in the MFMA loop together, then all in
         // the VALU epilogue together) and the two pipes never overlap.  A one-off start offset per wave
         // slot keeps them apart: the work per wave-tile is identical, so the offset persists.
-        const uint32_t slot = ((wave >> 2) + 2u * (blockIdx.x & 1u) + (m.dbg >> 8)) & 3u;
+        const uint32_t slot = ((wave >> 2) + 2u * (blockIdx.x & 1u) + (dbg >> 8)) & 3u;
         for (uint32_t i = 0; i < slot * m.stagger; ++i) __builtin_amdgcn_s_sleep(16);
     }
+#endif
 
+#if D2D_DIAG
     unsigned long long st_sum[6] = {0, 0, 0, 0, 0, 0}, st_last = 0;
     auto stamp = [&](int slot) {
-        if (m.dbg & 16) {
+        if (dbg & 16) {
             unsigned long long t;
             asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
             if (slot >= 0) st_sum[slot] += t - st_last;
             st_last = t;
         }
     };
+#else
+    auto stamp = [](int) {};
+#endif
     const uint32_t r = lane & 31, h = lane >> 5;
     // this lane's row words: logical dword X0 + u of row r, pair-interleaved and padded in LDS
     const uint32_t X0 = (d >> 2) + h * U;
@@ -267,7 +282,7 @@ __global__ __launch_bounds__(MFMA_MAX_THREADS, 3) void d2d_fir_mfma_kernel(MfmaA
                 v4i P0 = bp[0], P1 = bp[64], Q0 = bp[2 * 64], Q1 = bp[3 * 64];
                 uint32_t u = 0;
                 const v4i* bq = bp;
-                if (m.dbg & 32) {          // diagnostic: the chain without its LDS reads
+                if (dbg & 32) {          // diagnostic: the chain without its LDS reads
                     for (; u + 2 <= U; u += 2) {
                         kpair(wP, P0, P1, two_tag);
                         wP.x += 0x01010101u; P0.x ^= (int)u;
@@ -287,18 +302,22 @@ __global__ __launch_bounds__(MFMA_MAX_THREADS, 3) void d2d_fir_mfma_kernel(MfmaA
             // Waves that share a SIMD (w and w+4 of a block) take turns in the MFMA phase: while one
             // multiplies, the other runs its VALU/memory phases, so the two pipes overlap instead of
             // all waves queueing on the matrix pipe together and then on the VALU together.
-            const bool use_token = (m.dbg & 64) != 0;
+#if D2D_DIAG
+            const bool use_token = (dbg & 64) != 0;
             if (use_token) {
                 if (lane == 0) { while (atomicCAS(&tokens[wave & 3u], 0u, 1u) != 0u) __builtin_amdgcn_s_sleep(2); }
                 __builtin_amdgcn_wave_barrier();
             }
-            if (m.dbg & 1) { acc0[0] = (int)lane; acc1[0] = (int)r; }
+#endif
+            if (dbg & 1) { acc0[0] = (int)lane; acc1[0] = (int)r; }
             else if (two) chain(std::true_type{}); else chain(std::false_type{});
+#if D2D_DIAG
             if (use_token) {
                 asm volatile("" :: "v"(acc0[15]), "v"(acc1[15]));
                 if (lane == 0) atomicExch(&tokens[wave & 3u], 0u);
             }
-            if (m.dbg & 16) { asm volatile("" :: "v"(acc0[15]), "v"(acc1[15])); }
+#endif
+            if (dbg & 16) { asm volatile("" :: "v"(acc0[15]), "v"(acc1[15])); }
             stamp(2);
 
             // ---- epilogue: lane (r, h) owns phases ph = h + 2k of row r for both channels ----
@@ -378,7 +397,7 @@ __global__ __launch_bounds__(MFMA_MAX_THREADS, 3) void d2d_fir_mfma_kernel(MfmaA
                 }
             };
             const bool reg_store = full && two && Ct == 2 && sb == 3 && !a.to_scratch;
-            if (m.dbg & 2) { if (acc0[0] == 0x12345 && acc1[5] == 77 && acc0[9] + acc1[13] + acc0[15] + acc1[2] == 99) outw[lane] = 1; }
+            if (dbg & 2) { if (acc0[0] == 0x12345 && acc1[5] == 77 && acc0[9] + acc1[13] + acc0[15] + acc1[2] == 99) outw[lane] = 1; }
             else if (reg_store) {
                 // Stereo 24-bit, whole tile: no LDS round trip.  Lane (r, h) owns frames 4h .. 4h+3 of
                 // row r for both channels = 24 contiguous output bytes; a few byte permutes pack them
@@ -441,7 +460,7 @@ __global__ __launch_bounds__(MFMA_MAX_THREADS, 3) void d2d_fir_mfma_kernel(MfmaA
             stored_from_regs = reg_store;
         }
         stamp(3);
-        if (!a.to_scratch && !(m.dbg & 4) && !stored_from_regs) {
+        if (!a.to_scratch && !(dbg & 4) && !stored_from_regs) {
             wave_sync();
             // the wave-tile's interleaved frames: LDS -> HBM, 16 bytes per lane per store
             const uint32_t left = j0.nout - wt * 256;
@@ -463,8 +482,10 @@ __global__ __launch_bounds__(MFMA_MAX_THREADS, 3) void d2d_fir_mfma_kernel(MfmaA
         }
         stamp(4);
     }
-    if ((m.dbg & 16) && lane == 0)
+#if D2D_DIAG
+    if ((dbg & 16) && lane == 0)
         for (int i = 0; i < 5; ++i) atomicAdd(&d2d_stamp_acc[i], st_sum[i]);
+#endif
     if (!a.to_scratch) {
         // peak meter: |x| was tracked in the scaled domain; undo the power-of-two part exactly
         const double unscale = a.epi.bits == 32 ? 1.0 : 1.0 / (double)(1u << (a.epi.bits - 1));

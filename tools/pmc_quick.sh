@@ -1,4 +1,5 @@
 #!/bin/bash
+# needs a diagnostic build: make -C dsd2dxd_amd/csrc clean && make -C dsd2dxd_amd/csrc DIAG=1 (rebuild without DIAG afterwards)
 # usage: tools/pmc_quick.sh <tag> "<counters>" [bench args]   (env is inherited: D2D_DBG, D2D_MFMA_NO_REG)
 TAG=$1; PMC=$2; shift; shift
 cd /tmp && export TMPDIR=/tmp
