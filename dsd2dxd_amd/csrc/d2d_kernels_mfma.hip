@@ -160,6 +160,10 @@ __global__ __launch_bounds__(MFMA_MAX_THREADS, 3) void d2d_fir_mfma_kernel(MfmaA
     auto lds_word_addr = [&](uint32_t c, uint32_t Ld) -> uint32_t {   // byte offset of staged dword Ld of channel c
         return (c >> 1) * m.ppair + (2u * (Ld + (Ld >> ls)) + (c & 1u)) * 4u;
     };
+    // dword k of a 16-byte chunk lands 8k bytes behind the chunk's first dword (the other channel of
+    // the pair sits in between), plus one 8-byte row pad after every second dword when the row stride
+    // is two dwords (MB = 1); with wider rows a chunk never straddles a pad.
+    auto chunk_dword_off = [](int k) -> uint32_t { return 8u * (uint32_t)k + (ls == 1 ? 8u * (uint32_t)(k >> 1) : 0u); };
 #pragma unroll
     for (int i = 0; i < MFMA_PF; ++i) {
         const uint32_t ch = lane + 64 * i;
@@ -228,10 +232,11 @@ __global__ __launch_bounds__(MFMA_MAX_THREADS, 3) void d2d_fir_mfma_kernel(MfmaA
 #pragma unroll
         for (int i = 0; i < MFMA_PF; ++i)
             if (lane + 64 * i < nch) {
-                *reinterpret_cast<uint32_t*>(wbase + lds_word_addr(pf_c[i], pf_q[i] * 4 + 0)) = pf[i].x;
-                *reinterpret_cast<uint32_t*>(wbase + lds_word_addr(pf_c[i], pf_q[i] * 4 + 1)) = pf[i].y;
-                *reinterpret_cast<uint32_t*>(wbase + lds_word_addr(pf_c[i], pf_q[i] * 4 + 2)) = pf[i].z;
-                *reinterpret_cast<uint32_t*>(wbase + lds_word_addr(pf_c[i], pf_q[i] * 4 + 3)) = pf[i].w;
+                uint8_t* dst = wbase + lds_word_addr(pf_c[i], pf_q[i] * 4);
+                *reinterpret_cast<uint32_t*>(dst + chunk_dword_off(0)) = pf[i].x;
+                *reinterpret_cast<uint32_t*>(dst + chunk_dword_off(1)) = pf[i].y;
+                *reinterpret_cast<uint32_t*>(dst + chunk_dword_off(2)) = pf[i].z;
+                *reinterpret_cast<uint32_t*>(dst + chunk_dword_off(3)) = pf[i].w;
             }
         for (uint32_t ch = lane + 64 * MFMA_PF; ch < nch; ch += 64) {   // many channels / long windows
             const uint32_t c = ch / cpc, q = ch - c * cpc;
@@ -257,14 +262,16 @@ __global__ __launch_bounds__(MFMA_MAX_THREADS, 3) void d2d_fir_mfma_kernel(MfmaA
             auto row_word = [&](uint32_t t) -> u32x2 {      // both channels' dword t of this lane's row
                 return *reinterpret_cast<const u32x2*>(prow + 8u * (t + (t >> ls)));
             };
-            auto kpair = [&](const u32x2& w, const v4i& B0, const v4i& B1, auto two_tag) {
+            auto kpair = [&](const u32x2& w, const v4i& B0, const v4i& B1, auto two_tag, auto first_tag) {
                 constexpr bool TWO = decltype(two_tag)::value;
+                constexpr bool FIRST = decltype(first_tag)::value;   // start from the inline constant 0: no zero-fill
+                const v16i zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
                 const uint32_t W0 = w.x, W1 = w.y;
                 const v4i A00 = {(int)(W0 & K1), (int)(W0 & (K1 << 1)), (int)(W0 & (K1 << 2)), (int)(W0 & (K1 << 3))};
-                acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(B0, A00, acc0, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(B0, A00, FIRST ? zero : acc0, 0, 0, 0);
                 if constexpr (TWO) {
                     const v4i A10 = {(int)(W1 & K1), (int)(W1 & (K1 << 1)), (int)(W1 & (K1 << 2)), (int)(W1 & (K1 << 3))};
-                    acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(B0, A10, acc1, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(B0, A10, FIRST ? zero : acc1, 0, 0, 0);
                 }
                 const v4i A01 = {(int)(W0 & (K1 << 4)), (int)(W0 & (K1 << 5)), (int)(W0 & (K1 << 6)), (int)(W0 & (K1 << 7))};
                 acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(B1, A01, acc0, 0, 0, 0);
@@ -280,24 +287,23 @@ __global__ __launch_bounds__(MFMA_MAX_THREADS, 3) void d2d_fir_mfma_kernel(MfmaA
                 // Zero fragments and spare row words exist past the end for the read-ahead.
                 u32x2 wP = row_word(X0), wQ = row_word(X0 + 1);
                 v4i P0 = bp[0], P1 = bp[64], Q0 = bp[2 * 64], Q1 = bp[3 * 64];
-                uint32_t u = 0;
                 const v4i* bq = bp;
-                if (dbg & 32) {          // diagnostic: the chain without its LDS reads
-                    for (; u + 2 <= U; u += 2) {
-                        kpair(wP, P0, P1, two_tag);
-                        wP.x += 0x01010101u; P0.x ^= (int)u;
-                        kpair(wQ, Q0, Q1, two_tag);
-                        wQ.y += 0x01010101u; Q1.y ^= (int)u;
-                    }
-                } else
+                // the first K pair starts both accumulators from the inline constant 0 (U >= 1 always)
+                kpair(wP, P0, P1, two_tag, std::true_type{});
+                if (U < 2) return;
+                wP = row_word(X0 + 2); P0 = bq[4 * 64]; P1 = bq[5 * 64];
+                kpair(wQ, Q0, Q1, two_tag, std::false_type{});
+                wQ = row_word(X0 + 3); Q0 = bq[6 * 64]; Q1 = bq[7 * 64];
+                bq += 4 * 64;
+                uint32_t u = 2;
                 for (; u + 2 <= U; u += 2) {
-                    kpair(wP, P0, P1, two_tag);
+                    kpair(wP, P0, P1, two_tag, std::false_type{});
                     wP = row_word(X0 + u + 2); P0 = bq[4 * 64]; P1 = bq[5 * 64];
-                    kpair(wQ, Q0, Q1, two_tag);
+                    kpair(wQ, Q0, Q1, two_tag, std::false_type{});
                     wQ = row_word(X0 + u + 3); Q0 = bq[6 * 64]; Q1 = bq[7 * 64];
                     bq += 4 * 64;
                 }
-                if (u < U) kpair(wP, P0, P1, two_tag);
+                if (u < U) kpair(wP, P0, P1, two_tag, std::false_type{});
             };
             // Waves that share a SIMD (w and w+4 of a block) take turns in the MFMA phase: while one
             // multiplies, the other runs its VALU/memory phases, so the two pipes overlap instead of
