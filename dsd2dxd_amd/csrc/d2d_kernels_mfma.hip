@@ -164,11 +164,13 @@ __global__ __launch_bounds__(MFMA_MAX_THREADS, 3) void d2d_fir_mfma_kernel(MfmaA
     // the pair sits in between), plus one 8-byte row pad after every second dword when the row stride
     // is two dwords (MB = 1); with wider rows a chunk never straddles a pad.
     auto chunk_dword_off = [](int k) -> uint32_t { return 8u * (uint32_t)k + (ls == 1 ? 8u * (uint32_t)(k >> 1) : 0u); };
+    uint32_t pf_a[MFMA_PF];                                // LDS byte offset of the chunk's first dword
 #pragma unroll
     for (int i = 0; i < MFMA_PF; ++i) {
         const uint32_t ch = lane + 64 * i;
         pf_c[i] = ch / cpc;
         pf_q[i] = ch - pf_c[i] * cpc;
+        pf_a[i] = lds_word_addr(pf_c[i], pf_q[i] * 4);
     }
     u32x4 pf[MFMA_PF];
     uint32_t wt = blockIdx.x * m.nwaves + wave;
@@ -179,9 +181,27 @@ __global__ __launch_bounds__(MFMA_MAX_THREADS, 3) void d2d_fir_mfma_kernel(MfmaA
     const bool pow2B = Bsz >= 16 && (Bsz & (Bsz - 1)) == 0;
     const uint32_t bshift = pow2B ? 31 - __builtin_clz(Bsz) : 0;
     const uint32_t full_bytes = pow2B ? (Lcall >> bshift) << bshift : 0;   // bytes per channel in full blocks
+    // inside that path a staged range shorter than one block crosses at most one block boundary:
+    // address = (uniform start of the first block group) + (0 or one group) + channel offset + offset
+    // inside the block -- five 32-bit VALU per chunk and a scalar base for the load
+    const bool short_span = pow2B && m.span <= Bsz && ((uint64_t)Bsz * Ct * 2u) < (1ull << 32);
+    uint32_t pf_cs[MFMA_PF];                               // (cbase + channel) << bshift
+#pragma unroll
+    for (int i = 0; i < MFMA_PF; ++i) pf_cs[i] = (cbase + pf_c[i]) << bshift;
+    const uint32_t group_bytes = Bsz * Ct;
     auto prefetch = [&](uint32_t w) {
         const int32_t ab = tile_abeg(w);
-        if (pow2B && ab >= 0 && (uint32_t)ab + m.span <= full_bytes) {
+        if (short_span && ab >= 0 && (uint32_t)ab + m.span <= full_bytes) {
+            const uint8_t* gbase = j0.in + ((uint64_t)(((uint32_t)ab >> bshift) * Ct) << bshift);   // uniform
+            const uint32_t r0 = (uint32_t)ab & (Bsz - 1);
+#pragma unroll
+            for (int i = 0; i < MFMA_PF; ++i)
+                if (lane + 64 * i < nch) {
+                    const uint32_t rr = r0 + pf_q[i] * 16;                          // < 2 * Bsz
+                    const uint32_t voff = ((rr >> bshift) ? group_bytes : 0u) + pf_cs[i] + (rr & (Bsz - 1));
+                    pf[i] = *reinterpret_cast<D2D_GLOBAL const u32x4*>(as_global(gbase) + voff);
+                }
+        } else if (pow2B && ab >= 0 && (uint32_t)ab + m.span <= full_bytes) {
 #pragma unroll
             for (int i = 0; i < MFMA_PF; ++i)
                 if (lane + 64 * i < nch) {
@@ -232,7 +252,7 @@ __global__ __launch_bounds__(MFMA_MAX_THREADS, 3) void d2d_fir_mfma_kernel(MfmaA
 #pragma unroll
         for (int i = 0; i < MFMA_PF; ++i)
             if (lane + 64 * i < nch) {
-                uint8_t* dst = wbase + lds_word_addr(pf_c[i], pf_q[i] * 4);
+                uint8_t* dst = wbase + pf_a[i];
                 *reinterpret_cast<uint32_t*>(dst + chunk_dword_off(0)) = pf[i].x;
                 *reinterpret_cast<uint32_t*>(dst + chunk_dword_off(1)) = pf[i].y;
                 *reinterpret_cast<uint32_t*>(dst + chunk_dword_off(2)) = pf[i].z;
