@@ -138,7 +138,9 @@ __device__ __forceinline__ uint32_t quantise_bits(const ResampArgs& a, const Str
     asm("v_max_f64 %0, %1, |%2|" : "=v"(pk) : "v"(pk), "v"(x));      // plain max with the |.| source modifier
     const uint32_t term = a.dsel ? (z & 0xFFFFu) + (z >> 16) + 1u : 2u * (z >> 16) + 1u;
     const double q = x + fma((double)term, a.dmul, a.dadd);
-    const int32_t ri = (int32_t)trunc(q + copysign(0.5, q));
+    int32_t ri;
+    const double t = q + copysign(0.5, q);
+    asm("v_cvt_i32_f64 %0, %1" : "=v"(ri) : "v"(t));            // truncates toward zero and saturates
     return (uint32_t)(min(max(ri, a.qmin_i), a.qmax_i) << a.qsh);
 }
 

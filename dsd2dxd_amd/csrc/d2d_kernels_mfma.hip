@@ -401,7 +401,9 @@ __global__ __launch_bounds__(MFMA_MAX_THREADS, 3) void d2d_fir_mfma_kernel(MfmaA
                         const double dd = fma((double)term, m.dmul, m.dadd);
                         const double q = xv[k] + dd;
                         // round half away from zero; v_cvt_i32_f64 saturates, the clip is an integer med3
-                        const int32_t ri = (int32_t)trunc(q + copysign(0.5, q));
+                        int32_t ri;
+                        const double t = q + copysign(0.5, q);
+                        asm("v_cvt_i32_f64 %0, %1" : "=v"(ri) : "v"(t));
                         iv[k] = min(max(ri, m.qmin_i), m.qmax_i) << m.qsh;
                     }
                     if (iv_out) {          // the caller packs and stores from registers
@@ -422,7 +424,7 @@ __global__ __launch_bounds__(MFMA_MAX_THREADS, 3) void d2d_fir_mfma_kernel(MfmaA
                     }
                 }
             };
-            const bool reg_store = full && two && Ct == 2 && sb == 3 && !a.to_scratch;
+            const bool reg_store = full && two && Ct == 2 && sb == 3 && m.qsh == 0 && !a.to_scratch;
             if (dbg & 2) { if (acc0[0] == 0x12345 && acc1[5] == 77 && acc0[9] + acc1[13] + acc0[15] + acc1[2] == 99) outw[lane] = 1; }
             else if (reg_store) {
                 // Stereo 24-bit, whole tile: no LDS round trip.  Lane (r, h) owns frames 4h .. 4h+3 of
@@ -433,6 +435,7 @@ __global__ __launch_bounds__(MFMA_MAX_THREADS, 3) void d2d_fir_mfma_kernel(MfmaA
                 const uint32_t key0 = rngw[c0 * 4], st0 = rngw[c0 * 4 + 1], lo00 = rngw[c0 * 4 + 2];
                 const uint32_t key1 = rngw[c1 * 4], st1 = rngw[c1 * 4 + 1], lo01 = rngw[c1 * 4 + 2];
                 double pk0 = pkw[c0 * 64 + lane], pk1 = pkw[c1 * 64 + lane];
+                const int32_t qmax_v = m.qmax_i;
                 auto one = [&](const v16i& acc, int k, uint32_t key, uint32_t stp, uint32_t lo0, double& pk) -> uint32_t {
                     double accd;
                     if (m.wide) {
@@ -450,8 +453,13 @@ __global__ __launch_bounds__(MFMA_MAX_THREADS, 3) void d2d_fir_mfma_kernel(MfmaA
                     z ^= z >> 16;
                     const uint32_t term = m.dsel ? (z & 0xFFFFu) + (z >> 16) + 1u : 2u * (z >> 16) + 1u;
                     const double q = x + fma((double)term, m.dmul, m.dadd);
-                    const int32_t ri = (int32_t)trunc(q + copysign(0.5, q));
-                    return (uint32_t)(min(max(ri, m.qmin_i), m.qmax_i) << m.qsh);
+                    // round half away from zero: the conversion itself truncates toward zero (and saturates),
+                    // the clip is one integer med3 (one bound has to sit in a VGPR: one SGPR per VOP3 on gfx9)
+                    int32_t ri, o;
+                    const double t = q + copysign(0.5, q);
+                    asm("v_cvt_i32_f64 %0, %1" : "=v"(ri) : "v"(t));
+                    asm("v_med3_i32 %0, %1, %2, %3" : "=v"(o) : "v"(ri), "s"(m.qmin_i), "v"(qmax_v));
+                    return (uint32_t)o;                                   // (qsh == 0 on this path)
                 };
                 // frames k, k+1 -> 12 bytes: [L0 L1 L2 R0 | R1 R2 L0' L1' | L2' R0' R1' R2']
                 uint32_t w0, w1, w2, w3, w4, w5;
