@@ -194,8 +194,8 @@ int d2d_create(const d2d_params* params, uint32_t n_files, d2d_engine** out) {
     uint32_t mfma_waves = 0;
     const bool mfma_ok = mfma_supported(e->M, e->N) &&
                          mfma_smem_bytes(e->mfma, e->C, e->epi.sample_bytes, &mfma_waves) <= 160 * 1024;
-    // AUTO: the matrix-core kernel whenever a full 4-wave block fits in LDS (many channels x a long
-    // filter do not: then the LUT kernel, which works per channel)
+    // AUTO: the matrix-core kernel whenever a full 4-wave block fits in LDS (it works per channel pair,
+    // so only an extremely long window can fail this; then the LUT kernel)
     e->kernel = e->p.kernel == D2D_KERNEL_AUTO ? (mfma_ok && mfma_waves >= 4 ? D2D_KERNEL_MFMA : D2D_KERNEL_LUT) : e->p.kernel;
     if (e->kernel == D2D_KERNEL_MFMA && !mfma_ok) {
         g_create_error = "MFMA kernel does not support this configuration (decimation or LDS budget)"; delete e; return D2D_ERR_PARAM;

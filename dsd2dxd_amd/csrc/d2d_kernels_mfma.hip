@@ -54,8 +54,8 @@ __device__ unsigned long long d2d_stamp_acc[8];
 struct MfmaArgs {
     FirArgs f;
     double c1, c0;        // x = fma(acc128, c1, -c0) == round(y*c0): c1 = 2^(1-S-7)*c0, c0 = scale | gain | 1
-    // integer-depth epilogue as data: d = fma(term, dmul, dadd), clamp to [qmin, qmax], * qmul
-    double dmul, dadd, qmin, qmax;
+    // integer-depth epilogue as data: d = fma(term, dmul, dadd), clamp to [qmin_i, qmax_i], << qsh
+    double dmul, dadd;
     uint32_t dsel;        // 1: triangular term, 0: rectangular term
     uint32_t qsh;         // 4 for 20-bit samples in a 24-bit container, else 0
     int32_t qmin_i, qmax_i;
@@ -605,8 +605,6 @@ static void mfma_geometry(const FirArgs& a, const MfmaLayout& g, MfmaArgs& m, si
     m.dsel = a.epi.dither == 'T' ? 1u : 0u;
     m.dmul = a.epi.dither == 'T' ? 0x1p-16 : (a.epi.dither == 'R' ? 0x1p-17 : 0.0);
     m.dadd = a.epi.dither == 'T' ? -1.0 : (a.epi.dither == 'R' ? -0.5 : 0.0);
-    const double lim = a.epi.bits == 32 ? 1.0 : (double)(1u << (a.epi.bits - 1));
-    m.qmax = lim - 1.0; m.qmin = -lim;
     m.qsh = a.epi.bits == 20 ? 4u : 0u;
     m.qmin_i = a.epi.bits == 32 ? 0 : -(1 << (a.epi.bits - 1)); m.qmax_i = a.epi.bits == 32 ? 0 : (1 << (a.epi.bits - 1)) - 1;
     m.U = (uint32_t)g.ksteps / 2;

@@ -113,7 +113,9 @@ typedef struct d2d_file_io {
 /* All `n_files` files of the engine advance by one call each, in ONE set of launches on
  * `hip_stream` (a hipStream_t, NULL = the null stream).  Asynchronous: returns once the work is
  * enqueued; io[i].frames_out is known at return.  This is the Rayon par_iter over files
- * (src/main.rs:280-300) turned into a grid dimension. */
+ * (src/main.rs:280-300) turned into a grid dimension.  The engine's state (history, job table,
+ * scratch) lives on the device: successive calls on one engine must be ordered on the device, i.e.
+ * use one stream or order the streams with events. */
 int d2d_translate_batch_device(d2d_engine* e, d2d_file_io* io, uint32_t n_files, void* hip_stream);
 
 /* The same batch with HOST-resident buffers: `dsd` and `pcm` of every d2d_file_io are host pointers
