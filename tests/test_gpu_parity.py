@@ -79,6 +79,27 @@ def test_depths_and_dithers(engine_lib, oracle_mod, bits, dither, out_rate, kern
         assert np.sqrt(np.mean((a - b) ** 2)) <= FLOAT_RMS_TOL
 
 
+@pytest.mark.parametrize("kernel", KERNELS)
+@pytest.mark.parametrize("out_rate,bits,level", [(88200, 24, 70.0), (88200, 16, 12.0), (96000, 24, 70.0), (352800, 20, 200.0), (192000, 16, 6.0)])
+def test_overload_clips_like_the_oracle(engine_lib, oracle_mod, out_rate, bits, level, kernel):
+    """full-scale input and absurd gains: the requantiser saturates (the f64 -> i32 conversion first, then
+    the clip to the sample range) exactly where the oracle does, on both sides"""
+    nbytes = 4096 * 3
+    a = np.concatenate([np.full(4096, 0xFF, np.uint8), np.zeros(4096, np.uint8), synth("sine", 4096, seed=1, amp=0.9)])
+    b = np.concatenate([synth("sine", 4096, seed=2, amp=0.9), np.full(4096, 0xFF, np.uint8), np.zeros(4096, np.uint8)])
+    buf = pack_layout([a[:nbytes], b[:nbytes]], "P", 4096)
+    kw = dict(dsd_rate=1, output_rate=out_rate, channels=2, fmt="P", endianness="L", block_size=4096,
+              filter="E", bit_depth=bits, dither="T", seed=3, level_db=level)
+    g, r, e, o = run_pair(engine_lib, oracle_mod, [buf], kw, kernel)
+    assert np.array_equal(g, r)
+    pcm = decode_pcm(g, bits, 2)
+    lim = 1 << ((20 if bits == 20 else bits) - 1)
+    if bits == 20:
+        pcm = pcm >> 4
+    assert pcm.max() == lim - 1 and pcm.min() == -lim          # both rails are reached
+    assert e.peak_dbfs() == o.peak_dbfs()
+
+
 @pytest.mark.parametrize("bits,dither,out_rate", [(16, "T", 88200), (20, "R", 176400), (32, "F", 352800), (24, "T", 96000), (32, "X", 192000)])
 @pytest.mark.parametrize("channels,fmt", [(5, "P"), (6, "I")])
 def test_multichannel_depths(engine_lib, oracle_mod, bits, dither, out_rate, channels, fmt):
