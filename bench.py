@@ -35,6 +35,8 @@ WORKLOADS = {
     "dsd64_to_352k8_f32_stereo": (1, 352800, 32, "X", 2, 8 / 8 + 4),
     "dsd128_to_88k2_s24_stereo": (2, 88200, 24, "T", 2, 64 / 8 + 3),
     "dsd64_to_96k_s24_stereo": (1, 96000, 24, "T", 2, 29.4 / 8 + 3),
+    "dsd64_to_192k_s24_stereo": (1, 192000, 24, "T", 2, 14.7 / 8 + 3),
+    "dsd128_to_384k_s24_stereo": (2, 384000, 24, "T", 2, 14.7 / 8 + 3),
     "dsd512_to_96k_s24_8ch": (8, 96000, 24, "T", 8, 235.2 / 8 + 3),      # config 5: byte-interleaved MSB-first
 }
 LAYOUTS = {"dsd512_to_96k_s24_8ch": ("I", "M", 1)}                       # default: planar 4096 LSB-first
