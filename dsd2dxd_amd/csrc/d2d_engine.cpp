@@ -570,30 +570,69 @@ int d2d_convert_stream(d2d_engine* e, d2d_read_fn read, void* ru, d2d_write_fn w
     if (!e) return D2D_ERR_PARAM;
     if (!read) return e->fail(D2D_ERR_PARAM, "null read callback");
     if (e->n_files != 1) return e->fail(D2D_ERR_STATE, "d2d_convert_stream needs a single-file engine");
+    HIPCHK(e, hipSetDevice(e->p.device));
     if (chunk == 0) chunk = 1u << 22;
     if (e->B > 1) chunk = std::max<size_t>(e->B, chunk / e->B * e->B);   // whole planar blocks per read
-    std::vector<uint8_t> in(chunk * e->C);
-    std::vector<uint8_t> out;
+    // Pinned staging, two deep: while the GPU uploads, converts and downloads chunk k, the host reads
+    // chunk k+1 and writes chunk k-1 (the callbacks are the file and sink I/O).
+    const size_t fb = d2d_frame_bytes(e);
+    const double ratio = e->fc.resamp ? (double)e->fc.resamp->L / (double)e->fc.resamp->Mdn / (double)e->M : 1.0 / (double)e->M;
+    const size_t in_cap = chunk * e->C, out_cap = ((size_t)((double)chunk * 8.0 * ratio) + 4) * fb;
+    struct Pinned {
+        uint8_t* in[2] = {nullptr, nullptr}; uint8_t* out[2] = {nullptr, nullptr};
+        hipEvent_t ev[2] = {nullptr, nullptr};
+        ~Pinned() { for (int b = 0; b < 2; ++b) { if (in[b]) hipHostFree(in[b]); if (out[b]) hipHostFree(out[b]); if (ev[b]) hipEventDestroy(ev[b]); } }
+    } pin;
+    for (int b = 0; b < 2; ++b) {
+        HIPCHK(e, hipHostMalloc((void**)&pin.in[b], std::max<size_t>(in_cap, 16), hipHostMallocDefault));
+        HIPCHK(e, hipHostMalloc((void**)&pin.out[b], std::max<size_t>(out_cap, 16), hipHostMallocDefault));
+        HIPCHK(e, hipEventCreateWithFlags(&pin.ev[b], hipEventDisableTiming));
+    }
+    int rc = ensure_cap(e, &e->d_in, &e->d_in_cap, std::max<size_t>(in_cap, 16));
+    if (rc) return rc;
+    rc = ensure_cap(e, &e->d_out, &e->d_out_cap, std::max<size_t>(out_cap, 16));
+    if (rc) return rc;
+    hipStream_t s = e->own_stream;
+    size_t pend_bytes[2] = {0, 0};
+    uint64_t pend_in[2] = {0, 0};
+    bool pending[2] = {false, false};
     uint64_t done = 0;
-    for (;;) {
-        if (cancel && *cancel) return e->fail(D2D_ERR_CANCELLED, "Conversion cancelled");
-        long got = read(ru, in.data(), chunk);
-        if (got < 0) return e->fail(D2D_ERR_IO, "read callback failed");
-        if (got == 0) break;
-        const size_t frames = d2d_next_frames(e, 0, (size_t)got);
-        out.resize(std::max<size_t>(frames * d2d_frame_bytes(e), 16));
-        size_t fo = 0;
-        int rc = d2d_translate(e, in.data(), (size_t)got, out.data(), out.size(), &fo);
-        if (rc) return rc;
-        if (write && fo) {
-            if (write(wu, out.data(), fo * d2d_frame_bytes(e)) != 0) return e->fail(D2D_ERR_IO, "write callback failed");
+    auto retire = [&](int b) -> int {                // wait for chunk in buffer b, hand it to the sink
+        if (!pending[b]) return D2D_OK;
+        HIPCHK(e, hipEventSynchronize(pin.ev[b]));
+        pending[b] = false;
+        if (write && pend_bytes[b]) {
+            if (write(wu, pin.out[b], pend_bytes[b]) != 0) return e->fail(D2D_ERR_IO, "write callback failed");
         }
-        done += (uint64_t)got;
+        done += pend_in[b];
         if (progress && total) {
             float pct = (float)(100.0 * (double)done / (double)total);
             if (pct >= 100.0f) pct = 99.99f;   // exactly 100 is reserved for the end (src/main.rs:417-418)
             progress(pu, pct);
         }
+        return D2D_OK;
+    };
+    auto drain = [&]() { hipStreamSynchronize(s); pending[0] = pending[1] = false; };
+    for (int b = 0;; b ^= 1) {
+        if (cancel && *cancel) { drain(); return e->fail(D2D_ERR_CANCELLED, "Conversion cancelled"); }
+        rc = retire(b);                              // buffer b was used two chunks ago
+        if (rc) { drain(); return rc; }
+        long got = read(ru, pin.in[b], chunk);
+        if (got < 0) { drain(); return e->fail(D2D_ERR_IO, "read callback failed"); }
+        if (got == 0) { rc = retire(b ^ 1); if (rc) { drain(); return rc; } break; }
+        const size_t L = (size_t)got;
+        HIPCHK(e, hipMemcpyAsync(e->d_in, pin.in[b], L * e->C, hipMemcpyHostToDevice, s));
+        d2d_file_io io{};
+        io.dsd = e->d_in; io.bytes_per_channel = L; io.pcm = e->d_out; io.pcm_capacity_bytes = e->d_out_cap;
+        rc = d2d_translate_batch_device(e, &io, 1, s);
+        if (rc) { drain(); return rc; }
+        pend_bytes[b] = io.frames_out * fb;
+        pend_in[b] = (uint64_t)got;
+        if (pend_bytes[b]) HIPCHK(e, hipMemcpyAsync(pin.out[b], e->d_out, pend_bytes[b], hipMemcpyDeviceToHost, s));
+        HIPCHK(e, hipEventRecord(pin.ev[b], s));
+        pending[b] = true;
+        rc = retire(b ^ 1);                          // the previous chunk: its write overlaps this chunk's GPU work
+        if (rc) { drain(); return rc; }
     }
     if (progress) progress(pu, 100.0f);
     return D2D_OK;
