@@ -16,12 +16,48 @@ def declared_symbols():
 
 
 def test_exports_match_header(engine_lib):
+    engine_lib.lib()                                            # loads torch's HIP runtime first (see _capi.lib)
     L = C.CDLL(engine_lib.library_path())
     names = declared_symbols()
     assert len(names) >= 19
     for n in names:
         assert hasattr(L, n), f"{n} declared in the header but not exported"
     assert sorted(engine_lib._capi.EXPORTS) == names
+
+
+def test_host_driver_abi_exports_and_errors(engine_lib, tmp_path):
+    """include/rdsd2pcm_c.h: every d2dh_* symbol is exported; constructors validate like the crate's do
+    (same message texts as the CLI, src/main.rs:176-190) and need no GPU to be created"""
+    engine_lib.lib()                                            # loads torch's HIP runtime first (see _capi.lib)
+    L = C.CDLL(engine_lib.library_path())
+    text = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "rdsd2pcm_c.h")).read(), flags=re.S)
+    names = sorted(set(re.findall(r"\b(d2dh_[a-z0-9_]+)\s*\(", text)) - {"d2dh_progress_fn", "d2dh_path_fn"})
+    assert len(names) == 14
+    for n in names:
+        assert hasattr(L, n), n
+    L.d2dh_last_error.restype = C.c_char_p
+    L.d2dh_file_name.restype = C.c_char_p
+    h = C.c_void_p()
+    args = lambda **k: [C.c_uint32(k.get("bits", 24)), C.c_uint32(ord(k.get("out", "W"))), C.c_double(0.0), C.c_uint32(k.get("rate", 88200)), None,
+                        C.c_uint32(ord(k.get("dither", "T"))), C.c_uint32(ord(k.get("fmt", "P"))), C.c_uint32(ord("L")), C.c_uint32(1), C.c_uint32(4096),
+                        C.c_uint32(2), C.c_uint32(ord("E")), C.c_int(0), b".", k.get("path", b"x.dsd"), C.byref(h)]
+    assert L.d2dh_new(*args(dither="Q")) < 0 and L.d2dh_last_error() == b"Invalid dither type; must be T, R, F, or X"
+    assert L.d2dh_new(*args(fmt="Z")) < 0 and L.d2dh_last_error() == b"Invalid format; must be I (interleaved) or P (planar)"
+    assert L.d2dh_new(*args(rate=44100)) < 0 and b"Invalid output rate" in L.d2dh_last_error()
+    assert L.d2dh_new(*args()) == 0 and h.value
+    assert L.d2dh_file_name(h) == b"x.dsd"
+    L.d2dh_free(h)
+    assert L.d2dh_is_container(b"a/b.DSF") == 1 and L.d2dh_is_container(b"a/b.dsd") == 0
+    (tmp_path / "sub").mkdir()
+    for n in ("a.dsf", "b.txt", "sub/c.dff", "sub/d.dsd"):
+        (tmp_path / n).write_bytes(b"")
+    found = []
+    CB = C.CFUNCTYPE(None, C.c_void_p, C.c_char_p)
+    cb = CB(lambda u, p: found.append(os.path.relpath(p.decode(), str(tmp_path))))
+    paths = (C.c_char_p * 1)(str(tmp_path).encode())
+    assert L.d2dh_find_dsd_files(paths, 1, 1, cb, None) == 0 and sorted(found) == ["a.dsf", "sub/c.dff", "sub/d.dsd"]
+    found.clear()
+    assert L.d2dh_find_dsd_files(paths, 1, 0, cb, None) == 0 and found == []      # directories need -R (README.md:97-101)
 
 
 def test_params_struct_layout(engine_lib):

@@ -379,3 +379,46 @@ def test_tags_and_artwork_travel_with_the_audio(cli, oracle_mod, tmp_path):
     assert b"damaged" in p.stderr
     ck = _chunks(str(src_dir / "bad.wav"), False)
     assert b"id3 " not in ck and np.array_equal(np.frombuffer(ck[b"data"], dtype=np.uint8), r[:rf * 6])
+
+
+@pytest.mark.gpu
+def test_host_driver_c_abi_converts_like_the_cli(cli, engine_lib, oracle_mod, tmp_path):
+    """include/rdsd2pcm_c.h (what the rdsd2pcm shim crate binds): from_container + do_conversion with a
+    progress callback, check_level, cancel"""
+    import ctypes as C
+    engine_lib.lib()                                            # loads torch's HIP runtime first (see _capi.lib)
+    L = C.CDLL(engine_lib.library_path())
+    L.d2dh_last_error.restype = C.c_char_p
+    L.d2dh_output_path.restype = C.c_char_p
+    n = 4096 * 5
+    chans = [synth("sine", n, seed=31), synth("pink", n, seed=32, amp=0.098)]
+    src = str(tmp_path / "t.dsf")
+    write_dsf(src, chans)
+    h = C.c_void_p()
+    rc = L.d2dh_from_container(24, ord("W"), C.c_double(0.0), 88200, None, ord("T"), ord("E"), 1, b".", src.encode(), C.byref(h))
+    assert rc == 0, L.d2dh_last_error()
+    seen = []
+    PCB = C.CFUNCTYPE(None, C.c_void_p, C.c_float)
+    pcb = PCB(lambda u, p: seen.append(p))
+    assert L.d2dh_do_conversion(h, None, pcb, None) == 0, L.d2dh_last_error()
+    assert seen and seen[-1] == 100.0 and all(a <= b for a, b in zip(seen, seen[1:]))
+    out = L.d2dh_output_path(h).decode()
+    assert out.endswith("t_88_2K.wav")
+    L.d2dh_free(h)
+    o = oracle_mod.Oracle(dsd_rate=1, output_rate=88200, channels=2, fmt="P", endianness="L", block_size=4096,
+                          bit_depth=24, dither="T", seed=0)
+    r, rf = o.translate(pack_layout(chans, "P", 4096))
+    fmt, pay = _wav_payload(out)
+    assert np.array_equal(pay, r[:rf * 6])
+    # the level check (dsd_levels): same number as the CLI prints
+    assert L.d2dh_new_level_check(88200, src.encode(), ord("P"), ord("L"), 2, 4096, 1, C.byref(h)) == 0
+    db = C.c_float()
+    assert L.d2dh_check_level(h, None, None, None, C.byref(db)) == 0
+    L.d2dh_free(h)
+    line = subprocess.check_output([cli, "levels", "-r", "88200", src]).decode().splitlines()[0]
+    assert line == "t.dsf: %.4f dBFS" % db.value
+    # a raised cancel flag stops the run with the reference's message
+    assert L.d2dh_from_container(24, ord("W"), C.c_double(0.0), 88200, None, ord("T"), ord("E"), 0, b".", src.encode(), C.byref(h)) == 0
+    flag = C.c_int(1)
+    assert L.d2dh_do_conversion(h, C.byref(flag), None, None) == -30 and L.d2dh_last_error() == b"Conversion cancelled"
+    L.d2dh_free(h)
