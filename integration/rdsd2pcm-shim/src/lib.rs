@@ -34,6 +34,19 @@ impl Endianness { fn code(self) -> u32 { match self { Self::LsbFirst => b'L', Se
 impl FilterType { fn code(self) -> u32 { match self { Self::Equiripple => b'E', Self::XLD => b'X', Self::Dsd2Pcm => b'D', Self::Chebyshev => b'C' } as u32 } }
 impl OutputType { fn code(self) -> u32 { match self { Self::Stdout => b'S', Self::Aiff => b'A', Self::Aifc => b'C', Self::Wav => b'W', Self::Flac => b'F' } as u32 } }
 
+/// The DSD rate as a multiple of 2.8224 MHz.  The call sites write `cli.input_rate.try_into()?`
+/// (src/main.rs:334,385; src/bin/dsd_levels/main.rs:221,280) inside functions that return
+/// `Result<_, Box<dyn Error>>` and `Result<_, String>`: the parameter type is concrete and its
+/// `TryFrom<u32>::Error` is `String`, which converts into both.
+#[derive(Clone, Copy, Debug, PartialEq, Eq)]
+pub struct DsdRate(u32);
+impl TryFrom<u32> for DsdRate {
+    type Error = String;
+    fn try_from(v: u32) -> Result<Self, String> {
+        match v { 1 | 2 | 4 | 8 => Ok(Self(v)), _ => Err("Unsupported DSD input rate; must be 1, 2, 4 or 8".to_string()) }
+    }
+}
+
 /// `DsdFileFormat::from(&path).is_container()` (src/main.rs:361)
 #[derive(Clone, Copy, Debug, PartialEq, Eq)]
 pub enum DsdFileFormat { Dsf, Dff, Raw }
@@ -116,13 +129,12 @@ unsafe extern "C" fn progress_cb(user: *mut c_void, percent: f32) {
 }
 
 impl Rdsd2Pcm {
-    /// src/main.rs:325-342 (argument order kept); `dsd_rate` is anything that converts into the 1/2/4/8 multiple
+    /// src/main.rs:325-342 (argument order kept)
     #[allow(clippy::too_many_arguments)]
-    pub fn new<R>(bit_depth: usize, output: OutputType, level_db: f64, output_rate: u32, out_dir: Option<PathBuf>, dither: DitherType,
-                  fmt: FmtType, endian: Endianness, dsd_rate: R, block_size: u32, channels: usize, filter: FilterType, append_rate: bool,
-                  base_dir: PathBuf, in_path: Option<PathBuf>) -> Result<Self, String>
-    where R: TryInto<u32>, R::Error: std::fmt::Display {
-        let rate: u32 = dsd_rate.try_into().map_err(|e| e.to_string())?;
+    pub fn new(bit_depth: usize, output: OutputType, level_db: f64, output_rate: u32, out_dir: Option<PathBuf>, dither: DitherType,
+               fmt: FmtType, endian: Endianness, dsd_rate: DsdRate, block_size: u32, channels: usize, filter: FilterType, append_rate: bool,
+               base_dir: PathBuf, in_path: Option<PathBuf>) -> Result<Self, String> {
+        let rate: u32 = dsd_rate.0;
         let (od, ip, bd) = (opt_cpath(&out_dir), opt_cpath(&in_path), cpath(&base_dir));
         let mut h = std::ptr::null_mut();
         let rc = unsafe {
@@ -149,10 +161,10 @@ impl Rdsd2Pcm {
 
     /// src/bin/dsd_levels/main.rs:214-223
     pub fn new_level_check(output_rate: u32, path: PathBuf, fmt: FmtType, endian: Endianness, channels: usize, block_size: u32,
-                           input_rate: u32) -> Result<Self, String> {
+                           input_rate: DsdRate) -> Result<Self, String> {
         let p = cpath(&path);
         let mut h = std::ptr::null_mut();
-        let rc = unsafe { ffi::d2dh_new_level_check(output_rate, p.as_ptr(), fmt.code(), endian.code(), channels as u32, block_size, input_rate, &mut h) };
+        let rc = unsafe { ffi::d2dh_new_level_check(output_rate, p.as_ptr(), fmt.code(), endian.code(), channels as u32, block_size, input_rate.0, &mut h) };
         if rc != 0 { return Err(last_error()); }
         Ok(Self { h })
     }
