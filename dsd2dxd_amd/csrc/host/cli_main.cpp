@@ -136,7 +136,7 @@ int main(int argc, char** argv) {
             std::optional<std::string> od; if (have_out_dir) od = out_dir;
             std::optional<std::string> ip; if (!is_stdin) ip = path;
             if (levels) {
-                Rdsd2Pcm lib = Rdsd2Pcm::new_level_check(rate, path, ft, en, channels, block, inrate);
+                Rdsd2Pcm lib = Rdsd2Pcm::new_level_check(rate, ip, ft, en, channels, block, inrate);
                 lib.set_device(device);
                 float db = lib.check_level(CANCEL_FLAG);
                 printf("%s: %.4f dBFS\n", lib.file_name().c_str(), db);

@@ -122,11 +122,11 @@ Rdsd2Pcm Rdsd2Pcm::from_container(size_t bit_depth, OutputType output, double le
     return r;
 }
 
-Rdsd2Pcm Rdsd2Pcm::new_level_check(uint32_t output_rate, std::string path, FmtType fmt, Endianness endian,
+Rdsd2Pcm Rdsd2Pcm::new_level_check(uint32_t output_rate, std::optional<std::string> path, FmtType fmt, Endianness endian,
                                    size_t channels, uint32_t block_size, uint32_t input_rate) {
-    Rdsd2Pcm r = DsdFileFormat::from(path).is_container()
+    Rdsd2Pcm r = (path && DsdFileFormat::from(*path).is_container())
                      ? from_container(32, OutputType::Stdout, 0.0, output_rate, std::nullopt, DitherType::None,
-                                      FilterType::Equiripple, false, ".", path)
+                                      FilterType::Equiripple, false, ".", *path)
                      : create(32, OutputType::Stdout, 0.0, output_rate, std::nullopt, DitherType::None, fmt, endian,
                               input_rate, block_size, channels, FilterType::Equiripple, false, ".", path);
     r.p_->level_only = true;

@@ -87,10 +87,10 @@ int d2dh_from_container(uint32_t bit_depth, uint32_t output, double level_db, ui
 
 int d2dh_new_level_check(uint32_t output_rate, const char* path, uint32_t fmt, uint32_t endian, uint32_t channels,
                          uint32_t block_size, uint32_t input_rate, d2dh_conv** out) {
-    if (!out || !path) { g_err = "null argument"; return D2D_ERR_PARAM; }
+    if (!out) { g_err = "null argument"; return D2D_ERR_PARAM; }
     *out = nullptr;
     return guarded([&] {
-        *out = new d2dh_conv(Rdsd2Pcm::new_level_check(output_rate, path, fmt_of(fmt), endian_of(endian), channels, block_size, input_rate));
+        *out = new d2dh_conv(Rdsd2Pcm::new_level_check(output_rate, opt(path), fmt_of(fmt), endian_of(endian), channels, block_size, input_rate));
     });
 }
 

@@ -49,7 +49,8 @@ class Rdsd2Pcm {
     static Rdsd2Pcm from_container(size_t bit_depth, OutputType output, double level_db, uint32_t output_rate,
                                    std::optional<std::string> out_dir, DitherType dither, FilterType filter,
                                    bool append_rate, std::string base_dir, std::string path);
-    static Rdsd2Pcm new_level_check(uint32_t output_rate, std::string path, FmtType fmt, Endianness endian,
+    // path: nullopt = stdin (src/bin/dsd_levels/main.rs:214-223 passes Some(path), :273-281 None)
+    static Rdsd2Pcm new_level_check(uint32_t output_rate, std::optional<std::string> path, FmtType fmt, Endianness endian,
                                     size_t channels, uint32_t block_size, uint32_t input_rate);
     Rdsd2Pcm(Rdsd2Pcm&&) noexcept;
     Rdsd2Pcm& operator=(Rdsd2Pcm&&) noexcept;

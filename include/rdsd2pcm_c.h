@@ -39,7 +39,7 @@ int d2dh_new(uint32_t bit_depth, uint32_t output, double level_db, uint32_t outp
              uint32_t filter, int append_rate, const char* base_dir, const char* in_path /* NULL = stdin */, d2dh_conv** out);
 int d2dh_from_container(uint32_t bit_depth, uint32_t output, double level_db, uint32_t output_rate, const char* out_dir,
                         uint32_t dither, uint32_t filter, int append_rate, const char* base_dir, const char* path, d2dh_conv** out);
-int d2dh_new_level_check(uint32_t output_rate, const char* path, uint32_t fmt, uint32_t endian, uint32_t channels,
+int d2dh_new_level_check(uint32_t output_rate, const char* path /* NULL = stdin */, uint32_t fmt, uint32_t endian, uint32_t channels,
                          uint32_t block_size, uint32_t input_rate, d2dh_conv** out);
 void d2dh_free(d2dh_conv* c);
 

@@ -160,11 +160,11 @@ impl Rdsd2Pcm {
     }
 
     /// src/bin/dsd_levels/main.rs:214-223
-    pub fn new_level_check(output_rate: u32, path: PathBuf, fmt: FmtType, endian: Endianness, channels: usize, block_size: u32,
+    pub fn new_level_check(output_rate: u32, path: Option<PathBuf>, fmt: FmtType, endian: Endianness, channels: usize, block_size: u32,
                            input_rate: DsdRate) -> Result<Self, String> {
-        let p = cpath(&path);
+        let p = opt_cpath(&path); // None = stdin (src/bin/dsd_levels/main.rs:273-281)
         let mut h = std::ptr::null_mut();
-        let rc = unsafe { ffi::d2dh_new_level_check(output_rate, p.as_ptr(), fmt.code(), endian.code(), channels as u32, block_size, input_rate.0, &mut h) };
+        let rc = unsafe { ffi::d2dh_new_level_check(output_rate, ptr(&p), fmt.code(), endian.code(), channels as u32, block_size, input_rate.0, &mut h) };
         if rc != 0 { return Err(last_error()); }
         Ok(Self { h })
     }
