@@ -9,6 +9,7 @@
 // No CPU fallback exists: without a HIP device d2d_create fails with D2D_ERR_DEVICE.
 #include <hip/hip_runtime.h>
 #include <math.h>
+#include <stddef.h>
 #include <string.h>
 
 #include <algorithm>
@@ -42,7 +43,9 @@ struct d2d_engine {
     uint32_t n_files = 1;
     FilterChoice fc;
     int M = 0, Mb = 0, N = 0, Wb = 0, S = 0;
-    uint32_t B = 1, keep = 0, C = 0, nstreams = 0;
+    uint32_t B = 1, keep = 0, nstreams = 0;
+    uint32_t Cin = 0;          // channels of the input layout
+    uint32_t C = 0, c0 = 0;    // channels converted (streams per file, width of the output frame) and the first of them
     uint32_t kernel = D2D_KERNEL_LUT;
     LutLayout lut{};
     MfmaLayout mfma{};
@@ -120,6 +123,7 @@ static int validate(const d2d_params& p, std::string& err) {
     if (p.fmt == D2D_FMT_PLANAR && p.block_size == 0) { err = "Invalid block size"; return D2D_ERR_PARAM; }
     if (p.kernel > D2D_KERNEL_MFMA) { err = "Invalid kernel selector"; return D2D_ERR_PARAM; }
     if (!isfinite(p.level_db)) { err = "Invalid level"; return D2D_ERR_PARAM; }
+    if (p.channel_first >= p.channels || p.channel_count > p.channels - p.channel_first) { err = "Invalid channel subset"; return D2D_ERR_PARAM; }
     return D2D_OK;
 }
 
@@ -164,20 +168,25 @@ const char* d2d_create_error(void) { return g_create_error.c_str(); }
 int d2d_create(const d2d_params* params, uint32_t n_files, d2d_engine** out) {
     if (out) *out = nullptr;
     if (!params || !out) { g_create_error = "null argument"; return D2D_ERR_PARAM; }
-    if (params->struct_size != sizeof(d2d_params)) { g_create_error = "d2d_params.struct_size mismatch"; return D2D_ERR_PARAM; }
+    constexpr size_t legacy_size = offsetof(d2d_params, channel_first);           // ABI 1: no channel subset
+    if (params->struct_size != sizeof(d2d_params) && params->struct_size != legacy_size) { g_create_error = "d2d_params.struct_size mismatch"; return D2D_ERR_PARAM; }
     if (n_files < 1 || n_files > 65535) { g_create_error = "Invalid file count"; return D2D_ERR_PARAM; }
     d2d_engine* e = new d2d_engine();
-    e->p = *params;
+    memset(&e->p, 0, sizeof(e->p));
+    memcpy(&e->p, params, params->struct_size);
+    e->p.struct_size = sizeof(d2d_params);
     e->n_files = n_files;
     int rc = validate(e->p, g_create_error);
     if (rc == D2D_OK) rc = choose_filters(e->p, e->fc, g_create_error);
     if (rc != D2D_OK) { delete e; return rc; }
     const d2d_filter_def& f = *e->fc.fir;
     e->M = f.M; e->Mb = f.M / 8; e->N = f.ntaps; e->Wb = f.ntaps / 8; e->S = f.S;
-    e->C = e->p.channels;
+    e->Cin = e->p.channels;
+    e->C = e->p.channel_count ? e->p.channel_count : e->p.channels - e->p.channel_first;
+    e->c0 = e->p.channel_first;
     e->B = e->p.fmt == D2D_FMT_INTERLEAVED ? 1u : e->p.block_size;   // README.md:9
     if (e->B == 1) {   // byte interleaved: mono is already planar; otherwise a planar copy is made per call
-        e->deinterleave = e->C > 1;
+        e->deinterleave = e->Cin > 1;
         e->B = 4096;
     }
     e->nstreams = n_files * e->C;
@@ -325,7 +334,7 @@ int d2d_translate_batch_device(d2d_engine* e, d2d_file_io* io, uint32_t n_files,
     uint32_t max_L = 0;
     for (uint32_t f = 0; f < n_files; ++f) max_L = std::max<uint32_t>(max_L, (uint32_t)io[f].bytes_per_channel);
     if (e->deinterleave) {
-        const size_t need = (((size_t)max_L * C) + 4095) & ~(size_t)4095;
+        const size_t need = (((size_t)max_L * e->Cin) + 4095) & ~(size_t)4095;
         if (need > e->planar_stride) {
             HIPCHK(e, hipStreamSynchronize(s));
             if (e->d_planar) HIPCHK(e, hipFree(e->d_planar));
@@ -356,11 +365,12 @@ int d2d_translate_batch_device(d2d_engine* e, d2d_file_io* io, uint32_t n_files,
             j.e0 = (int64_t)((st.nfir + 1) * (uint64_t)e->Mb) - (int64_t)st.pos;
             j.n0 = st.nfir;
             j.nout = (uint32_t)(nfir1[f] - st.nfir);
-            j.ch = c;
+            j.ch = e->c0 + c;
+            j.och = c;
             j.m0 = st.nres;
             j.nres = e->fc.resamp ? (uint32_t)(nres1[f] - st.nres) : 0;
             const uint64_t i0 = e->fc.resamp ? st.nres : st.nfir;     // index the dither counter runs on
-            const uint64_t k = rng_key64(e->p.seed, c);
+            const uint64_t k = rng_key64(e->p.seed, e->c0 + c);
             j.rng_kstep = (uint32_t)k | 1u;
             j.rng_key = (uint32_t)(k >> 32) + (uint32_t)(i0 >> 32) * j.rng_kstep;
             j.rng_lo0 = (uint32_t)i0;
@@ -370,7 +380,7 @@ int d2d_translate_batch_device(d2d_engine* e, d2d_file_io* io, uint32_t n_files,
     HIPCHK(e, hipEventRecord(e->job_ev[slot], s));
     e->job_ev_used[slot] = true;
 
-    if (e->deinterleave) HIPCHK(e, launch_deinterleave(e->d_jobs, n_files, C, max_L, s));
+    if (e->deinterleave) HIPCHK(e, launch_deinterleave(e->d_jobs, n_files, e->Cin, C, max_L, s));
 
     FirArgs a{};
     a.jobs = e->d_jobs;
@@ -381,6 +391,7 @@ int d2d_translate_batch_device(d2d_engine* e, d2d_file_io* io, uint32_t n_files,
     a.to_scratch = e->fc.resamp ? 1u : 0u;
     a.ksteps = (uint32_t)e->mfma.ksteps;
     a.scale_bits = e->S;
+    a.in_channels = e->Cin;
     a.epi = e->epi;
     std::pair<hipEvent_t, hipEvent_t>* pe = nullptr;
     if (e->profiling && max_nx) {
@@ -411,7 +422,7 @@ int d2d_translate_batch_device(d2d_engine* e, d2d_file_io* io, uint32_t n_files,
         HIPCHK(e, launch_resample(r, max_frames, e->nstreams, s));
         HIPCHK(e, launch_xhist(e->d_jobs, e->nstreams, r.P, s));
     }
-    HIPCHK(e, launch_history(e->d_jobs, e->nstreams, C, e->B, e->keep, s));
+    HIPCHK(e, launch_history(e->d_jobs, e->nstreams, e->Cin, e->B, e->keep, s));
     e->hist_cur = cur ^ 1;
     for (uint32_t f = 0; f < n_files; ++f) {
         FileState& st = e->files[f];
@@ -445,7 +456,7 @@ int d2d_translate(d2d_engine* e, const uint8_t* dsd, size_t L, void* pcm, size_t
     const size_t out_bytes = frames * d2d_frame_bytes(e);
     if (out_bytes > cap) return e->fail(D2D_ERR_CAPACITY, "pcm buffer too small");
     if (out_bytes && !pcm) return e->fail(D2D_ERR_PARAM, "null pcm pointer");
-    const size_t in_bytes = L * e->C;
+    const size_t in_bytes = L * e->Cin;
     int rc = ensure_cap(e, &e->d_in, &e->d_in_cap, std::max<size_t>(in_bytes, 16));
     if (rc) return rc;
     rc = ensure_cap(e, &e->d_out, &e->d_out_cap, std::max<size_t>(out_bytes, 16));
@@ -466,7 +477,7 @@ int d2d_translate_batch_host(d2d_engine* e, d2d_file_io* io, uint32_t n_files, s
     if (!e) return D2D_ERR_PARAM;
     if (!io || n_files != e->n_files) return e->fail(D2D_ERR_PARAM, "file count does not match the engine");
     HIPCHK(e, hipSetDevice(e->p.device));
-    const uint32_t C = e->C;
+    const uint32_t C = e->Cin;                       // the uploads move whole input frames
     const size_t fb = d2d_frame_bytes(e);
     if (slice == 0) slice = 4u << 20;
     if (e->B > 1) slice = std::max<size_t>(e->B, slice / e->B * e->B);       // whole planar blocks per slice
@@ -577,7 +588,7 @@ int d2d_convert_stream(d2d_engine* e, d2d_read_fn read, void* ru, d2d_write_fn w
     // chunk k+1 and writes chunk k-1 (the callbacks are the file and sink I/O).
     const size_t fb = d2d_frame_bytes(e);
     const double ratio = e->fc.resamp ? (double)e->fc.resamp->L / (double)e->fc.resamp->Mdn / (double)e->M : 1.0 / (double)e->M;
-    const size_t in_cap = chunk * e->C, out_cap = ((size_t)((double)chunk * 8.0 * ratio) + 4) * fb;
+    const size_t in_cap = chunk * e->Cin, out_cap = ((size_t)((double)chunk * 8.0 * ratio) + 4) * fb;
     struct Pinned {
         uint8_t* in[2] = {nullptr, nullptr}; uint8_t* out[2] = {nullptr, nullptr};
         hipEvent_t ev[2] = {nullptr, nullptr};
@@ -621,7 +632,7 @@ int d2d_convert_stream(d2d_engine* e, d2d_read_fn read, void* ru, d2d_write_fn w
         if (got < 0) { drain(); return e->fail(D2D_ERR_IO, "read callback failed"); }
         if (got == 0) { rc = retire(b ^ 1); if (rc) { drain(); return rc; } break; }
         const size_t L = (size_t)got;
-        HIPCHK(e, hipMemcpyAsync(e->d_in, pin.in[b], L * e->C, hipMemcpyHostToDevice, s));
+        HIPCHK(e, hipMemcpyAsync(e->d_in, pin.in[b], L * e->Cin, hipMemcpyHostToDevice, s));
         d2d_file_io io{};
         io.dsd = e->d_in; io.bytes_per_channel = L; io.pcm = e->d_out; io.pcm_capacity_bytes = e->d_out_cap;
         rc = d2d_translate_batch_device(e, &io, 1, s);

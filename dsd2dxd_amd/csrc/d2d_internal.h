@@ -25,13 +25,14 @@ struct StreamJob {
     int64_t        e0;      // one past the newest byte of output n0's window (call-relative)
     uint64_t       n0;      // absolute index of the first FIR output of this call
     uint32_t       nout;    // FIR outputs this call
-    uint32_t       ch;      // channel index inside the file
+    uint32_t       ch;      // channel index inside the FILE (input layout, dither key)
     // stage B (48k family)
     uint64_t       m0;      // absolute index of the first resampler output of this call
     uint32_t       nres;    // resampler outputs this call
     uint32_t       rng_key;   // dither key at this call's first output index i0: k32 + hi32(i0)*kstep
     uint32_t       rng_kstep; // added once more where lo32(index) wraps inside this call
     uint32_t       rng_lo0;   // lo32(i0); the index is n (44.1k family) or m (48k family)
+    uint32_t       och;       // channel index inside the OUTPUT frame (differs from ch when the engine converts a channel subset)
 };
 
 // How to turn an f64 sample into output bytes (a5-a7 of SURVEY 8a).
@@ -57,7 +58,7 @@ struct FirArgs {
     uint32_t to_scratch;       // 1: write the FIR outputs as integers y*2^S to job.xs (stage A of the 48k cascade)
     uint32_t ksteps;           // MFMA: K steps
     int32_t  scale_bits;       // S of the tap table (h = q * 2^-S)
-    uint32_t reserved;
+    uint32_t in_channels;      // channels of the input layout (epi.channels = channels of the output frame; fewer for a channel subset)
     Epilogue epi;
 };
 

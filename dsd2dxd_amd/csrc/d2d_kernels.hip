@@ -55,7 +55,7 @@ __global__ __launch_bounds__(LUT_THREADS) void d2d_fir_lut_kernel(FirArgs a) {
         const int64_t abeg = tile_first & ~(int64_t)15;
         const uint32_t d = (uint32_t)(tile_first - abeg);
         __syncthreads();
-        stage_window(win, job, a.epi.channels, a.B, a.keep, abeg, span, tid, LUT_THREADS);
+        stage_window(win, job, a.in_channels, a.B, a.keep, abeg, span, tid, LUT_THREADS);
         __syncthreads();
 
         const uint8_t* lp = win + LS * tid + 8 * (d >> 3);
@@ -88,7 +88,7 @@ __global__ __launch_bounds__(LUT_THREADS) void d2d_fir_lut_kernel(FirArgs a) {
                 if (a.to_scratch) {
                     job.xs[nl] = (int32_t)ldexp(acc[r], a.scale_bits);      // exact integer, |.| < 2^31
                 } else {
-                    uint8_t* dst = reinterpret_cast<uint8_t*>(job.out) + (size_t)nl * frame_bytes + job.ch * sample_bytes;
+                    uint8_t* dst = reinterpret_cast<uint8_t*>(job.out) + (size_t)nl * frame_bytes + job.och * sample_bytes;
                     pk = fmax(pk, emit_sample(a.epi, job, acc[r], job.n0 + nl, dst));
                 }
             }
@@ -262,7 +262,7 @@ __global__ __launch_bounds__(RS_THREADS, 6) void d2d_resample_kernel(ResampArgs 
         __syncthreads();
         const uint32_t sample_bytes = a.epi.sample_bytes;
         const uint32_t frame_bytes = sample_bytes * a.epi.channels;
-        uint8_t* pcm = reinterpret_cast<uint8_t*>(job.out) + job.ch * sample_bytes;
+        uint8_t* pcm = reinterpret_cast<uint8_t*>(job.out) + job.och * sample_bytes;
         const int32_t o_tile = o_c0 + (int32_t)(tile * 64 * L);
         for (uint32_t i = tid; i < 64 * L; i += RS_THREADS) {
             const int32_t o = o_tile + (int32_t)i;
@@ -291,9 +291,10 @@ constexpr uint32_t DI_TILE = 1024;
 constexpr uint32_t DI_BLOCK = 4096;
 __host__ __device__ constexpr uint32_t di_lds_bytes(uint32_t C) { return DI_TILE * C + (DI_TILE / 16) * 4; }
 
-__global__ __launch_bounds__(256) void d2d_deinterleave_kernel(const StreamJob* jobs, uint32_t C) {
+// (C = channels of the file; spf = streams per file in the job table, fewer for a channel subset)
+__global__ __launch_bounds__(256) void d2d_deinterleave_kernel(const StreamJob* jobs, uint32_t C, uint32_t spf) {
     extern __shared__ __align__(16) unsigned char smem[];
-    const StreamJob job = jobs[blockIdx.y * C];
+    const StreamJob job = jobs[blockIdx.y * spf];
     const uint32_t L = (uint32_t)job.L;
     const D2D_GLOBAL uint8_t* src = as_global(job.in_raw);
     D2D_GLOBAL uint8_t* dst = as_global(const_cast<uint8_t*>(job.in));
@@ -436,7 +437,7 @@ hipError_t launch_resample(const ResampArgs& a_in, uint32_t max_out, uint32_t ns
     }
 }
 
-hipError_t launch_deinterleave(const StreamJob* jobs, uint32_t nfiles, uint32_t C, uint32_t max_L, hipStream_t s) {
+hipError_t launch_deinterleave(const StreamJob* jobs, uint32_t nfiles, uint32_t C, uint32_t spf, uint32_t max_L, hipStream_t s) {
     if (nfiles == 0 || max_L == 0) return hipSuccess;
     uint32_t gx = (max_L + DI_TILE - 1) / DI_TILE;
     const uint32_t cap = (8192 + nfiles - 1) / nfiles;
@@ -444,7 +445,7 @@ hipError_t launch_deinterleave(const StreamJob* jobs, uint32_t nfiles, uint32_t 
     static KernelPrep prep;                                            // 64 channels need 66 KB of LDS
     hipError_t e = prep.max_dynamic_lds(reinterpret_cast<const void*>(&d2d_deinterleave_kernel), 80 * 1024);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(d2d_deinterleave_kernel, dim3(gx, nfiles), dim3(256), (size_t)di_lds_bytes(C), s, jobs, C);
+    hipLaunchKernelGGL(d2d_deinterleave_kernel, dim3(gx, nfiles), dim3(256), (size_t)di_lds_bytes(C), s, jobs, C, spf);
     return hipGetLastError();
 }
 

@@ -81,7 +81,7 @@ __device__ __forceinline__ void wave_sync() {
 }
 
 // 16 bytes of channel c's stream starting at call-relative byte j (j % 16 == 0).
-// (jobs[c] is the job of channel cbase + c of a file with C channels)
+// (jobs[c] is the job of file channel cbase + c of a file with C channels)
 __device__ __forceinline__ u32x4 load_chunk(const StreamJob* jobs, const StreamJob& j0, uint32_t c, uint32_t cbase, int32_t j,
                                             uint32_t C, uint32_t B, uint32_t keep) {
     const uint32_t L = (uint32_t)j0.L;
@@ -112,18 +112,20 @@ __global__ __launch_bounds__(MFMA_MAX_THREADS, 3) void d2d_fir_mfma_kernel(MfmaA
     extern __shared__ __align__(16) unsigned char smem[];
     // A block serves one channel group of one file: all channels for mono/stereo, one channel PAIR
     // otherwise (many channels would not leave LDS for more than a few waves, and staging them all
-    // at once overruns the register prefetch).  Ct = channels of the file (input layout, output frame
-    // stride), C = channels of this group, cbase = its first channel.
-    const uint32_t Ct = a.epi.channels, sb = a.epi.sample_bytes;
+    // at once overruns the register prefetch).  Ct = channels of the file (input layout), Cs = channels
+    // the engine converts = width of the output frame (fewer than Ct for a channel subset), C =
+    // channels of this group, cbase = its first channel among the Cs; jobs[c].ch is the channel's
+    // index in the FILE.
+    const uint32_t Ct = a.in_channels, Cs = a.epi.channels, sb = a.epi.sample_bytes;
     const uint32_t fidx = blockIdx.y / m.ngroups, cbase = (blockIdx.y - fidx * m.ngroups) * 2u;
-    const uint32_t C = m.ngroups == 1 ? Ct : (Ct - cbase < 2u ? Ct - cbase : 2u);
+    const uint32_t C = m.ngroups == 1 ? Cs : (Cs - cbase < 2u ? Cs - cbase : 2u);
     const uint32_t fbytes = sb * C;                        // frame bytes inside the wave's LDS out-slice
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     uint8_t* wbase = smem + m.off_waves + wave * m.wave_lds;
     uint8_t* outw = wbase + m.off_out;
     double* pkw = reinterpret_cast<double*>(wbase + m.off_pk);
     uint32_t* rngw = reinterpret_cast<uint32_t*>(pkw + C * 64);
-    const StreamJob* jobs = a.jobs + (size_t)fidx * Ct + cbase;   // jobs[c]: channel cbase + c
+    const StreamJob* jobs = a.jobs + (size_t)fidx * Cs + cbase;   // jobs[c]: converted channel cbase + c
     const StreamJob j0 = jobs[0];          // in, L, e0, n0, nout are common to a file's channels
 
     const int64_t first0 = j0.e0 - (int64_t)a.Wb;          // first byte of output 0's window
@@ -187,7 +189,7 @@ __global__ __launch_bounds__(MFMA_MAX_THREADS, 3) void d2d_fir_mfma_kernel(MfmaA
     const bool short_span = pow2B && m.span <= Bsz && ((uint64_t)Bsz * Ct * 2u) < (1ull << 32);
     uint32_t pf_cs[MFMA_PF];                               // (cbase + channel) << bshift
 #pragma unroll
-    for (int i = 0; i < MFMA_PF; ++i) pf_cs[i] = (cbase + pf_c[i]) << bshift;
+    for (int i = 0; i < MFMA_PF; ++i) pf_cs[i] = (j0.ch + pf_c[i]) << bshift;   // the group's channels are consecutive in the file
     const uint32_t group_bytes = Bsz * Ct;
     auto prefetch = [&](uint32_t w) {
         const int32_t ab = tile_abeg(w);
@@ -207,13 +209,13 @@ __global__ __launch_bounds__(MFMA_MAX_THREADS, 3) void d2d_fir_mfma_kernel(MfmaA
                 if (lane + 64 * i < nch) {
                     const uint32_t j = (uint32_t)ab + pf_q[i] * 16;
                     const uint64_t off = (uint64_t)((j >> bshift) * Ct) << bshift;   // start of the block group
-                    const uint8_t* p = j0.in + off + (((cbase + pf_c[i]) << bshift) + (j & (Bsz - 1)));
+                    const uint8_t* p = j0.in + off + (((j0.ch + pf_c[i]) << bshift) + (j & (Bsz - 1)));
                     pf[i] = *reinterpret_cast<D2D_GLOBAL const u32x4*>(as_global(p));
                 }
         } else {
 #pragma unroll
             for (int i = 0; i < MFMA_PF; ++i)
-                if (lane + 64 * i < nch) pf[i] = load_chunk(jobs, j0, pf_c[i], cbase, ab + (int32_t)(pf_q[i] * 16), Ct, a.B, a.keep);
+                if (lane + 64 * i < nch) pf[i] = load_chunk(jobs, j0, pf_c[i], j0.ch, ab + (int32_t)(pf_q[i] * 16), Ct, a.B, a.keep);
         }
     };
     if (wt < nwt) prefetch(wt);
@@ -260,7 +262,7 @@ __global__ __launch_bounds__(MFMA_MAX_THREADS, 3) void d2d_fir_mfma_kernel(MfmaA
             }
         for (uint32_t ch = lane + 64 * MFMA_PF; ch < nch; ch += 64) {   // many channels / long windows
             const uint32_t c = ch / cpc, q = ch - c * cpc;
-            const u32x4 v = load_chunk(jobs, j0, c, cbase, tile_abeg(wt) + (int32_t)(q * 16), Ct, a.B, a.keep);
+            const u32x4 v = load_chunk(jobs, j0, c, j0.ch, tile_abeg(wt) + (int32_t)(q * 16), Ct, a.B, a.keep);
             *reinterpret_cast<uint32_t*>(wbase + lds_word_addr(c, q * 4 + 0)) = v.x;
             *reinterpret_cast<uint32_t*>(wbase + lds_word_addr(c, q * 4 + 1)) = v.y;
             *reinterpret_cast<uint32_t*>(wbase + lds_word_addr(c, q * 4 + 2)) = v.z;
@@ -424,7 +426,7 @@ __global__ __launch_bounds__(MFMA_MAX_THREADS, 3) void d2d_fir_mfma_kernel(MfmaA
                     }
                 }
             };
-            const bool reg_store = full && two && Ct == 2 && sb == 3 && m.qsh == 0 && !a.to_scratch;
+            const bool reg_store = full && two && Cs == 2 && sb == 3 && m.qsh == 0 && !a.to_scratch;
             if (dbg & 2) { if (acc0[0] == 0x12345 && acc1[5] == 77 && acc0[9] + acc1[13] + acc0[15] + acc1[2] == 99) outw[lane] = 1; }
             else if (reg_store) {
                 // Stereo 24-bit, whole tile: no LDS round trip.  Lane (r, h) owns frames 4h .. 4h+3 of
@@ -508,7 +510,7 @@ __global__ __launch_bounds__(MFMA_MAX_THREADS, 3) void d2d_fir_mfma_kernel(MfmaA
                 for (uint32_t i = nb16 + lane; i < nb; i += 64) as_global(g)[i] = outw[i];
             } else {
                 // this group's `fbytes` bytes of every frame sit sb*cbase bytes into the file's frame
-                const uint32_t gstride = sb * Ct;
+                const uint32_t gstride = sb * Cs;
                 uint8_t* g = reinterpret_cast<uint8_t*>(j0.out) + (size_t)wt * 256 * gstride + sb * cbase;
                 for (uint32_t fr = lane; fr < nfr; fr += 64)
                     for (uint32_t b = 0; b < fbytes; ++b) as_global(g)[(size_t)fr * gstride + b] = outw[fr * fbytes + b];

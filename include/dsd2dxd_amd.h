@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define D2D_ABI_VERSION 1
+#define D2D_ABI_VERSION 2
 
 /* status codes */
 enum {
@@ -63,6 +63,14 @@ typedef struct d2d_params {
     int32_t  device;        /* HIP device ordinal (Rayon workers can be pinned to GPUs)         */
     double   level_db;      /* volume in dB                `level_db`     src/main.rs:107-110   */
     uint64_t seed;          /* dither seed (counter-based generator)             */
+    /* Channel subset (ABI 2; a 64-byte struct without these two means "all channels").  The engine
+     * reads the `channels`-wide input but converts only channels [channel_first, channel_first +
+     * channel_count) and its PCM frames are `channel_count` wide; filter state, dither and peaks of a
+     * channel are the same as in a full conversion, so the ranks of a multi-GPU job can take a few
+     * channels each of ONE multichannel stream (config 5) and the host interleaves their
+     * frames.  channel_count = 0: all channels. */
+    uint32_t channel_first;
+    uint32_t channel_count;
 } d2d_params;
 
 typedef struct d2d_engine d2d_engine;

@@ -194,3 +194,40 @@ def test_host_resident_batch_pipeline(engine_lib, oracle_mod, out_rate, fmt, pin
     ios[3].pcm_capacity_bytes = 64
     with pytest.raises(Exception, match="pcm buffer too small"):
         e2.translate_batch_host(ios, 8192)
+
+
+@pytest.mark.parametrize("kernel", [1, 2])
+@pytest.mark.parametrize("out_rate,fmt,bits", [(88200, "I", 24), (96000, "I", 24), (176400, "P", 16), (352800, "P", 32)])
+def test_channel_subsets_reproduce_the_full_conversion(engine_lib, oracle_mod, kernel, out_rate, fmt, bits):
+    """SURVEY.md 8e / BASELINE config 5: the ranks of a multi-GPU job take a few channels each of ONE
+    multichannel stream.  Every subset engine (fed the whole input) must emit exactly the columns of the
+    full conversion -- same filter state, same per-channel dither, same peaks -- call after call."""
+    chn = 6
+    kw = dict(KW, output_rate=out_rate, channels=chn, fmt=fmt, endianness="M" if fmt == "I" else "L", bit_depth=bits,
+              dither="F" if bits == 32 else "T")
+    block = 4096 if fmt == "P" else 1
+    nbytes = 4096 * 3 + 300
+    chans = [random_bytes(nbytes, 500 + c) for c in range(chn)]
+    cuts = [0, 4096 * 2, nbytes]
+    bufs = [pack_layout([ch[a:b] for ch in chans], fmt, block) for a, b in zip(cuts[:-1], cuts[1:])]
+    o = oracle_mod.Oracle(**kw)
+    sb = {16: 2, 32: 4}.get(bits, 3)
+    full = []
+    for b in bufs:
+        r, rf = o.translate(b)
+        full.append(r[:rf * sb * chn].reshape(rf, chn, sb))
+    full = np.concatenate(full)
+    for first, count in ((0, 1), (1, 2), (3, 3), (5, 0), (2, 4)):
+        e = engine_lib.Engine(n_files=1, kernel=kernel, channel_first=first, channel_count=count, **kw)
+        n = count or chn - first
+        assert e.out_channels == n and e.frame_bytes == sb * n
+        got = []
+        for b in bufs:
+            out, fr = e.translate(b)
+            got.append(out.reshape(fr, n, sb))
+        got = np.concatenate(got)
+        assert np.array_equal(got, full[:, first:first + n, :]), (first, count)
+        for c in range(n):
+            assert e.peak(c) == o.peak(first + c)
+    with pytest.raises(engine_lib.D2DError, match="Invalid channel subset"):
+        engine_lib.Engine(n_files=1, kernel=kernel, channel_first=4, channel_count=3, **kw)
