@@ -102,6 +102,9 @@ def main():
     ap.add_argument("--distinct", type=int, default=0, help="distinct synthetic files generated per rank (0 = all of them distinct; fewer are tiled to --files)")
     ap.add_argument("--workload", default="dsd64_to_88k2_s24_stereo", choices=sorted(WORKLOADS))
     ap.add_argument("--kernel", default="auto", choices=["auto", "lut", "mfma"])
+    ap.add_argument("--shard", default="files", choices=["files", "channels"],
+                    help="files: every rank converts its own files (weak scaling, the default).  channels: every rank holds the SAME "
+                         "multichannel files and converts its channel range (BASELINE config 5: one stream split by channel; strong scaling)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--pcie", action="store_true", help="also time the host-resident batch (pinned host in/out, upload/convert/download overlapped); reported as an extra pcie_inclusive object, never as value")
     ap.add_argument("--cpu-budget", type=float, default=12.0, help="seconds of CPU-baseline work")
@@ -146,7 +149,15 @@ def main():
 
     if args.distinct <= 0:
         args.distinct = args.files
-    files = make_files(args.files, bpc, dsd_rate, args.distinct, rank, gen_threads, channels, fmt, endian, block)
+    ch_first, ch_count = 0, channels
+    if args.shard == "channels":
+        from dsd2dxd_amd.shard import shard_channels
+        if world > channels:
+            raise SystemExit(f"--shard channels: {world} ranks but only {channels} channels")
+        ch_first, ch_count = shard_channels(channels, world, rank)
+        kw.update(channel_first=ch_first, channel_count=ch_count)
+    # file shards differ per rank; a channel shard reads the same files on every rank
+    files = make_files(args.files, bpc, dsd_rate, args.distinct, rank if args.shard == "files" else 0, gen_threads, channels, fmt, endian, block)
     eng = d.Engine(n_files=args.files, kernel=kernel, device=local_dev, **kw)
     stream = torch.cuda.current_stream().cuda_stream
 
@@ -207,8 +218,13 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
-    samples_per_step_rank = frames * channels * args.files
-    total_samples = samples_per_step_rank * args.steps * world
+    samples_per_step_rank = frames * ch_count * args.files
+    if world > 1 and args.shard == "channels":
+        tot = torch.tensor([samples_per_step_rank], dtype=torch.int64, device=cdev)
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        total_samples = int(tot.item()) * args.steps
+    else:
+        total_samples = samples_per_step_rank * args.steps * world
     value = total_samples / dt / 1e6
     fir_s = fir_ms / 1e3 / max(1, launches)
     alg_bytes = samples_per_step_rank * bytes_per_sample      # per launch (one launch = one step of one rank)
@@ -217,11 +233,12 @@ def main():
     out = {
         "metric": "output PCM Msamples/s, DSD64->88.2k stereo" if args.workload.startswith("dsd64_to_88k2") else f"output PCM Msamples/s, {args.workload}",
         "value": round(value, 3), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+        "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak" if args.shard == "files" else "strong",
         "vs_baseline": None, "dtype": "f64", "data": "synthetic (2nd-order 1-bit modulator: 1 kHz-family sines at 0.352 FS and pink noise at ~0.1 RMS; %d distinct files per rank%s)" % (min(args.distinct, args.files), "" if args.distinct >= args.files else " tiled to %d" % args.files),
         "config": {"workload": f"{args.workload}: {args.files} files/GPU x {blocks * 4096 * 8 / (DSD64 * dsd_rate):.1f} s, {'planar 4096-B LSB-first' if fmt == 'P' else 'byte-interleaved MSB-first'} {channels} ch -> {bits}-bit {out_rate} Hz, dither {dither}, filter E ({eng.info()['ntaps']} taps, M={M:g})",
                    "files_per_gpu": args.files, "seconds_per_file": round(blocks * 4096 * 8 / (DSD64 * dsd_rate), 3),
-                   "parallelism": f"files sharded over {world} GPU(s), no data-path collective", "kernel": eng.kernel_name()},
+                   "parallelism": (f"files sharded over {world} GPU(s), no data-path collective" if args.shard == "files" else
+                                   f"channels of every file split over {world} GPU(s) ({ch_count} of {channels} on rank 0), no data-path collective"), "kernel": eng.kernel_name()},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
                      "kernel": eng.kernel_name(), "kernel_ms": round(fir_s * 1e3, 4),

@@ -291,7 +291,8 @@ constexpr uint32_t DI_TILE = 1024;
 constexpr uint32_t DI_BLOCK = 4096;
 __host__ __device__ constexpr uint32_t di_lds_bytes(uint32_t C) { return DI_TILE * C + (DI_TILE / 16) * 4; }
 
-// (C = channels of the file; spf = streams per file in the job table, fewer for a channel subset)
+// (C = channels of the file; spf = streams per file in the job table: the channels the engine converts,
+// jobs[file * spf].ch the first of them -- only those are written to the planar copy)
 __global__ __launch_bounds__(256) void d2d_deinterleave_kernel(const StreamJob* jobs, uint32_t C, uint32_t spf) {
     extern __shared__ __align__(16) unsigned char smem[];
     const StreamJob job = jobs[blockIdx.y * spf];
@@ -320,8 +321,8 @@ __global__ __launch_bounds__(256) void d2d_deinterleave_kernel(const StreamJob* 
         const uint32_t blk = j0 / DI_BLOCK, off0 = j0 - blk * DI_BLOCK;   // DI_TILE divides DI_BLOCK
         const uint32_t blen = min(DI_BLOCK, L - blk * DI_BLOCK);
         const uint32_t nq = (nj + 15) / 16;
-        for (uint32_t t = threadIdx.x; t < nq * C; t += 256) {
-            const uint32_t c = t / nq, q = t - c * nq;
+        for (uint32_t t = threadIdx.x; t < nq * spf; t += 256) {
+            const uint32_t cl = t / nq, q = t - cl * nq, c = job.ch + cl;
             const uint32_t n = min(16u, nj - q * 16);
             const uint8_t* g = smem + q * gpitch + c;
             uint32_t w[4] = {0, 0, 0, 0};

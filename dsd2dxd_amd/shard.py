@@ -29,3 +29,34 @@ def shard_by_bytes(sizes, world):
     for lst in out:
         lst.sort()
     return out
+
+
+def shard_channels(channels, world, rank):
+    """(channel_first, channel_count) of ONE multichannel stream for `rank` of `world`: contiguous,
+    balanced channel ranges (SURVEY.md 8e / BASELINE config 5: 8 channels -> one channel per GPU).  A rank
+    beyond the channel count gets (0, 0) and sits the job out.  The pair feeds d2d_params.channel_first /
+    channel_count: every rank reads the whole interleaved input and converts its own columns."""
+    begin, end = shard_range(channels, world, rank)
+    if end == begin:
+        return 0, 0
+    return begin, end - begin
+
+
+def merge_channel_frames(parts, sample_bytes):
+    """Interleave per-rank PCM back into full-width frames.  `parts`: (channel_first, channel_count,
+    uint8 array of frames * channel_count * sample_bytes bytes) per rank; the channel ranges must tile
+    the stream's channels and all parts hold the same number of frames."""
+    import numpy as np
+    parts = sorted((p for p in parts if p[1] > 0), key=lambda p: p[0])
+    frames = np.asarray(parts[0][2]).size // (parts[0][1] * sample_bytes)
+    cols = []
+    expect = parts[0][0]
+    for first, count, buf in parts:
+        if first != expect:
+            raise ValueError("channel ranges do not tile")
+        a = np.asarray(buf, dtype=np.uint8)
+        if a.size != frames * count * sample_bytes:
+            raise ValueError("parts disagree on the frame count")
+        cols.append(a.reshape(frames, count * sample_bytes))
+        expect = first + count
+    return np.concatenate(cols, axis=1).reshape(-1)

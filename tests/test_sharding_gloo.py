@@ -100,3 +100,63 @@ def test_two_rank_sharded_batch_equals_single_rank():
     assert got == ref                               # 1 GPU == N GPUs: same files, same bytes
     assert total == sum(r[2] for r in ref)
     assert abs(tmax - 0.2) < 1e-12                  # MAX over ranks, as bench.py times a step
+
+
+def test_shard_channels_tiles_and_merge_restores_frames():
+    from dsd2dxd_amd.shard import merge_channel_frames, shard_channels
+    for channels in (1, 2, 5, 6, 8):
+        for world in (1, 2, 3, 8, 10):
+            got = [shard_channels(channels, world, r) for r in range(world)]
+            used = [(f, c) for f, c in got if c]
+            assert sum(c for _, c in used) == channels and used[0][0] == 0
+            assert all(a[0] + a[1] == b[0] for a, b in zip(used[:-1], used[1:]))
+            assert max(c for _, c in used) - min(c for _, c in used) <= 1
+    rng = np.random.default_rng(1)
+    frames, chn, sb = 37, 5, 3
+    full = rng.integers(0, 256, size=(frames, chn, sb), dtype=np.uint8)
+    parts = [(f, c, full[:, f:f + c, :].reshape(-1).copy()) for f, c in (shard_channels(chn, 3, r) for r in range(3))]
+    assert np.array_equal(merge_channel_frames(parts[::-1], sb), full.reshape(-1))
+    with pytest.raises(ValueError):
+        merge_channel_frames([parts[0], parts[2]], sb)
+
+
+def _channel_worker(rank, world, port, q):
+    """BASELINE config 5's split: ONE multichannel stream, a channel range per rank.  The conversion is the
+    oracle's (no GPU here) restricted to the rank's columns -- what a subset engine emits, see
+    tests/test_gpu_api.py::test_channel_subsets_reproduce_the_full_conversion."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from dsd2dxd_amd.shard import merge_channel_frames, shard_channels
+    from helpers import pack_layout, random_bytes
+    from oracle import oracle as O
+    chn, nbytes = 5, 4096 * 2 + 77
+    kw = dict(dsd_rate=1, output_rate=96000, channels=chn, fmt="I", endianness="M", block_size=1, filter="E", bit_depth=24, dither="T", seed=9)
+    buf = pack_layout([random_bytes(nbytes, 40 + c) for c in range(chn)], "I", 1)     # every rank reads the whole stream
+    pcm, fr = O.Oracle(**kw).translate(buf)
+    first, count = shard_channels(chn, world, rank)
+    mine = pcm[:fr * chn * 3].reshape(fr, chn, 3)[:, first:first + count, :].reshape(-1).copy()
+    gathered = [None] * world
+    dist.all_gather_object(gathered, (first, count, mine))
+    if rank == 0:
+        q.put((np.array_equal(merge_channel_frames(gathered, 3), pcm[:fr * chn * 3]), [g[:2] for g in gathered]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_two_ranks_split_one_stream_by_channel():
+    from oracle import oracle as O
+    O.build()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_channel_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    same, ranges = q.get(timeout=100)
+    for p in procs:
+        p.join(30)
+        assert p.exitcode == 0
+    assert same and ranges == [(0, 3), (3, 2)]
