@@ -99,3 +99,62 @@ def test_c3_dsd128_shift_invariance(engine_lib):
     ob, _ = _run_batch(engine_lib, [pack_layout(b, "P", 4096)], kw, 2)
     fa, fb = oa[0].reshape(-1, 6), ob[0].reshape(-1, 6)
     assert np.array_equal(fb[k:], fa[:-k])
+
+
+def test_c5_full_length_channel_split_and_streaming(engine_lib, oracle_mod):
+    """config 5 at its full size: ONE DSD512 8-channel byte-interleaved MSB-first stream of 30 s
+    (84.7 MB per channel) -> 24-bit 96 kHz through the 48k cascade.  Properties: four engines that take
+    two channels each (the multi-GPU split of SURVEY.md 8e) reproduce the whole conversion exactly;
+    feeding the stream in three calls equals one call; the first stretch equals the oracle."""
+    import torch
+    from dsd2dxd_amd.shard import merge_channel_frames, shard_channels
+    chn, seconds = 8, 30
+    nbytes = seconds * 2822400 * 8 // 8                    # per channel
+    rng = np.random.default_rng(5)
+    # a cheap 1-bit stream with low-frequency content: bytes drawn from a slowly varying density
+    base = (np.sin(np.arange(nbytes // 4096 + 1) * 0.01)[:, None] * 40 + 128).astype(np.int32)
+    data = np.empty((nbytes, chn), np.uint8)
+    for c in range(chn):
+        dens = np.repeat(base, 4096, axis=0).reshape(-1)[:nbytes]
+        data[:, c] = (rng.integers(0, 256, nbytes, dtype=np.int32) + (dens - 128) // 8).clip(0, 255).astype(np.uint8)
+    buf = data.reshape(-1)                                 # byte-interleaved: c0 c1 ... c7 per byte time
+    kw = dict(dsd_rate=8, output_rate=96000, channels=chn, fmt="I", endianness="M", block_size=1, filter="E",
+              bit_depth=24, dither="T", seed=206)
+    d_in = torch.from_numpy(buf).cuda()
+
+    def run(chunks, **extra):
+        e = engine_lib.Engine(n_files=1, kernel=2, **kw, **extra)
+        outs, pos = [], 0
+        per = (nbytes // chunks + 15) // 16 * 16
+        while pos < nbytes:
+            L = min(per, nbytes - pos)
+            frames = e.next_frames(L)
+            d_out = torch.empty(frames * e.frame_bytes + 16, dtype=torch.uint8, device="cuda")
+            ios = (engine_lib.FileIO * 1)()
+            ios[0].dsd = d_in.data_ptr() + pos * chn
+            ios[0].bytes_per_channel = L
+            ios[0].pcm = d_out.data_ptr()
+            ios[0].pcm_capacity_bytes = frames * e.frame_bytes
+            e.translate_batch_device(ios, torch.cuda.current_stream().cuda_stream)
+            torch.cuda.synchronize()
+            outs.append(d_out[:frames * e.frame_bytes].cpu().numpy())
+            pos += L
+        return np.concatenate(outs), e
+
+    whole, e = run(1)
+    frames = whole.size // (3 * chn)
+    assert frames == -(-(nbytes * 8 // 64) * 40 // 147)     # ceil(n_x * L / 147), n_x = bits / 64
+    streamed, _ = run(3)
+    assert np.array_equal(streamed, whole)
+    parts = []
+    for r in range(4):
+        first, count = shard_channels(chn, 4, r)
+        out, es = run(1, channel_first=first, channel_count=count)
+        parts.append((first, count, out))
+        for c in range(count):
+            assert es.peak(c) == e.peak(first + c)
+    assert np.array_equal(merge_channel_frames(parts, 3), whole)
+    # the head of the stream against the oracle (1/64 of it: the oracle's 48k path is slow)
+    head = nbytes // 64 // 16 * 16
+    r, rf = oracle_mod.Oracle(**kw).translate(buf[:head * chn])
+    assert np.array_equal(whole[:(rf - 200) * 3 * chn], r[:(rf - 200) * 3 * chn])
