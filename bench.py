@@ -34,6 +34,7 @@ WORKLOADS = {
     "dsd64_to_88k2_s24_stereo": (1, 88200, 24, "T", 2, 32 / 8 + 3),
     "dsd64_to_352k8_f32_stereo": (1, 352800, 32, "X", 2, 8 / 8 + 4),
     "dsd128_to_88k2_s24_stereo": (2, 88200, 24, "T", 2, 64 / 8 + 3),
+    "dsd128_to_88k2_s24_stereo_ns": (2, 88200, 24, "N", 2, 64 / 8 + 3),   # BASELINE config 3's noise-shaped variant (an extension)
     "dsd64_to_96k_s24_stereo": (1, 96000, 24, "T", 2, 29.4 / 8 + 3),
     "dsd64_to_192k_s24_stereo": (1, 192000, 24, "T", 2, 14.7 / 8 + 3),
     "dsd128_to_384k_s24_stereo": (2, 384000, 24, "T", 2, 14.7 / 8 + 3),

@@ -59,6 +59,9 @@ struct d2d_engine {
     uint8_t* d_hist[2] = {nullptr, nullptr}; int hist_cur = 0;
     double* d_peak = nullptr;
     int32_t* d_scratch = nullptr; size_t scratch_stride = 0;  // stage-A integers per stream (multiple of 4)
+    bool noise_shape = false;             // 'N' dither: the FIR writes integers, a sequential pass requantises
+    double* d_ns = nullptr;               // its state: two errors per stream
+    uint32_t xs_hist = 0;                 // samples carried in front of each scratch line (P of the resampler, else 0)
     StreamJob* d_jobs = nullptr;
     StreamJob* h_jobs = nullptr;          // pinned, JOB_SLOTS x nstreams
     hipEvent_t job_ev[JOB_SLOTS]{}; bool job_ev_used[JOB_SLOTS]{}; int job_slot = 0;
@@ -113,7 +116,7 @@ static int validate(const d2d_params& p, std::string& err) {
     if (p.bit_depth != 16 && p.bit_depth != 20 && p.bit_depth != 24 && p.bit_depth != 32) {
         err = "Invalid bit depth; must be 16, 20, 24 or 32"; return D2D_ERR_PARAM;
     }
-    if (p.dither != 'T' && p.dither != 'R' && p.dither != 'F' && p.dither != 'X') {
+    if (p.dither != 'T' && p.dither != 'R' && p.dither != 'F' && p.dither != 'X' && p.dither != 'N') {
         err = "Invalid dither type; must be T, R, F, or X"; return D2D_ERR_PARAM;   // src/main.rs:176-180
     }
     if (p.fmt != D2D_FMT_INTERLEAVED && p.fmt != D2D_FMT_PLANAR) {
@@ -134,6 +137,7 @@ static void free_device(d2d_engine* e) {
     if (e->d_hist[1]) hipFree(e->d_hist[1]);
     if (e->d_peak) hipFree(e->d_peak);
     if (e->d_scratch) hipFree(e->d_scratch);
+    if (e->d_ns) hipFree(e->d_ns);
     if (e->d_jobs) hipFree(e->d_jobs);
     if (e->h_jobs) hipHostFree(e->h_jobs);
     if (e->d_in) hipFree(e->d_in);
@@ -156,6 +160,7 @@ static int reset_state(d2d_engine* e) {
     HIPCHK(e, hipMemset(e->d_hist[1], idle, hbytes));
     HIPCHK(e, hipMemset(e->d_peak, 0, sizeof(double) * e->nstreams));
     if (e->d_scratch) HIPCHK(e, hipMemset(e->d_scratch, 0, sizeof(int32_t) * e->scratch_stride * e->nstreams));
+    if (e->d_ns) HIPCHK(e, hipMemset(e->d_ns, 0, sizeof(double) * 2 * e->nstreams));
     for (auto& f : e->files) f = FileState{};
     e->hist_cur = 0;
     return D2D_OK;
@@ -196,6 +201,11 @@ int d2d_create(const d2d_params* params, uint32_t n_files, d2d_engine** out) {
     e->epi.seed = e->p.seed;
     e->epi.bits = e->p.bit_depth;
     e->epi.dither = e->p.dither;
+    if (e->p.dither == 'N') {
+        if (e->fc.resamp) { g_create_error = "Noise-shaped dither is available for 44.1 kHz-family output rates only"; delete e; return D2D_ERR_PARAM; }
+        if (e->p.bit_depth == 32) e->epi.dither = 'X';                     // float output: nothing to shape
+        else e->noise_shape = true;
+    }
     e->epi.sample_bytes = (uint32_t)sample_bytes_of(e->p.bit_depth);
     e->epi.channels = e->C;
     e->lut = lut_layout(e->Mb, e->Wb);
@@ -245,8 +255,14 @@ int d2d_create(const d2d_params* params, uint32_t n_files, d2d_engine** out) {
         e->resamp_bytes = sizeof(double) * rt.size();
         CK(hipMalloc((void**)&e->d_resamp, e->resamp_bytes));
         CK(hipMemcpy(e->d_resamp, rt.data(), e->resamp_bytes, hipMemcpyHostToDevice));
+        e->xs_hist = (uint32_t)e->fc.resamp->P;
         e->scratch_stride = (size_t)e->fc.resamp->P + 4096;
         CK(hipMalloc((void**)&e->d_scratch, sizeof(int32_t) * e->scratch_stride * e->nstreams));
+    }
+    if (e->noise_shape) {
+        e->scratch_stride = 4096;
+        CK(hipMalloc((void**)&e->d_scratch, sizeof(int32_t) * e->scratch_stride * e->nstreams));
+        CK(hipMalloc((void**)&e->d_ns, sizeof(double) * 2 * e->nstreams));
     }
     const size_t hbytes = (size_t)e->nstreams * e->keep;
     CK(hipMalloc((void**)&e->d_hist[0], hbytes));
@@ -293,9 +309,9 @@ static int grow_scratch(d2d_engine* e, size_t need_stride, hipStream_t s) {
     size_t ns = (std::max(need_stride, e->scratch_stride * 2) + 3) & ~(size_t)3;
     int32_t* nb = nullptr;
     HIPCHK(e, hipMalloc((void**)&nb, sizeof(int32_t) * ns * e->nstreams));
-    const size_t P = (size_t)e->fc.resamp->P;
-    HIPCHK(e, hipMemcpy2DAsync(nb, ns * sizeof(int32_t), e->d_scratch, e->scratch_stride * sizeof(int32_t),
-                               P * sizeof(int32_t), e->nstreams, hipMemcpyDeviceToDevice, s));
+    const size_t P = (size_t)e->xs_hist;
+    if (P) HIPCHK(e, hipMemcpy2DAsync(nb, ns * sizeof(int32_t), e->d_scratch, e->scratch_stride * sizeof(int32_t),
+                                      P * sizeof(int32_t), e->nstreams, hipMemcpyDeviceToDevice, s));
     HIPCHK(e, hipStreamSynchronize(s));
     HIPCHK(e, hipFree(e->d_scratch));
     e->d_scratch = nb; e->scratch_stride = ns;
@@ -327,8 +343,8 @@ int d2d_translate_batch_device(d2d_engine* e, d2d_file_io* io, uint32_t n_files,
         max_frames = std::max<uint32_t>(max_frames, (uint32_t)frames);
         io[f].frames_out = (size_t)frames;
     }
-    if (e->fc.resamp) {
-        int rc = grow_scratch(e, (size_t)e->fc.resamp->P + max_nx, s);
+    if (e->fc.resamp || e->noise_shape) {
+        int rc = grow_scratch(e, (size_t)e->xs_hist + max_nx, s);
         if (rc) return rc;
     }
     uint32_t max_L = 0;
@@ -359,7 +375,7 @@ int d2d_translate_batch_device(d2d_engine* e, d2d_file_io* io, uint32_t n_files,
             j.hist = e->d_hist[cur] + (size_t)sidx * e->keep;
             j.hist_next = e->d_hist[cur ^ 1] + (size_t)sidx * e->keep;
             j.out = io[f].pcm;
-            j.xs = e->d_scratch ? e->d_scratch + (size_t)sidx * e->scratch_stride + e->fc.resamp->P : nullptr;
+            j.xs = e->d_scratch ? e->d_scratch + (size_t)sidx * e->scratch_stride + e->xs_hist : nullptr;
             j.peak = e->d_peak + sidx;
             j.L = io[f].bytes_per_channel;
             j.e0 = (int64_t)((st.nfir + 1) * (uint64_t)e->Mb) - (int64_t)st.pos;
@@ -388,7 +404,7 @@ int d2d_translate_batch_device(d2d_engine* e, d2d_file_io* io, uint32_t n_files,
     a.Wb = (uint32_t)e->Wb;
     a.ntab = (uint32_t)e->lut.ntab; a.pad = (uint32_t)e->lut.pad; a.nq = (uint32_t)e->lut.nq;
     a.B = e->B; a.keep = e->keep;
-    a.to_scratch = e->fc.resamp ? 1u : 0u;
+    a.to_scratch = (e->fc.resamp || e->noise_shape) ? 1u : 0u;
     a.ksteps = (uint32_t)e->mfma.ksteps;
     a.scale_bits = e->S;
     a.in_channels = e->Cin;
@@ -413,6 +429,11 @@ int d2d_translate_batch_device(d2d_engine* e, d2d_file_io* io, uint32_t n_files,
         }
     }
     if (pe) HIPCHK(e, hipEventRecord(pe->second, s));
+    if (e->noise_shape) {
+        NoiseShapeArgs ns{};
+        ns.jobs = e->d_jobs; ns.state = e->d_ns; ns.scale_bits = e->S; ns.nstreams = e->nstreams; ns.max_nout = max_nx; ns.epi = e->epi;
+        HIPCHK(e, launch_noise_shape(ns, s));
+    }
     if (e->fc.resamp) {
         ResampArgs r{};
         r.jobs = e->d_jobs; r.coef = e->d_resamp;

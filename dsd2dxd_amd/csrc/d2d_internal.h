@@ -62,6 +62,17 @@ struct FirArgs {
     Epilogue epi;
 };
 
+// the noise-shaping pass ('N' dither): one thread per (stream, 65536-output segment) walks its integers in order
+struct NoiseShapeArgs {
+    const StreamJob* jobs;
+    double*  state;            // [nstreams][2]: the last two requantisation errors, carried from call to call
+    int32_t  scale_bits;       // S: the scratch holds y * 2^S
+    uint32_t nstreams;
+    uint32_t max_nout;         // the longest stream's outputs this call (sizes the grid)
+    uint32_t reserved;
+    Epilogue epi;
+};
+
 struct ResampArgs {
     const StreamJob* jobs;
     const double*    coef;     // packed per task: [L/4][nsteps][4] and pre-scaled by 2^-S, see build_resamp_table()

@@ -339,6 +339,54 @@ __global__ __launch_bounds__(256) void d2d_deinterleave_kernel(const StreamJob* 
     }
 }
 
+// 'N' dither (an extension, see dsd2dxd_amd.h): TPDF dither inside the error-feedback loop
+//   w = x - (2*e1 - e2);  r = round_half_away(w + d);  e = r - w;  e2 = e1;  e1 = e
+// in exactly the oracle's operation order (emit_sample() in oracle/d2d_oracle.c).  The loop is a
+// recurrence through a rounding, so it cannot be reassociated; by definition it restarts from
+// e1 = e2 = 0 at every output index that is a multiple of NS_SEG, and one thread walks one such segment
+// (the part of it that lies in this call; a segment begun in an earlier call continues from the carried
+// state).  blockIdx.y = stream, blockIdx.x * 64 + threadIdx.x = segment of this call.
+constexpr uint32_t NS_SEG_BITS = 16;
+
+__global__ __launch_bounds__(64) void d2d_noise_shape_kernel(NoiseShapeArgs a) {
+    const uint32_t sidx = blockIdx.y;
+    const StreamJob job = a.jobs[sidx];
+    if (job.nout == 0) return;
+    const uint64_t n_end = job.n0 + job.nout;
+    const uint64_t k0 = job.n0 >> NS_SEG_BITS, k1 = (n_end - 1) >> NS_SEG_BITS;
+    const uint64_t k = k0 + blockIdx.x * 64 + threadIdx.x;
+    if (k > k1) return;
+    const uint64_t seg_lo = k << NS_SEG_BITS, seg_hi = (k + 1) << NS_SEG_BITS;
+    const uint32_t i0 = seg_lo > job.n0 ? (uint32_t)(seg_lo - job.n0) : 0u;
+    const uint32_t i1 = (uint32_t)((seg_hi < n_end ? seg_hi : n_end) - job.n0);
+    const D2D_GLOBAL int32_t* xs = as_global(job.xs);
+    uint8_t* out = reinterpret_cast<uint8_t*>(job.out) + job.och * a.epi.sample_bytes;
+    const uint32_t frame_bytes = a.epi.sample_bytes * a.epi.channels;
+    const bool carried = seg_lo < job.n0;                                  // begun in an earlier call
+    double e1 = carried ? a.state[2 * sidx] : 0.0, e2 = carried ? a.state[2 * sidx + 1] : 0.0, pk = 0.0;
+    const double lim = (double)(1u << (a.epi.bits - 1));
+    for (uint32_t i = i0; i < i1; ++i) {
+        const double y = ldexp((double)xs[i], -a.scale_bits);            // exact
+        pk = fmax(pk, fabs(y * a.epi.gain));
+        const double x = y * a.epi.scale;
+        const uint32_t rnd = rng32(job, job.n0 + i);
+        const double d = (double)((rnd & 0xFFFFu) + (rnd >> 16) + 1u) * 0x1p-16 - 1.0;
+        const double fb = 2.0 * e1 - e2;
+        const double w = x - fb;
+        const double q = w + d;
+        const double r = trunc(q + copysign(0.5, q));
+        e2 = e1;
+        e1 = r - w;
+        int32_t iv = (int32_t)fmax(fmin(r, lim - 1.0), -lim);
+        if (a.epi.bits == 20) iv *= 16;
+        uint8_t* dst = out + (size_t)i * frame_bytes;
+        if (a.epi.bits == 16) { *reinterpret_cast<uint16_t*>(dst) = (uint16_t)iv; }
+        else { dst[0] = (uint8_t)iv; dst[1] = (uint8_t)(iv >> 8); dst[2] = (uint8_t)(iv >> 16); }
+    }
+    if (k == k1) { a.state[2 * sidx] = e1; a.state[2 * sidx + 1] = e2; }   // the open segment's state travels on
+    if (pk > 0.0) atomicMax(reinterpret_cast<unsigned long long*>(job.peak), (unsigned long long)__double_as_longlong(pk));
+}
+
 // new_hist[j] = stream byte (L - keep + j), j in [0, keep)
 __global__ void d2d_history_kernel(const StreamJob* jobs, uint32_t C, uint32_t B, uint32_t keep) {
     const StreamJob job = jobs[blockIdx.x];
@@ -447,6 +495,13 @@ hipError_t launch_deinterleave(const StreamJob* jobs, uint32_t nfiles, uint32_t 
     hipError_t e = prep.max_dynamic_lds(reinterpret_cast<const void*>(&d2d_deinterleave_kernel), 80 * 1024);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(d2d_deinterleave_kernel, dim3(gx, nfiles), dim3(256), (size_t)di_lds_bytes(C), s, jobs, C, spf);
+    return hipGetLastError();
+}
+
+hipError_t launch_noise_shape(const NoiseShapeArgs& a, hipStream_t s) {
+    if (a.nstreams == 0) return hipSuccess;
+    const uint32_t max_seg = (a.max_nout >> NS_SEG_BITS) + 2;                 // segments one call can touch
+    hipLaunchKernelGGL(d2d_noise_shape_kernel, dim3((max_seg + 63) / 64, a.nstreams), dim3(64), 0, s, a);
     return hipGetLastError();
 }
 

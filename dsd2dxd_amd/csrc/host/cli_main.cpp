@@ -118,6 +118,7 @@ int main(int argc, char** argv) {
         DitherType dt;
         switch (tolower(dither)) { case 't': dt = DitherType::TPDF; break; case 'r': dt = DitherType::Rectangular; break;
             case 'f': dt = DitherType::FPD; break; case 'x': dt = DitherType::None; break;
+            case 'n': dt = DitherType::NoiseShaped; break;                 // extension: noise-shaped TPDF
             default: throw std::runtime_error("Invalid dither type; must be T, R, F, or X"); }
         FmtType ft;
         switch (tolower(fmt)) { case 'i': ft = FmtType::Interleaved; break; case 'p': ft = FmtType::Planar; break;

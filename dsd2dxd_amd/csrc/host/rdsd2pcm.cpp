@@ -47,7 +47,7 @@ struct Rdsd2Pcm::Impl {
     int artwork_copied = 0;
 };
 
-static uint32_t dither_code(DitherType d) { return d == DitherType::TPDF ? 'T' : d == DitherType::Rectangular ? 'R' : d == DitherType::FPD ? 'F' : 'X'; }
+static uint32_t dither_code(DitherType d) { return d == DitherType::TPDF ? 'T' : d == DitherType::Rectangular ? 'R' : d == DitherType::FPD ? 'F' : d == DitherType::NoiseShaped ? 'N' : 'X'; }
 static uint32_t filter_code(FilterType f) { return f == FilterType::Equiripple ? 'E' : f == FilterType::XLD ? 'X' : f == FilterType::Dsd2Pcm ? 'D' : 'C'; }
 
 static std::string dirname_of(const std::string& p) { size_t s = p.find_last_of('/'); return s == std::string::npos ? "." : (s == 0 ? "/" : p.substr(0, s)); }

@@ -25,7 +25,8 @@ int fail(const std::exception& ex) {
 }
 DitherType dither_of(uint32_t c) {
     switch (c) { case 'T': case 't': return DitherType::TPDF; case 'R': case 'r': return DitherType::Rectangular;
-                 case 'F': case 'f': return DitherType::FPD; case 'X': case 'x': return DitherType::None; }
+                 case 'F': case 'f': return DitherType::FPD; case 'X': case 'x': return DitherType::None;
+                 case 'N': case 'n': return DitherType::NoiseShaped; }                       // extension
     throw std::runtime_error("Invalid dither type; must be T, R, F, or X");           // src/main.rs:176-180
 }
 FmtType fmt_of(uint32_t c) {

@@ -20,7 +20,8 @@
 
 namespace rdsd2pcm {
 
-enum class DitherType { TPDF, Rectangular, FPD, None };           // src/main.rs:172-175
+enum class DitherType { TPDF, Rectangular, FPD, None,              // src/main.rs:172-175
+                        NoiseShaped };                            // extension ('N'): see dsd2dxd_amd.h
 enum class FmtType { Interleaved, Planar };                       // src/main.rs:185-186
 enum class Endianness { LsbFirst, MsbFirst };                     // src/main.rs:194-196
 enum class FilterType { Equiripple, XLD, Dsd2Pcm, Chebyshev };    // src/main.rs:200-204

@@ -18,7 +18,7 @@ pub struct ProgressUpdate {
 }
 
 #[derive(Clone, Copy, Debug, PartialEq, Eq)]
-pub enum DitherType { TPDF, Rectangular, FPD, None } // src/main.rs:172-175
+pub enum DitherType { TPDF, Rectangular, FPD, None, /* extension: */ NoiseShaped } // src/main.rs:172-175
 #[derive(Clone, Copy, Debug, PartialEq, Eq)]
 pub enum FmtType { Interleaved, Planar } // src/main.rs:185-186
 #[derive(Clone, Copy, Debug, PartialEq, Eq)]
@@ -28,7 +28,7 @@ pub enum FilterType { Equiripple, XLD, Dsd2Pcm, Chebyshev } // src/main.rs:200-2
 #[derive(Clone, Copy, Debug, PartialEq, Eq)]
 pub enum OutputType { Stdout, Aiff, Aifc, Wav, Flac } // src/main.rs:208-213
 
-impl DitherType { fn code(self) -> u32 { match self { Self::TPDF => b'T', Self::Rectangular => b'R', Self::FPD => b'F', Self::None => b'X' } as u32 } }
+impl DitherType { fn code(self) -> u32 { match self { Self::TPDF => b'T', Self::Rectangular => b'R', Self::FPD => b'F', Self::None => b'X', Self::NoiseShaped => b'N' } as u32 } }
 impl FmtType { fn code(self) -> u32 { match self { Self::Interleaved => b'I', Self::Planar => b'P' } as u32 } }
 impl Endianness { fn code(self) -> u32 { match self { Self::LsbFirst => b'L', Self::MsbFirst => b'M' } as u32 } }
 impl FilterType { fn code(self) -> u32 { match self { Self::Equiripple => b'E', Self::XLD => b'X', Self::Dsd2Pcm => b'D', Self::Chebyshev => b'C' } as u32 } }

@@ -41,6 +41,7 @@ struct orc_ctx {
     double* xhist;    /* C x P   last P stage-A outputs (48k only) */
     uint64_t nres;    /* stage-B outputs so far */
     double* peak;     /* C */
+    double* ns_err;   /* C x 2: the last two requantisation errors of the noise shaper ('N') */
 };
 
 static uint8_t bitrev8(uint8_t v) {
@@ -114,7 +115,7 @@ int orc_create(const orc_params* p, orc_ctx** out, const char** err) {
     *out = NULL;
     if (p->channels < 1 || p->channels > 64) { *err = "Invalid channel count"; return -4; }
     if (p->bit_depth != 16 && p->bit_depth != 20 && p->bit_depth != 24 && p->bit_depth != 32) { *err = "Invalid bit depth; must be 16, 20, 24 or 32"; return -5; }
-    if (p->dither != 'T' && p->dither != 'R' && p->dither != 'F' && p->dither != 'X') { *err = "Invalid dither type; must be T, R, F, or X"; return -6; } /* src/main.rs:176-180 */
+    if (p->dither != 'T' && p->dither != 'R' && p->dither != 'F' && p->dither != 'X' && p->dither != 'N') { *err = "Invalid dither type; must be T, R, F, or X"; return -6; } /* src/main.rs:176-180 */
     if (p->fmt > 1) { *err = "Invalid format; must be I (interleaved) or P (planar)"; return -7; }  /* src/main.rs:187-190 */
     if (p->fmt == 1 && p->block_size == 0) { *err = "Invalid block size"; return -8; }
     const d2d_filter_def* f; const d2d_resamp_def* r;
@@ -149,13 +150,14 @@ int orc_create(const orc_params* p, orc_ctx** out, const char** err) {
     memset(c->hist_raw, p->endianness ? IDLE_BYTE : bitrev8(IDLE_BYTE), c->keep * c->C);
     if (r) c->xhist = (double*)calloc((size_t)r->P * c->C, sizeof(double));
     c->peak = (double*)calloc(c->C, sizeof(double));
+    c->ns_err = (double*)calloc((size_t)c->C * 2, sizeof(double));
     *out = c;
     return 0;
 }
 
 void orc_destroy(orc_ctx* c) {
     if (!c) return;
-    free(c->taps); free(c->lut); free(c->hist_raw); free(c->xhist); free(c->peak); free(c);
+    free(c->taps); free(c->lut); free(c->hist_raw); free(c->xhist); free(c->peak); free(c->ns_err); free(c);
 }
 
 size_t orc_frame_bytes(const orc_ctx* c) {
@@ -216,7 +218,7 @@ static double fir_lut(const orc_ctx* c, const uint8_t* canon, const uint8_t* can
 /* Dither + requantise one sample.  `v` = FIR (or cascade) output times the level gain.
  * Depths and containers: src/main.rs:58-60, build_test_*.sh (s16le/s24le/f32le; 20 bit in 24).
  * Dither kinds: src/main.rs:171-181, README.md:11-12,236. */
-static void emit_sample(const orc_ctx* c, double y, uint32_t ch, uint64_t n, uint8_t* dst) {
+static void emit_sample(orc_ctx* c, double y, uint32_t ch, uint64_t n, uint8_t* dst) {
     uint32_t bits = c->p.bit_depth;
     uint32_t rnd = orc_rng(c->p.seed, ch, n);
     if (bits == 32) {
@@ -241,12 +243,32 @@ static void emit_sample(const orc_ctx* c, double y, uint32_t ch, uint64_t n, uin
     double d = 0.0;
     /* the word's two 16-bit halves are the two uniforms of the triangular pdf; both forms are
      * symmetric about zero, so the dither adds no DC */
-    if (c->p.dither == 'T') d = (double)((rnd & 0xFFFFu) + (rnd >> 16) + 1u) * 0x1p-16 - 1.0;   /* triangular, +-1 LSB */
+    if (c->p.dither == 'T' || c->p.dither == 'N') d = (double)((rnd & 0xFFFFu) + (rnd >> 16) + 1u) * 0x1p-16 - 1.0;   /* triangular, +-1 LSB */
     else if (c->p.dither == 'R') d = (double)(2u * (rnd >> 16) + 1u) * 0x1p-17 - 0.5;          /* rectangular, +-1/2 LSB */
     /* [own] 'F' at an integer depth: no dither */
-    double q = x + d;
+    /* [own] 'N': TPDF dither inside a second-order error-feedback loop, noise transfer function
+     * (1 - z^-1)^2 (an extension: the reference CLI offers T/R/F/X only, src/main.rs:171-181; BASELINE
+     * config 3 and the north star ask for a noise-shaped variant).  Per channel, in output order:
+     *   w = x - (2*e1 - e2);  r = round(w + d);  e = r - w  (taken before clipping);  e2 = e1; e1 = e.
+     * Every operation is one IEEE f64 operation in this order.  The loop restarts from e1 = e2 = 0 at
+     * every output index that is a multiple of 65536 (0.74 s at 88.2 kHz): the segments are then
+     * independent of each other, which is what lets a GPU run them side by side; the restart adds
+     * white noise 41 dB below one LSB of white noise, far under the shaped in-band floor. */
+    double w = x;
+    if (c->p.dither == 'N') {
+        double* e = c->ns_err + 2 * (size_t)ch;
+        if ((n & 65535u) == 0) e[0] = e[1] = 0.0;
+        double fb = 2.0 * e[0] - e[1];
+        w = x - fb;
+    }
+    double q = w + d;
     /* [lineage] dsd2pcm main.cpp rounds half away from zero and clips */
     double r = q >= 0.0 ? floor(q + 0.5) : ceil(q - 0.5);
+    if (c->p.dither == 'N') {
+        double* e = c->ns_err + 2 * (size_t)ch;
+        e[1] = e[0];
+        e[0] = r - w;
+    }
     double lim = ldexp(1.0, (int)bits - 1);
     if (r > lim - 1.0) r = lim - 1.0;
     if (r < -lim) r = -lim;

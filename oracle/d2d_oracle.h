@@ -37,7 +37,7 @@ typedef struct {
     uint32_t block_size;   /* bytes per channel per block (planar)    (src/main.rs:75-78,335)   */
     uint32_t filter;       /* 'E','X','D','C'                         (src/main.rs:199-205)     */
     uint32_t bit_depth;    /* 16,20,24 int; 32 float                  (src/main.rs:58-60)       */
-    uint32_t dither;       /* 'T','R','F','X'                         (src/main.rs:171-181)     */
+    uint32_t dither;       /* 'T','R','F','X' (src/main.rs:171-181); 'N' = noise-shaped TPDF, an extension   */
     uint32_t fir_mode;     /* 0 = direct bit-by-bit form, 1 = byte-LUT form (dsd2pcm lineage)   */
     double   level_db;     /*                                         (src/main.rs:107-110,328) */
     uint64_t seed;         /* dither seed (the reference's seeding is unknown; see header)      */

@@ -177,3 +177,45 @@ def test_known_answers_on_device(engine_lib, kernel):
     e.reset()
     g, fr = e.translate(np.zeros(4096 * 4, dtype=np.uint8))
     assert (decode_pcm(g, 24, 1)[200:, 0] == -8388608).all()
+
+
+@pytest.mark.parametrize("kernel", KERNELS)
+@pytest.mark.parametrize("dsd_rate,out_rate,bits,level", [(1, 88200, 16, 0.0), (2, 88200, 24, -2.0), (1, 176400, 20, 0.0), (1, 352800, 16, 30.0)])
+def test_noise_shaped_dither_matches_the_oracle(engine_lib, oracle_mod, dsd_rate, out_rate, bits, level, kernel):
+    """the 'N' extension (BASELINE config 3 names a noise-shaped variant): an error-feedback loop per
+    channel, carried across calls and files, identical to the oracle's sequential loop, clipping included"""
+    nbytes = 4096 * 4 + 90
+    chans = [synth("sine", nbytes, seed=1, dsd_rate=dsd_rate, amp=0.5), synth("pink", nbytes, seed=2, amp=0.098, dsd_rate=dsd_rate)]
+    cuts = [0, 4096, 4096 * 3, nbytes]
+    bufs = [pack_layout([ch[a:b] for ch in chans], "P", 4096) for a, b in zip(cuts[:-1], cuts[1:])]
+    kw = dict(dsd_rate=dsd_rate, output_rate=out_rate, channels=2, fmt="P", endianness="L", block_size=4096,
+              filter="E", bit_depth=bits, dither="N", seed=21, level_db=level)
+    g, r, e, o = run_pair(engine_lib, oracle_mod, bufs, kw, kernel)
+    assert np.array_equal(g, r)
+    assert e.peak_dbfs() == o.peak_dbfs()
+    # the same conversion with plain TPDF differs (the loop is really in the path) ...
+    kw_t = dict(kw, dither="T")
+    g_t, _, _, _ = run_pair(engine_lib, oracle_mod, bufs, kw_t, kernel)
+    assert not np.array_equal(g, g_t)
+    # ... float output has nothing to shape, and the 48 kHz family refuses the option
+    e32 = engine_lib.Engine(n_files=1, kernel=kernel, **dict(kw, bit_depth=32))
+    x32 = engine_lib.Engine(n_files=1, kernel=kernel, **dict(kw, bit_depth=32, dither="X"))
+    assert np.array_equal(e32.translate(bufs[0])[0], x32.translate(bufs[0])[0])
+    with pytest.raises(engine_lib.D2DError, match="44.1 kHz-family"):
+        engine_lib.Engine(n_files=1, kernel=kernel, **dict(kw, dsd_rate=1, output_rate=96000))
+
+
+@pytest.mark.parametrize("kernel", KERNELS)
+def test_noise_shaped_segments_restart_and_carry(engine_lib, oracle_mod, kernel):
+    """the shaper restarts at output indices that are multiples of 65536: calls that end inside a segment,
+    start exactly on a boundary, or span two boundaries all match the oracle"""
+    nbytes = 65536 * 2 + 5000                             # M = 8: one output per byte, 136072 outputs per channel
+    chans = [synth("sine", nbytes, seed=3, msb_first=True, amp=0.4), synth("pink", nbytes, seed=4, amp=0.098, msb_first=True)]
+    cuts = [0, 30000, 65536, 65537, 131071, 135000, nbytes]
+    bufs = [pack_layout([ch[a:b] for ch in chans], "I", 1) for a, b in zip(cuts[:-1], cuts[1:])]
+    kw = dict(dsd_rate=1, output_rate=352800, channels=2, fmt="I", endianness="M", block_size=1,
+              filter="E", bit_depth=16, dither="N", seed=5)
+    g, r, e, o = run_pair(engine_lib, oracle_mod, bufs, kw, kernel)
+    assert np.array_equal(g, r)
+    one, r1, _, _ = run_pair(engine_lib, oracle_mod, [pack_layout(chans, "I", 1)], kw, kernel)
+    assert np.array_equal(one, g)                          # one call (three segments side by side) == six calls

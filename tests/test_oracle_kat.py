@@ -229,3 +229,41 @@ def test_parameter_errors(oracle_mod):
     for kw in [dict(dsd_rate=2, output_rate=705600), dict(dsd_rate=4, output_rate=1411200), dict(dsd_rate=8, output_rate=352800),
                dict(dsd_rate=1, output_rate=352800, filter="D"), dict(dsd_rate=2, output_rate=176400, filter="C")]:
         oracle_mod.Oracle(**kw)
+
+
+def test_noise_shaped_dither_moves_the_error_out_of_band(oracle_mod):
+    """'N' (extension): TPDF dither inside a second-order error-feedback loop with NTF (1 - z^-1)^2.  The
+    requantisation error against the float conversion falls at low frequencies and rises towards Nyquist;
+    the loop follows w = x - (2 e1 - e2), r = round(w + d), e = r - w exactly."""
+    n = 4096 * 16
+    buf = pack_layout([synth("sine", n, seed=1, amp=0.3), synth("sine", n, seed=2, amp=0.3, freq=3000.0)], "P", 4096)
+    kw = dict(dsd_rate=1, output_rate=88200, channels=2, fmt="P", endianness="L", block_size=4096, seed=3)
+    ref, rf = oracle_mod.Oracle(dither="X", bit_depth=32, **kw).translate(buf)
+    x = decode_pcm(ref[:rf * 8], 32, 2).astype(np.float64) * 32768.0
+
+    def err(d):
+        r, rf2 = oracle_mod.Oracle(dither=d, bit_depth=16, **kw).translate(buf)
+        return decode_pcm(r[:rf2 * 4], 16, 2).astype(np.float64) - x
+
+    def band(e, lo, hi):
+        E = np.abs(np.fft.rfft(e[2000:, 0] * np.hanning(len(e) - 2000))) ** 2
+        f = np.fft.rfftfreq(len(e) - 2000, 1 / 88200.0)
+        return 10 * np.log10(E[(f > lo) & (f < hi)].mean())
+    et, en = err("T"), err("N")
+    assert band(en, 200, 4000) < band(et, 200, 4000) - 20          # in-band noise at least 20 dB down
+    assert band(en, 30000, 44100) > band(et, 30000, 44100) + 6     # paid for near Nyquist
+    assert abs(en[2000:].mean()) < 0.02                              # no DC offset
+    # the loop itself, replayed in numpy on channel 0 from the oracle's own pre-dither samples
+    o = oracle_mod.Oracle(dither="N", bit_depth=16, **kw)
+    r, rf2, pre = o.translate(buf, want_f64=True)
+    got = decode_pcm(r[:rf2 * 4], 16, 2)[:, 0]
+    xs = pre.reshape(-1, 2)[:, 0] * 32768.0
+    e1 = e2 = 0.0
+    for i in range(400):                                              # (the loop restarts at multiples of 65536)
+        z = oracle_mod.rng(3, 0, i)
+        d = ((z & 0xFFFF) + (z >> 16) + 1) * 2.0 ** -16 - 1.0
+        w = xs[i] - (2.0 * e1 - e2)
+        q = w + d
+        rr = np.floor(q + 0.5) if q >= 0 else np.ceil(q - 0.5)
+        e2, e1 = e1, rr - w
+        assert got[i] == int(rr), i
