@@ -222,7 +222,7 @@ def test_parameter_errors(oracle_mod):
            dict(dsd_rate=2, output_rate=88200, filter="X"), dict(dsd_rate=1, output_rate=88200, filter="D"),
            dict(dsd_rate=1, output_rate=88200, filter="C"), dict(dsd_rate=1, output_rate=96000, filter="X"),
            dict(dsd_rate=1, output_rate=44100), dict(dsd_rate=3, output_rate=88200), dict(output_rate=88200, bit_depth=8),
-           dict(output_rate=88200, dither="N")]
+           dict(output_rate=88200, dither="Q")]
     for kw in bad:
         with pytest.raises(oracle_mod.OracleError):
             oracle_mod.Oracle(**kw)
