@@ -27,6 +27,8 @@ def _case(seed):
     block = int(rng.choice([4096, 4096, 1024, 256, 48, 7])) if fmt == "P" else 1
     endian = str(rng.choice(["L", "M"]))
     level = float(rng.choice([0.0, 0.0, -3.0, 4.0, -0.5]))
+    if out_rate % 44100 == 0 and rng.integers(5) == 0:     # drawn last so the other parameters of a seed stay what they were
+        dither = "N"                                        # the noise-shaped extension (44.1 kHz family only)
     kw = dict(dsd_rate=dsd_rate, output_rate=out_rate, channels=channels, fmt=fmt, endianness=endian, block_size=block,
               filter=str(filt), bit_depth=bits, dither=dither, seed=int(rng.integers(1 << 30)), level_db=level)
     total = int(rng.integers(2000, 30000))

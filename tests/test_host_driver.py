@@ -308,7 +308,7 @@ def test_levels_tool_and_error_exit(cli, oracle_mod, tmp_path):
     # errors: message on stderr, failure exit code (src/lib.rs:26-35)
     p = subprocess.run([cli, "-r", "705600", "-o", "w", pa], stderr=subprocess.PIPE)
     assert p.returncode == 1 and b"705600 output needs DSD128 or DSD256 input" in p.stderr
-    p = subprocess.run([cli, "-d", "N", pa], stderr=subprocess.PIPE)
+    p = subprocess.run([cli, "-d", "Q", pa], stderr=subprocess.PIPE)
     assert p.returncode == 1 and b"Invalid dither type; must be T, R, F, or X" in p.stderr
 
 
