@@ -365,8 +365,11 @@ __global__ __launch_bounds__(64) void d2d_noise_shape_kernel(NoiseShapeArgs a) {
     const bool carried = seg_lo < job.n0;                                  // begun in an earlier call
     double e1 = carried ? a.state[2 * sidx] : 0.0, e2 = carried ? a.state[2 * sidx + 1] : 0.0, pk = 0.0;
     const double lim = (double)(1u << (a.epi.bits - 1));
-    for (uint32_t i = i0; i < i1; ++i) {
-        const double y = ldexp((double)xs[i], -a.scale_bits);            // exact
+    // few waves are resident (outputs/65536 threads per stream), so nothing hides a global load's
+    // latency but the thread itself: the integers are fetched NS_AHEAD at a time, then walked
+    constexpr uint32_t NS_AHEAD = 16;
+    auto step = [&](int32_t X, uint32_t i) {
+        const double y = ldexp((double)X, -a.scale_bits);                // exact
         pk = fmax(pk, fabs(y * a.epi.gain));
         const double x = y * a.epi.scale;
         const uint32_t rnd = rng32(job, job.n0 + i);
@@ -382,7 +385,16 @@ __global__ __launch_bounds__(64) void d2d_noise_shape_kernel(NoiseShapeArgs a) {
         uint8_t* dst = out + (size_t)i * frame_bytes;
         if (a.epi.bits == 16) { *reinterpret_cast<uint16_t*>(dst) = (uint16_t)iv; }
         else { dst[0] = (uint8_t)iv; dst[1] = (uint8_t)(iv >> 8); dst[2] = (uint8_t)(iv >> 16); }
+    };
+    uint32_t i = i0;
+    for (; i + NS_AHEAD <= i1; i += NS_AHEAD) {
+        int32_t v[NS_AHEAD];
+#pragma unroll
+        for (uint32_t u = 0; u < NS_AHEAD; ++u) v[u] = xs[i + u];
+#pragma unroll
+        for (uint32_t u = 0; u < NS_AHEAD; ++u) step(v[u], i + u);
     }
+    for (; i < i1; ++i) step(xs[i], i);
     if (k == k1) { a.state[2 * sidx] = e1; a.state[2 * sidx + 1] = e2; }   // the open segment's state travels on
     if (pk > 0.0) atomicMax(reinterpret_cast<unsigned long long*>(job.peak), (unsigned long long)__double_as_longlong(pk));
 }
