@@ -57,6 +57,7 @@ struct MfmaArgs {
     // integer-depth epilogue as data: d = fma(term, dmul, dadd), clamp to [qmin_i, qmax_i], << qsh
     double dmul, dadd;
     uint32_t dsel;        // 1: triangular term, 0: rectangular term
+    uint32_t dkind;       // 0: no dither, 1: triangular, 2: rectangular (chooses the register epilogue's instantiation)
     uint32_t qsh;         // 4 for 20-bit samples in a 24-bit container, else 0
     int32_t qmin_i, qmax_i;
     uint32_t wide;        // 1: limb sums may exceed 2^23, recombine in f64
@@ -426,7 +427,7 @@ __global__ __launch_bounds__(MFMA_MAX_THREADS, 3) void d2d_fir_mfma_kernel(MfmaA
                     }
                 }
             };
-            const bool reg_store = full && two && Cs == 2 && sb == 3 && m.qsh == 0 && !a.to_scratch;
+            const bool reg_store = full && two && Cs == 2 && sb == 3 && m.qsh == 0 && !m.wide && !a.to_scratch;
             if (dbg & 2) { if (acc0[0] == 0x12345 && acc1[5] == 77 && acc0[9] + acc1[13] + acc0[15] + acc1[2] == 99) outw[lane] = 1; }
             else if (reg_store) {
                 // Stereo 24-bit, whole tile: no LDS round trip.  Lane (r, h) owns frames 4h .. 4h+3 of
@@ -434,57 +435,66 @@ __global__ __launch_bounds__(MFMA_MAX_THREADS, 3) void d2d_fir_mfma_kernel(MfmaA
                 // and the wave stores 1536 contiguous bytes.
                 // (frame by frame, both channels together: two independent sample pipelines in flight
                 // and only the six packed output words stay live)
-                const uint32_t key0 = rngw[c0 * 4], st0 = rngw[c0 * 4 + 1], lo00 = rngw[c0 * 4 + 2];
-                const uint32_t key1 = rngw[c1 * 4], st1 = rngw[c1 * 4 + 1], lo01 = rngw[c1 * 4 + 2];
-                double pk0 = pkw[c0 * 64 + lane], pk1 = pkw[c1 * 64 + lane];
-                const int32_t qmax_v = m.qmax_i;
-                auto one = [&](const v16i& acc, int k, uint32_t key, uint32_t stp, uint32_t lo0, double& pk) -> uint32_t {
-                    double accd;
-                    if (m.wide) {
-                        accd = fma((double)acc[4 * k + 3], 16777216.0,
-                                   fma((double)acc[4 * k + 2], 65536.0, fma((double)acc[4 * k + 1], 256.0, (double)acc[4 * k])));
-                    } else {
-                        accd = fma((double)(acc[4 * k + 2] + (acc[4 * k + 3] << 8)), 65536.0, (double)(acc[4 * k] + (acc[4 * k + 1] << 8)));
+                // The dither kind is fixed per launch: the body is instantiated per kind and chosen ONCE per
+                // tile, so the eight sample pipelines sit in one basic block (a per-sample branch on a
+                // uniform flag would cut the block there and stop the scheduler from interleaving them).
+                auto body = [&](auto kind_tag) {
+                    constexpr int KIND = decltype(kind_tag)::value;       // 0 none, 1 triangular, 2 rectangular
+                    const uint32_t key0 = rngw[c0 * 4], st0 = rngw[c0 * 4 + 1], lo00 = rngw[c0 * 4 + 2];
+                    const uint32_t key1 = rngw[c1 * 4], st1 = rngw[c1 * 4 + 1], lo01 = rngw[c1 * 4 + 2];
+                    double pk0 = pkw[c0 * 64 + lane], pk1 = pkw[c1 * 64 + lane];
+                    const int32_t qmax_v = m.qmax_i;
+                    auto one = [&](const v16i& acc, int k, uint32_t key, uint32_t stp, uint32_t lo0, double& pk) -> uint32_t {
+                        // (narrow recombination: the wide case does not take this path)
+                        const double accd = fma((double)(acc[4 * k + 2] + (acc[4 * k + 3] << 8)), 65536.0, (double)(acc[4 * k] + (acc[4 * k + 1] << 8)));
+                        const double x = fma(accd, m.c1, -m.c0);
+                        asm("v_max_f64 %0, %1, |%2|" : "=v"(pk) : "v"(pk), "v"(x));
+                        double q = x;
+                        if constexpr (KIND != 0) {
+                            const uint32_t nlo = (uint32_t)j0.n0 + wt * 256u + (8 * r + 4 * h + k);
+                            uint32_t z = nlo + key + (nlo < lo0 ? stp : 0u);
+                            z ^= z >> 16; z *= 0x7feb352dU;
+                            z ^= z >> 15; z *= 0x846ca68bU;
+                            z ^= z >> 16;
+                            const uint32_t term = KIND == 1 ? (z & 0xFFFFu) + (z >> 16) + 1u : 2u * (z >> 16) + 1u;
+                            q = x + fma((double)term, m.dmul, m.dadd);
+                        } else {
+                            q = x + 0.0;                                    // what quantise_int() does for "none" (a -0 becomes +0)
+                        }
+                        // round half away from zero: the conversion itself truncates toward zero (and saturates),
+                        // the clip is one integer med3 (one bound has to sit in a VGPR: one SGPR per VOP3 on gfx9)
+                        int32_t ri, o;
+                        const double t = q + copysign(0.5, q);
+                        asm("v_cvt_i32_f64 %0, %1" : "=v"(ri) : "v"(t));
+                        asm("v_med3_i32 %0, %1, %2, %3" : "=v"(o) : "v"(ri), "s"(m.qmin_i), "v"(qmax_v));
+                        return (uint32_t)o;                                   // (qsh == 0 on this path)
+                    };
+                    // frames k, k+1 -> 12 bytes: [L0 L1 L2 R0 | R1 R2 L0' L1' | L2' R0' R1' R2']
+                    uint32_t w0, w1, w2, w3, w4, w5;
+                    {
+                        const uint32_t La = one(acc0, 0, key0, st0, lo00, pk0), Ra = one(acc1, 0, key1, st1, lo01, pk1);
+                        const uint32_t Lb = one(acc0, 1, key0, st0, lo00, pk0), Rb = one(acc1, 1, key1, st1, lo01, pk1);
+                        w0 = __builtin_amdgcn_perm(Ra, La, 0x04020100u);
+                        w1 = __builtin_amdgcn_perm(Lb, Ra, 0x05040201u);
+                        w2 = __builtin_amdgcn_perm(Rb, Lb, 0x06050402u);
                     }
-                    const double x = fma(accd, m.c1, -m.c0);
-                    asm("v_max_f64 %0, %1, |%2|" : "=v"(pk) : "v"(pk), "v"(x));
-                    const uint32_t nlo = (uint32_t)j0.n0 + wt * 256u + (8 * r + 4 * h + k);
-                    uint32_t z = nlo + key + (nlo < lo0 ? stp : 0u);
-                    z ^= z >> 16; z *= 0x7feb352dU;
-                    z ^= z >> 15; z *= 0x846ca68bU;
-                    z ^= z >> 16;
-                    const uint32_t term = m.dsel ? (z & 0xFFFFu) + (z >> 16) + 1u : 2u * (z >> 16) + 1u;
-                    const double q = x + fma((double)term, m.dmul, m.dadd);
-                    // round half away from zero: the conversion itself truncates toward zero (and saturates),
-                    // the clip is one integer med3 (one bound has to sit in a VGPR: one SGPR per VOP3 on gfx9)
-                    int32_t ri, o;
-                    const double t = q + copysign(0.5, q);
-                    asm("v_cvt_i32_f64 %0, %1" : "=v"(ri) : "v"(t));
-                    asm("v_med3_i32 %0, %1, %2, %3" : "=v"(o) : "v"(ri), "s"(m.qmin_i), "v"(qmax_v));
-                    return (uint32_t)o;                                   // (qsh == 0 on this path)
+                    {
+                        const uint32_t La = one(acc0, 2, key0, st0, lo00, pk0), Ra = one(acc1, 2, key1, st1, lo01, pk1);
+                        const uint32_t Lb = one(acc0, 3, key0, st0, lo00, pk0), Rb = one(acc1, 3, key1, st1, lo01, pk1);
+                        w3 = __builtin_amdgcn_perm(Ra, La, 0x04020100u);
+                        w4 = __builtin_amdgcn_perm(Lb, Ra, 0x05040201u);
+                        w5 = __builtin_amdgcn_perm(Rb, Lb, 0x06050402u);
+                    }
+                    pkw[c0 * 64 + lane] = pk0; pkw[c1 * 64 + lane] = pk1;
+                    const u32x4 o4 = {w0, w1, w2, w3};
+                    const u32x2 o2 = {w4, w5};
+                    uint8_t* g = reinterpret_cast<uint8_t*>(j0.out) + (size_t)wt * 1536 + 48u * r + 24u * h;
+                    *reinterpret_cast<D2D_GLOBAL u32x4*>(as_global(g)) = o4;
+                    *reinterpret_cast<D2D_GLOBAL u32x2*>(as_global(g + 16)) = o2;
                 };
-                // frames k, k+1 -> 12 bytes: [L0 L1 L2 R0 | R1 R2 L0' L1' | L2' R0' R1' R2']
-                uint32_t w0, w1, w2, w3, w4, w5;
-                {
-                    const uint32_t La = one(acc0, 0, key0, st0, lo00, pk0), Ra = one(acc1, 0, key1, st1, lo01, pk1);
-                    const uint32_t Lb = one(acc0, 1, key0, st0, lo00, pk0), Rb = one(acc1, 1, key1, st1, lo01, pk1);
-                    w0 = __builtin_amdgcn_perm(Ra, La, 0x04020100u);
-                    w1 = __builtin_amdgcn_perm(Lb, Ra, 0x05040201u);
-                    w2 = __builtin_amdgcn_perm(Rb, Lb, 0x06050402u);
-                }
-                {
-                    const uint32_t La = one(acc0, 2, key0, st0, lo00, pk0), Ra = one(acc1, 2, key1, st1, lo01, pk1);
-                    const uint32_t Lb = one(acc0, 3, key0, st0, lo00, pk0), Rb = one(acc1, 3, key1, st1, lo01, pk1);
-                    w3 = __builtin_amdgcn_perm(Ra, La, 0x04020100u);
-                    w4 = __builtin_amdgcn_perm(Lb, Ra, 0x05040201u);
-                    w5 = __builtin_amdgcn_perm(Rb, Lb, 0x06050402u);
-                }
-                pkw[c0 * 64 + lane] = pk0; pkw[c1 * 64 + lane] = pk1;
-                const u32x4 o4 = {w0, w1, w2, w3};
-                const u32x2 o2 = {w4, w5};
-                uint8_t* g = reinterpret_cast<uint8_t*>(j0.out) + (size_t)wt * 1536 + 48u * r + 24u * h;
-                *reinterpret_cast<D2D_GLOBAL u32x4*>(as_global(g)) = o4;
-                *reinterpret_cast<D2D_GLOBAL u32x2*>(as_global(g + 16)) = o2;
+                if (m.dkind == 1) body(std::integral_constant<int, 1>{});
+                else if (m.dkind == 2) body(std::integral_constant<int, 2>{});
+                else body(std::integral_constant<int, 0>{});
             }
             else if (full) {
                 finish(acc0, c0, std::true_type{}, nullptr);
@@ -605,6 +615,7 @@ static void mfma_geometry(const FirArgs& a, const MfmaLayout& g, MfmaArgs& m, si
     m.c0 = a.to_scratch ? ldexp(1.0, a.scale_bits) : (a.epi.bits == 32 ? a.epi.gain : a.epi.scale);   // scratch: the integer y*2^S
     m.c1 = ldexp(m.c0, 1 - a.scale_bits - 7);     // exact: a power-of-two multiple of c0
     m.dsel = a.epi.dither == 'T' ? 1u : 0u;
+    m.dkind = a.epi.dither == 'T' ? 1u : (a.epi.dither == 'R' ? 2u : 0u);
     m.dmul = a.epi.dither == 'T' ? 0x1p-16 : (a.epi.dither == 'R' ? 0x1p-17 : 0.0);
     m.dadd = a.epi.dither == 'T' ? -1.0 : (a.epi.dither == 'R' ? -0.5 : 0.0);
     m.qsh = a.epi.bits == 20 ? 4u : 0u;
