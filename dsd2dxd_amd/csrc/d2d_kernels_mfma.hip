@@ -350,16 +350,17 @@ __global__ __launch_bounds__(MFMA_MAX_THREADS, 3) void d2d_fir_mfma_kernel(MfmaA
             stamp(2);
 
             // ---- epilogue: lane (r, h) owns phases ph = h + 2k of row r for both channels ----
-            auto finish = [&](const v16i& acc, uint32_t c, auto full_tag, int32_t* iv_out) {
+            // (the flags that are fixed per launch -- wide recombination, stage-A scratch output -- arrive as
+            // tags and are dispatched once per tile, so that the four samples of a lane share a basic block)
+            auto finish = [&](const v16i& acc, uint32_t c, auto full_tag, auto wide_tag, auto scratch_tag) {
                 constexpr bool FULL = decltype(full_tag)::value;
-                const uint32_t rkey = rngw[c * 4], rstep = rngw[c * 4 + 1], rlo0 = rngw[c * 4 + 2];
-                double pkx = pkw[c * 64 + lane];
+                constexpr bool WIDE = decltype(wide_tag)::value;
+                constexpr bool SCRATCH = decltype(scratch_tag)::value;
                 double xv[4];
-                uint32_t zv[4];
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     double accd;
-                    if (m.wide) {
+                    if constexpr (WIDE) {
                         accd = fma((double)acc[4 * k + 3], 16777216.0,
                                    fma((double)acc[4 * k + 2], 65536.0, fma((double)acc[4 * k + 1], 256.0, (double)acc[4 * k])));
                     } else {
@@ -368,20 +369,32 @@ __global__ __launch_bounds__(MFMA_MAX_THREADS, 3) void d2d_fir_mfma_kernel(MfmaA
                     }
                     // x = y*c0 with ONE rounding: acc*c1 - c0 is exactly y*c0 before the fma rounds
                     xv[k] = fma(accd, m.c1, -m.c0);
+                }
+                if constexpr (SCRATCH) {
+                    // stage A of the 48k cascade (or the input of the noise-shaping pass): the exact integers
+                    // y * 2^S; a lane's four frames are consecutive, one 16-byte store
+                    const uint32_t nl0 = wt * 256u + (8 * r + 4 * h);
+                    typedef int32_t i32x4 __attribute__((ext_vector_type(4)));
+                    if (FULL || nl0 + 3 < j0.nout) {
+                        *reinterpret_cast<D2D_GLOBAL i32x4*>(as_global(jobs[c].xs + nl0)) = i32x4{(int32_t)xv[0], (int32_t)xv[1], (int32_t)xv[2], (int32_t)xv[3]};
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k)
+                            if (nl0 + k < j0.nout) as_global(jobs[c].xs)[nl0 + k] = (int32_t)xv[k];
+                    }
+                    return;
+                }
+                const uint32_t rkey = rngw[c * 4], rstep = rngw[c * 4 + 1], rlo0 = rngw[c * 4 + 2];
+                double pkx = pkw[c * 64 + lane];
+                uint32_t zv[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
                     const uint32_t nlo = (uint32_t)j0.n0 + wt * 256u + (8 * r + 4 * h + k);
                     uint32_t z = nlo + rkey + (nlo < rlo0 ? rstep : 0u);
                     z ^= z >> 16; z *= 0x7feb352dU;
                     z ^= z >> 15; z *= 0x846ca68bU;
                     z ^= z >> 16;
                     zv[k] = z;
-                }
-                if (a.to_scratch) {
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        const uint32_t nl = wt * 256u + (8 * r + 4 * h + k);
-                        if (FULL || nl < j0.nout) as_global(jobs[c].xs)[nl] = (int32_t)xv[k];
-                    }
-                    return;
                 }
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
@@ -409,11 +422,6 @@ __global__ __launch_bounds__(MFMA_MAX_THREADS, 3) void d2d_fir_mfma_kernel(MfmaA
                         asm("v_cvt_i32_f64 %0, %1" : "=v"(ri) : "v"(t));
                         iv[k] = min(max(ri, m.qmin_i), m.qmax_i) << m.qsh;
                     }
-                    if (iv_out) {          // the caller packs and stores from registers
-#pragma unroll
-                        for (int k = 0; k < 4; ++k) iv_out[k] = iv[k];
-                        return;
-                    }
                     if (sb == 2) {
 #pragma unroll
                         for (int k = 0; k < 4; ++k)
@@ -426,6 +434,14 @@ __global__ __launch_bounds__(MFMA_MAX_THREADS, 3) void d2d_fir_mfma_kernel(MfmaA
                         }
                     }
                 }
+            };
+            auto finish_tile = [&](auto full_tag) {
+                auto both = [&](auto wide_tag, auto scratch_tag) {
+                    finish(acc0, c0, full_tag, wide_tag, scratch_tag);
+                    if (two) finish(acc1, c1, full_tag, wide_tag, scratch_tag);
+                };
+                if (a.to_scratch) { if (m.wide) both(std::true_type{}, std::true_type{}); else both(std::false_type{}, std::true_type{}); }
+                else { if (m.wide) both(std::true_type{}, std::false_type{}); else both(std::false_type{}, std::false_type{}); }
             };
             const bool reg_store = full && two && Cs == 2 && sb == 3 && m.qsh == 0 && !m.wide && !a.to_scratch;
             if (dbg & 2) { if (acc0[0] == 0x12345 && acc1[5] == 77 && acc0[9] + acc1[13] + acc0[15] + acc1[2] == 99) outw[lane] = 1; }
@@ -496,13 +512,8 @@ __global__ __launch_bounds__(MFMA_MAX_THREADS, 3) void d2d_fir_mfma_kernel(MfmaA
                 else if (m.dkind == 2) body(std::integral_constant<int, 2>{});
                 else body(std::integral_constant<int, 0>{});
             }
-            else if (full) {
-                finish(acc0, c0, std::true_type{}, nullptr);
-                if (two) finish(acc1, c1, std::true_type{}, nullptr);
-            } else {
-                finish(acc0, c0, std::false_type{}, nullptr);
-                if (two) finish(acc1, c1, std::false_type{}, nullptr);
-            }
+            else if (full) finish_tile(std::true_type{});
+            else finish_tile(std::false_type{});
             stored_from_regs = reg_store;
         }
         stamp(3);
