@@ -352,10 +352,11 @@ __global__ __launch_bounds__(MFMA_MAX_THREADS, 3) void d2d_fir_mfma_kernel(MfmaA
             // ---- epilogue: lane (r, h) owns phases ph = h + 2k of row r for both channels ----
             // (the flags that are fixed per launch -- wide recombination, stage-A scratch output -- arrive as
             // tags and are dispatched once per tile, so that the four samples of a lane share a basic block)
-            auto finish = [&](const v16i& acc, uint32_t c, auto full_tag, auto wide_tag, auto scratch_tag) {
+            auto finish = [&](const v16i& acc, uint32_t c, auto full_tag, auto wide_tag, auto scratch_tag, auto kind_tag) {
                 constexpr bool FULL = decltype(full_tag)::value;
                 constexpr bool WIDE = decltype(wide_tag)::value;
                 constexpr bool SCRATCH = decltype(scratch_tag)::value;
+                constexpr int KIND = decltype(kind_tag)::value;          // 0 no noise word needed, 1 triangular, 2 rectangular, 3 float FPD
                 double xv[4];
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
@@ -386,15 +387,17 @@ __global__ __launch_bounds__(MFMA_MAX_THREADS, 3) void d2d_fir_mfma_kernel(MfmaA
                 }
                 const uint32_t rkey = rngw[c * 4], rstep = rngw[c * 4 + 1], rlo0 = rngw[c * 4 + 2];
                 double pkx = pkw[c * 64 + lane];
-                uint32_t zv[4];
+                uint32_t zv[4] = {0, 0, 0, 0};
+                if constexpr (KIND != 0) {
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const uint32_t nlo = (uint32_t)j0.n0 + wt * 256u + (8 * r + 4 * h + k);
-                    uint32_t z = nlo + rkey + (nlo < rlo0 ? rstep : 0u);
-                    z ^= z >> 16; z *= 0x7feb352dU;
-                    z ^= z >> 15; z *= 0x846ca68bU;
-                    z ^= z >> 16;
-                    zv[k] = z;
+                    for (int k = 0; k < 4; ++k) {
+                        const uint32_t nlo = (uint32_t)j0.n0 + wt * 256u + (8 * r + 4 * h + k);
+                        uint32_t z = nlo + rkey + (nlo < rlo0 ? rstep : 0u);
+                        z ^= z >> 16; z *= 0x7feb352dU;
+                        z ^= z >> 15; z *= 0x846ca68bU;
+                        z ^= z >> 16;
+                        zv[k] = z;
+                    }
                 }
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
@@ -407,15 +410,18 @@ __global__ __launch_bounds__(MFMA_MAX_THREADS, 3) void d2d_fir_mfma_kernel(MfmaA
                 if (a.epi.bits == 32) {
 #pragma unroll
                     for (int k = 0; k < 4; ++k)
-                        *reinterpret_cast<float*>(outw + (size_t)((8 * r + 4 * h + k) * C + c) * 4) = finish_f32(a.epi, xv[k], zv[k]);
+                        *reinterpret_cast<float*>(outw + (size_t)((8 * r + 4 * h + k) * C + c) * 4) =
+                            KIND == 3 ? finish_f32(a.epi, xv[k], zv[k]) : (float)xv[k];        // finish_f32 without FPD is the plain cast
                 } else {
                     int32_t iv[4];
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
                         // dither term: T = lo16 + hi16 + 1 (x 2^-16, -1), R = 2*hi16 + 1 (x 2^-17, -1/2), none = 0
-                        const uint32_t term = m.dsel ? (zv[k] & 0xFFFFu) + (zv[k] >> 16) + 1u : 2u * (zv[k] >> 16) + 1u;
-                        const double dd = fma((double)term, m.dmul, m.dadd);
-                        const double q = xv[k] + dd;
+                        double q = xv[k] + 0.0;                             // "none": what quantise_int() does (a -0 becomes +0)
+                        if constexpr (KIND == 1 || KIND == 2) {
+                            const uint32_t term = KIND == 1 ? (zv[k] & 0xFFFFu) + (zv[k] >> 16) + 1u : 2u * (zv[k] >> 16) + 1u;
+                            q = xv[k] + fma((double)term, m.dmul, m.dadd);
+                        }
                         // round half away from zero; v_cvt_i32_f64 saturates, the clip is an integer med3
                         int32_t ri;
                         const double t = q + copysign(0.5, q);
@@ -436,12 +442,20 @@ __global__ __launch_bounds__(MFMA_MAX_THREADS, 3) void d2d_fir_mfma_kernel(MfmaA
                 }
             };
             auto finish_tile = [&](auto full_tag) {
-                auto both = [&](auto wide_tag, auto scratch_tag) {
-                    finish(acc0, c0, full_tag, wide_tag, scratch_tag);
-                    if (two) finish(acc1, c1, full_tag, wide_tag, scratch_tag);
+                auto both = [&](auto wide_tag, auto scratch_tag, auto kind_tag) {
+                    finish(acc0, c0, full_tag, wide_tag, scratch_tag, kind_tag);
+                    if (two) finish(acc1, c1, full_tag, wide_tag, scratch_tag, kind_tag);
                 };
-                if (a.to_scratch) { if (m.wide) both(std::true_type{}, std::true_type{}); else both(std::false_type{}, std::true_type{}); }
-                else { if (m.wide) both(std::true_type{}, std::false_type{}); else both(std::false_type{}, std::false_type{}); }
+                auto kinds = [&](auto wide_tag) {
+                    using K0 = std::integral_constant<int, 0>;
+                    if (a.to_scratch) { both(wide_tag, std::true_type{}, K0{}); return; }
+                    const uint32_t kind = a.epi.bits == 32 ? (a.epi.dither == 'F' ? 3u : 0u) : m.dkind;
+                    if (kind == 1) both(wide_tag, std::false_type{}, std::integral_constant<int, 1>{});
+                    else if (kind == 2) both(wide_tag, std::false_type{}, std::integral_constant<int, 2>{});
+                    else if (kind == 3) both(wide_tag, std::false_type{}, std::integral_constant<int, 3>{});
+                    else both(wide_tag, std::false_type{}, K0{});
+                };
+                if (m.wide) kinds(std::true_type{}); else kinds(std::false_type{});
             };
             const bool reg_store = full && two && Cs == 2 && sb == 3 && m.qsh == 0 && !m.wide && !a.to_scratch;
             if (dbg & 2) { if (acc0[0] == 0x12345 && acc1[5] == 77 && acc0[9] + acc1[13] + acc0[15] + acc1[2] == 99) outw[lane] = 1; }
