@@ -82,6 +82,8 @@ struct ResampArgs {
     // integer-depth epilogue as data (filled by launch_resample): d = fma(term, dmul, dadd), clamp, shift
     double   dmul, dadd;
     uint32_t dsel;             // 1: triangular term, 0: rectangular term (dmul = 0: no dither)
+    uint32_t kind;             // requantiser instantiation: 0 int/none, 1 triangular, 2 rectangular, 3 float FPD, 4 float cast
+    uint32_t reserved2;
     uint32_t qsh;              // 4 for 20-bit samples in a 24-bit container, else 0
     int32_t  qmin_i, qmax_i;
 };

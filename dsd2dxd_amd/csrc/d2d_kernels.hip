@@ -13,6 +13,7 @@
 
 #include <algorithm>
 #include <cstdlib>
+#include <type_traits>
 
 #include "d2d_device.h"
 #include "d2d_launch.h"
@@ -128,16 +129,23 @@ constexpr int RS_XPAD = 4;                           // doubles in front of the 
 // Integer depths track the peak in the scaled domain (|y*scale|, scale = gain*2^(bits-1): an exact
 // power-of-two multiple of |y*gain|, undone once at the end) and run the branch-free form of
 // quantise_int() that the MFMA kernel uses; float output takes quantise_f32().
+// KIND (fixed per launch, dispatched once per tile so that a lane's outputs share a basic block):
+// 0 integer, no dither; 1 triangular; 2 rectangular; 3 float with FPD; 4 float, plain cast.
+template <int KIND>
 __device__ __forceinline__ uint32_t quantise_bits(const ResampArgs& a, const StreamJob& job, double y, uint32_t o, double& pk) {
-    const uint32_t z = rng32(job, (uint64_t)(job.rng_lo0 + o));
-    if (a.epi.bits == 32) {
+    if constexpr (KIND >= 3) {
         pk = fmax(pk, fabs(y * a.epi.gain));
-        return __float_as_uint(quantise_f32(a.epi, y, z));
+        if constexpr (KIND == 3) return __float_as_uint(quantise_f32(a.epi, y, rng32(job, (uint64_t)(job.rng_lo0 + o))));
+        return __float_as_uint((float)(y * a.epi.gain));              // quantise_f32() without FPD
     }
     const double x = y * a.epi.scale;
     asm("v_max_f64 %0, %1, |%2|" : "=v"(pk) : "v"(pk), "v"(x));      // plain max with the |.| source modifier
-    const uint32_t term = a.dsel ? (z & 0xFFFFu) + (z >> 16) + 1u : 2u * (z >> 16) + 1u;
-    const double q = x + fma((double)term, a.dmul, a.dadd);
+    double q = x + 0.0;                                               // "none": what quantise_int() does
+    if constexpr (KIND == 1 || KIND == 2) {
+        const uint32_t z = rng32(job, (uint64_t)(job.rng_lo0 + o));
+        const uint32_t term = KIND == 1 ? (z & 0xFFFFu) + (z >> 16) + 1u : 2u * (z >> 16) + 1u;
+        q = x + fma((double)term, a.dmul, a.dadd);
+    }
     int32_t ri;
     const double t = q + copysign(0.5, q);
     asm("v_cvt_i32_f64 %0, %1" : "=v"(ri) : "v"(t));            // truncates toward zero and saturates
@@ -248,10 +256,19 @@ __global__ __launch_bounds__(RS_THREADS, 6) void d2d_resample_kernel(ResampArgs 
                 RS_TRIP(q + 1, da, db, y0, y1, y2, y3, ca, cb, x0, x1, x2, x3)
             }
             if (q < ntrips) RS_TRIP(q, ca, cb, x0, x1, x2, x3, da, db, y0, y1, y2, y3)
+            auto requantise = [&](auto kind_tag) {
 #pragma unroll
-            for (int j = 0; j < RS_R; ++j) {
-                const int32_t o = o_lane + (int32_t)(RS_R * task + j);
-                bits[tix][j] = ((uint32_t)o < nres && !(dbg & 1024)) ? quantise_bits(a, job, acc[j], (uint32_t)o, pk) : 0u;
+                for (int j = 0; j < RS_R; ++j) {
+                    const int32_t o = o_lane + (int32_t)(RS_R * task + j);
+                    bits[tix][j] = ((uint32_t)o < nres && !(dbg & 1024)) ? quantise_bits<decltype(kind_tag)::value>(a, job, acc[j], (uint32_t)o, pk) : 0u;
+                }
+            };
+            switch (a.kind) {
+                case 1: requantise(std::integral_constant<int, 1>{}); break;
+                case 2: requantise(std::integral_constant<int, 2>{}); break;
+                case 3: requantise(std::integral_constant<int, 3>{}); break;
+                case 4: requantise(std::integral_constant<int, 4>{}); break;
+                default: requantise(std::integral_constant<int, 0>{}); break;
             }
         }
         __syncthreads();                                       // all x reads done: reuse the tile for output
@@ -478,6 +495,7 @@ hipError_t launch_resample(const ResampArgs& a_in, uint32_t max_out, uint32_t ns
     if (nstreams == 0 || max_out == 0) return hipSuccess;
     ResampArgs a = a_in;
     a.dsel = a.epi.dither == 'T' ? 1u : 0u;
+    a.kind = a.epi.bits == 32 ? (a.epi.dither == 'F' ? 3u : 4u) : (a.epi.dither == 'T' ? 1u : (a.epi.dither == 'R' ? 2u : 0u));
     a.dmul = a.epi.dither == 'T' ? 0x1p-16 : (a.epi.dither == 'R' ? 0x1p-17 : 0.0);
     a.dadd = a.epi.dither == 'T' ? -1.0 : (a.epi.dither == 'R' ? -0.5 : 0.0);
     a.qsh = a.epi.bits == 20 ? 4u : 0u;
