@@ -3,7 +3,10 @@
 //   d2d_fir_lut_kernel<MB>   1-bit FIR decimator by M = 8*MB through per-nibble lookup tables in LDS
 //                            (the per-bit-pattern LUT path; 16-entry f64 tables are bank-conflict free:
 //                            16 entries x 8 B = 32 banks, equal indices broadcast)
-//   d2d_resample_kernel      stage B of the 48k cascade: polyphase L/147 on f64, one fma per tap
+//   d2d_resample_kernel<NT>  stage B of the 48k cascade: polyphase L/147 on f64, one fma per tap; lanes run along
+//                            cycles of L outputs so that coefficients are wave-uniform scalar operands
+//   d2d_deinterleave_kernel  byte-interleaved multichannel input -> the planar 4096-byte-block layout (one LDS pass)
+//   d2d_noise_shape_kernel   the 'N' dither extension: error-feedback requantiser, one thread per 65536-output segment
 //   d2d_history_kernel       carries the last `keep` bytes per channel to the next call
 //   d2d_xhist_kernel         carries the last P stage-A outputs per channel to the next call
 //

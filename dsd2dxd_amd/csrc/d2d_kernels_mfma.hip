@@ -13,8 +13,9 @@
 // the window 32 bits at a time; the 32 matrix rows are 8 phases x 4 limbs, so all four limbs of an
 // output land in ONE lane's accumulator registers and are recombined without any data movement.
 //
-// Schedule.  One wave = one independent worker converting wave-tiles of 256 frames: it stages the
-// packed bytes of every channel in its own LDS slice (next wave-tile's bytes already in flight),
+// Schedule.  One wave = one independent worker converting wave-tiles of 256 frames of its block's
+// channels (all of a mono/stereo file, one channel pair of a multichannel one): it stages the
+// packed bytes of those channels in its own LDS slice (next wave-tile's bytes already in flight),
 // runs TWO channels' MFMA chains together (each tap fragment read from the block-shared LDS table
 // feeds two MFMAs, the row words of both channels come in one ds_read_b64), then dithers,
 // requantises and packs in registers, and stores whole interleaved frames with 16-byte stores.
