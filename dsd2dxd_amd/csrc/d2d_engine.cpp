@@ -49,6 +49,8 @@ struct d2d_engine {
     uint32_t kernel = D2D_KERNEL_LUT;
     LutLayout lut{};
     MfmaLayout mfma{};
+    bool mfma_v2 = false;      // the two-group matrix-core kernel (d2d_kernels_mfma2.hip) serves this shape
+    std::string kname;
     Epilogue epi{};
     std::string err;
     std::vector<FileState> files;
@@ -211,8 +213,16 @@ int d2d_create(const d2d_params* params, uint32_t n_files, d2d_engine** out) {
     e->lut = lut_layout(e->Mb, e->Wb);
     e->mfma = mfma_layout(e->M, e->N);
     uint32_t mfma_waves = 0;
-    const bool mfma_ok = mfma_supported(e->M, e->N) &&
-                         mfma_smem_bytes(e->mfma, e->C, e->epi.sample_bytes, &mfma_waves) <= 160 * 1024;
+    bool mfma_ok = mfma_supported(e->M, e->N) &&
+                   mfma_smem_bytes(e->mfma, e->C, e->epi.sample_bytes, &mfma_waves) <= 160 * 1024;
+    {   // the two-group kernel wherever its shape is compiled and four waves fit in LDS (D2D_MFMA_V1=1: the older one)
+        static const char* v1 = getenv("D2D_MFMA_V1");
+        uint32_t w2 = 0;
+        if (!(v1 && atoi(v1)) && mfma2_supported(e->M, e->N) &&
+            mfma2_smem_bytes(e->M, e->N, e->C, e->epi.sample_bytes, &w2) <= 160 * 1024 && w2 >= 4) {
+            e->mfma_v2 = true; mfma_ok = true; mfma_waves = w2;
+        }
+    }
     // AUTO: the matrix-core kernel whenever a full 4-wave block fits in LDS (it works per channel pair,
     // so only an extremely long window can fail this; then the LUT kernel)
     e->kernel = e->p.kernel == D2D_KERNEL_AUTO ? (mfma_ok && mfma_waves >= 4 ? D2D_KERNEL_MFMA : D2D_KERNEL_LUT) : e->p.kernel;
@@ -245,7 +255,7 @@ int d2d_create(const d2d_params* params, uint32_t n_files, d2d_engine** out) {
         CK(hipMalloc(&e->d_fir_tables, e->fir_table_bytes));
         CK(hipMemcpy(e->d_fir_tables, t.data(), e->fir_table_bytes, hipMemcpyHostToDevice));
     } else {
-        std::vector<int8_t> t = build_mfma_tables(f, e->mfma, msb);
+        std::vector<int8_t> t = e->mfma_v2 ? build_mfma2_tables(f, msb) : build_mfma_tables(f, e->mfma, msb);
         e->fir_table_bytes = t.size();
         CK(hipMalloc(&e->d_fir_tables, e->fir_table_bytes));
         CK(hipMemcpy(e->d_fir_tables, t.data(), e->fir_table_bytes, hipMemcpyHostToDevice));
@@ -425,7 +435,8 @@ int d2d_translate_batch_device(d2d_engine* e, d2d_file_io* io, uint32_t n_files,
             const uint32_t per_tile = lut_outputs_per_tile(e->Mb);
             HIPCHK(e, launch_fir_lut(a, e->Mb, (max_nx + per_tile - 1) / per_tile, e->nstreams, s));
         } else {
-            HIPCHK(e, launch_fir_mfma(a, e->mfma, max_nx, e->nstreams, s));
+            if (e->mfma_v2) HIPCHK(e, launch_fir_mfma2(a, e->M, e->N, max_nx, e->nstreams, s));
+            else HIPCHK(e, launch_fir_mfma(a, e->mfma, max_nx, e->nstreams, s));
         }
     }
     if (pe) HIPCHK(e, hipEventRecord(pe->second, s));
@@ -752,6 +763,12 @@ void d2d_debug_stamps(unsigned long long* out8) { hipDeviceSynchronize(); mfma_d
 
 const char* d2d_kernel_name(const d2d_engine* e) {
     if (!e) return "";
+    if (e->kernel == D2D_KERNEL_MFMA && e->mfma_v2) {
+        d2d_engine* m = const_cast<d2d_engine*>(e);
+        m->kname = "d2d_fir_mfma2_kernel<" + std::to_string(e->Mb) + ", " + std::to_string(mfma2_pairs(e->M, e->N)) + ", " +
+                   std::to_string(e->C == 1 ? 1 : 2) + ">";
+        return m->kname.c_str();
+    }
     return e->kernel == D2D_KERNEL_LUT ? lut_kernel_name(e->Mb) : mfma_kernel_name(e->mfma);
 }
 

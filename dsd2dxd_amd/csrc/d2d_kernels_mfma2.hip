@@ -1,0 +1,659 @@
+// d2d_kernels_mfma2.hip -- the int8 matrix-core FIR decimator, second generation (gfx950), exact.
+//
+// Same arithmetic as d2d_kernels_mfma.hip (taps are 24-bit integers q, tap = q*2^-S; a stream dword W
+// becomes operand registers W & (0x01010101 << p), the tap table holds q*2^(7-p) in four balanced int8
+// limbs, the int32 accumulators hold 128 * sum q_k b_k exactly), different geometry:
+//
+//   * One matrix column = one "row window" that serves SIXTEEN consecutive outputs: two groups of eight
+//     phases.  The expanded stream operand of a K step (eight v_and per stream dword) is shared by the
+//     two groups' MFMAs, and the two groups read the SAME tap fragments, group 1 MB pair-steps later
+//     (its window starts 8*M bits further on).  Every stream bit is expanded 2.0x instead of 3.1x.
+//   * Lane half h takes the dwords 2u+h of the row window, so a K "pair step" u covers 64 contiguous
+//     bits and the all-zero tap blocks in front of group 1 / behind group 0 are never issued:
+//     2 * 2 * NPG MFMAs per 512 outputs, the same count as the one-group kernel.
+//   * A wave converts a tile of 512 outputs of ONE channel per chain (the channels of a stereo file one
+//     after the other); the chain is fully unrolled: every LDS address is the lane's base register plus
+//     an immediate, the loop carries no address arithmetic.
+//   * The tile's bytes are fetched as aligned 16-byte chunks and written to LDS shifted so that the
+//     window of matrix column r starts at staged dword 4*MB*r exactly (one pad dword per row stride keeps
+//     the 32 lanes' reads on distinct banks); only the byte misalignment (0..3) is left to the tap table,
+//     which comes in four pre-shifted variants.
+//
+// Replaces: the per-block translate loop inside Rdsd2Pcm::do_conversion
+// (/root/reference/src/main.rs:345,429); the crate that holds it is absent from the reference.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+
+#include <type_traits>
+
+#include "d2d_device.h"
+#include "d2d_launch.h"
+#include "d2d_mfma.h"
+
+namespace d2d {
+
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v16i __attribute__((ext_vector_type(16)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef int32_t i32x4 __attribute__((ext_vector_type(4)));
+
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
+struct Mfma2Args {
+    FirArgs f;
+    double c1, c0;        // x = fma(acc128, c1, -c0) == round(y*c0): c1 = 2^(1-S-7)*c0, c0 = scale | gain | 2^S
+    double dmul, dadd;    // integer depths: d = fma(term, dmul, dadd)
+    uint32_t dkind;       // 0: no dither, 1: triangular, 2: rectangular
+    uint32_t qsh;         // 4 for 20-bit samples in a 24-bit container, else 0
+    int32_t qmin_i, qmax_i;
+    uint32_t wide;        // 1: limb sums may exceed 2^23, recombine in f64
+    uint32_t off_waves;   // LDS: start of the per-wave regions (after the shared tap table)
+    uint32_t wave_lds;    // LDS bytes per wave
+    uint32_t off_out;     // the wave's output slice inside its region
+    uint32_t nwaves;      // waves per block
+    uint32_t ngroups;     // channel groups per file: 1 for mono/stereo, else one block row per channel PAIR
+    uint32_t intq;        // 1: unit gain at an integer depth -- the all-integer requantiser applies
+    int32_t  fbits;       // intq: x = v * 2^-fbits LSB (v = sum q s), fbits = S - (bits - 1)
+};
+
+constexpr int M2_TILE = 512;          // outputs per wave-tile and channel
+
+template <int MB>
+struct M2Geom {
+    static constexpr int RS = 4 * MB;                               // row stride in dwords (16 outputs)
+    static constexpr int LSH = MB == 1 ? 2 : MB == 2 ? 3 : MB == 4 ? 4 : MB == 8 ? 5 : 6;
+};
+
+__host__ __device__ constexpr int m2_span_dw(int MB, int NPG) { return 31 * 4 * MB + 2 * (NPG + MB); }
+__host__ __device__ constexpr int m2_chunks(int MB, int NPG) { return (m2_span_dw(MB, NPG) + 3 + 3) / 4; }   // + up to 3 dwords in front
+__host__ __device__ constexpr int m2_pf(int MB, int NPG) { return (m2_chunks(MB, NPG) + 63) / 64; }
+__host__ __device__ constexpr int m2_stream_bytes(int MB, int NPG) {
+    const int dw = 4 * 64 * m2_pf(MB, NPG);
+    const int lsh = MB == 1 ? 2 : MB == 2 ? 3 : MB == 4 ? 4 : MB == 8 ? 5 : 6;
+    return (((dw + (dw >> lsh) + 4) * 4 + 15) & ~15) + 16;   // + a dummy slot for the dwords in front of the window
+}
+
+__device__ __forceinline__ void wave_sync2() {
+    // LDS operations of one wave execute in order; this only stops the compiler from moving them.
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// 16 bytes of the channel's stream starting at call-relative byte j (any alignment): the slow,
+// always-right path (history, ragged blocks, interleaved layouts, call edges)
+__device__ __noinline__ u32x4 gather_chunk(const StreamJob* job, uint32_t C, uint32_t B, uint32_t keep, int32_t j) {
+    uint32_t w[4] = {0, 0, 0, 0};
+#pragma unroll 1
+    for (int b = 0; b < 16; ++b) {
+        const uint32_t x = stream_byte(*job, C, B, keep, j + b) << (8 * (b & 3));
+        if ((b >> 2) == 0) w[0] |= x; else if ((b >> 2) == 1) w[1] |= x; else if ((b >> 2) == 2) w[2] |= x; else w[3] |= x;
+    }
+    return u32x4{w[0], w[1], w[2], w[3]};
+}
+
+#ifndef D2D_M2_THREADS
+#define D2D_M2_THREADS 1024
+#endif
+template <int MB, int NPG, int CH>
+__global__ __launch_bounds__(D2D_M2_THREADS) void d2d_fir_mfma2_kernel(Mfma2Args m) {
+    using G = M2Geom<MB>;
+    constexpr int RS = G::RS, LSH = G::LSH;
+    constexpr int TP = NPG + MB;                                    // pair steps of one chain
+    constexpr int NCHK = m2_chunks(MB, NPG);
+    constexpr int PF = m2_pf(MB, NPG);
+    const FirArgs& a = m.f;
+    extern __shared__ __align__(16) unsigned char smem[];
+    // A block serves one channel group of one file: all channels for mono/stereo, one channel PAIR
+    // otherwise.  Ct = channels of the file (input layout), Cs = channels the engine converts = width of
+    // the output frame, C = channels of this group (== CH except for the odd last channel of a
+    // multichannel file, whose block runs the CH = 2 code with the second chain skipped).
+    const uint32_t Ct = a.in_channels, Cs = a.epi.channels, sb = a.epi.sample_bytes;
+    const uint32_t fidx = blockIdx.y / m.ngroups, cbase = (blockIdx.y - fidx * m.ngroups) * 2u;
+    const uint32_t C = m.ngroups == 1 ? Cs : (Cs - cbase < 2u ? Cs - cbase : 2u);
+    const uint32_t fbytes = sb * C;                        // frame bytes inside the wave's LDS out-slice
+    const uint32_t tid = threadIdx.x, lane = tid & 63;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    uint8_t* wbase = smem + m.off_waves + wave * m.wave_lds;
+    uint8_t* outw = wbase + m.off_out;
+    const StreamJob* jobs = a.jobs + (size_t)fidx * Cs + cbase;   // jobs[c]: converted channel cbase + c
+    const StreamJob j0 = jobs[0];          // in, L, e0, n0, nout are common to a file's channels
+
+    const int64_t first0 = j0.e0 - (int64_t)a.Wb;          // first byte of output 0's window
+    const uint32_t sh = (uint32_t)(first0 & 3);            // its misalignment inside the staged dword
+    {   // tap fragments: L2 -> LDS once per block; the variant for this byte misalignment
+        const uint4* s = reinterpret_cast<const uint4*>(a.tables) + (size_t)sh * (2 * NPG * 64);
+        uint4* dl = reinterpret_cast<uint4*>(smem);
+        for (uint32_t i = tid; i < 2 * NPG * 64; i += blockDim.x) dl[i] = s[i];
+    }
+    __syncthreads();
+
+    const uint32_t nwt = (j0.nout + (M2_TILE - 1)) / M2_TILE;      // wave-tiles in this file
+    const uint32_t wstride = gridDim.x * m.nwaves;
+    const uint32_t r = lane & 31, h = lane >> 5;
+
+    // ---- staging geometry (does not change from tile to tile: a tile advances the stream by 512*MB bytes) ----
+    // Global loads are 16-byte aligned chunks of the channel's stream; the first window dword of the tile
+    // is X0 dwords into chunk 0.  LDS dword L (L = 0: that first window dword) lives at L + (L >> LSH):
+    // a chunk's dwords k < X0 (they belong to the aligned group before) go to wlo + 4k, the others to
+    // whi + 4k; neither run crosses a pad.  The dwords in front of the window (chunk 0, k < X0) land in
+    // a dummy slot behind the buffer.
+    const uint32_t X0 = (uint32_t)(first0 >> 2) & 3u;
+    constexpr uint32_t DUMMY = (uint32_t)m2_stream_bytes(MB, NPG) - 16u;
+    uint32_t wlo[PF], whi[PF];
+#pragma unroll
+    for (int i = 0; i < PF; ++i) {
+        const uint32_t q = lane + 64u * i;
+        const uint32_t Lh = 4u * q;                                  // L of dword k = X0
+        whi[i] = 4u * (Lh + (Lh >> LSH)) - 4u * X0;
+        const uint32_t Ll = 4u * q - X0;                             // L of dword k = 0 (q > 0)
+        wlo[i] = q == 0 ? DUMMY : 4u * (Ll + (Ll >> LSH));
+    }
+    const uint32_t lane16 = lane * 16u;
+    const uint32_t Bsz = a.B, Lcall = (uint32_t)j0.L;
+    const bool pow2B = Bsz >= 16 && (Bsz & (Bsz - 1)) == 0;
+    const uint32_t bshift = pow2B ? 31 - __builtin_clz(Bsz) : 0;
+    const uint32_t full_bytes = pow2B ? (Lcall >> bshift) << bshift : 0;   // bytes per channel in full blocks
+    const uint32_t jump = (Ct - 1u) * Bsz;                                 // from a block's end to the channel's next block
+    const bool fast_layout = pow2B && (uint64_t)full_bytes * Ct < (1ull << 32) && jump < (1u << 24);
+    auto tile_ab16 = [&](uint32_t w) -> int32_t { return (int32_t)((first0 + (int64_t)w * (M2_TILE * MB)) & ~(int64_t)15); };
+
+    u32x4 pf[PF];
+    auto issue_loads = [&](uint32_t w, uint32_t c) {
+        const int32_t ab = tile_ab16(w);
+        const uint32_t chf = jobs[c].ch;                                    // the channel's index in the file
+        if (fast_layout && ab >= 0 && (uint32_t)ab + 16u * NCHK <= full_bytes) {
+            // planar power-of-two blocks, the whole staged range inside the call's full blocks:
+            // uniform start of the first block + offset inside it + one `jump` per block boundary crossed
+            const uint32_t blk0 = (uint32_t)ab >> bshift, r0 = (uint32_t)ab & (Bsz - 1);
+            const uint8_t* base = j0.in + ((uint64_t)(blk0 * Ct + chf) << bshift);
+#pragma unroll
+            for (int i = 0; i < PF; ++i)
+                if (lane + 64u * i < (uint32_t)NCHK) {
+                    const uint32_t off = r0 + 1024u * i + lane16;
+                    const uint32_t o = __umul24(off >> bshift, jump) + off;
+                    pf[i] = *reinterpret_cast<D2D_GLOBAL const u32x4*>(as_global(base) + o);
+                }
+        } else {
+#pragma unroll
+            for (int i = 0; i < PF; ++i)
+                if (lane + 64u * i < (uint32_t)NCHK) pf[i] = gather_chunk(jobs + c, Ct, a.B, a.keep, ab + (int32_t)(lane16 + 1024u * i));
+        }
+    };
+    auto write_lds_x = [&](auto xc) {
+        constexpr int X = decltype(xc)::value;
+#pragma unroll
+        for (int i = 0; i < PF; ++i)
+            if (lane + 64u * i < (uint32_t)NCHK) {
+                const uint32_t v[4] = {pf[i].x, pf[i].y, pf[i].z, pf[i].w};
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    *reinterpret_cast<uint32_t*>(wbase + (k < X ? wlo[i] : whi[i]) + 4 * k) = v[k];
+            }
+    };
+    auto write_lds = [&]() {
+        if (X0 == 0) write_lds_x(std::integral_constant<int, 0>{});
+        else if (X0 == 1) write_lds_x(std::integral_constant<int, 1>{});
+        else if (X0 == 2) write_lds_x(std::integral_constant<int, 2>{});
+        else write_lds_x(std::integral_constant<int, 3>{});
+    };
+
+    // this lane's row window: staged dwords RS*r + 2u + h, u = 0 .. TP-1, padded by one dword per RS
+    const uint8_t* rb = wbase + 4u * ((RS + 1) * r + h);
+    const v4i* tp = reinterpret_cast<const v4i*>(smem) + lane;      // fragment f: tp[64 * f]
+    const uint32_t K1 = 0x01010101u;
+
+    // dither keys of the block's channels (uniform)
+    uint32_t rkey[CH], rstep[CH], rlo0[CH];
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+        const uint32_t cc = (uint32_t)c < C ? c : 0;
+        rkey[c] = jobs[cc].rng_key; rstep[c] = jobs[cc].rng_kstep; rlo0[c] = jobs[cc].rng_lo0;
+    }
+    double pk[CH];
+#pragma unroll
+    for (int c = 0; c < CH; ++c) pk[c] = 0.0;
+
+    uint32_t wt = blockIdx.x * m.nwaves + wave;
+    if (wt < nwt) issue_loads(wt, 0);
+
+    const bool reg_store_cfg = CH == 2 && C == 2 && Cs == 2 && sb == 3 && m.qsh == 0 && !m.wide && !a.to_scratch;
+    for (; wt < nwt; wt += wstride) {
+        const bool full = wt * (uint32_t)M2_TILE + (uint32_t)M2_TILE <= j0.nout;
+        const bool reg_store = reg_store_cfg && full;
+        uint32_t held[8];                                   // channel 0's eight samples of the register-store path
+        static_for<0, CH>([&](auto cc_) {
+            constexpr int c = decltype(cc_)::value;
+            if ((uint32_t)c >= C) return;
+            wave_sync2();                                   // the previous chain's reads are done (same wave: in order)
+            write_lds();
+            // next unit's bytes: in flight during this chain
+            if ((uint32_t)c + 1 < C) issue_loads(wt, c + 1);
+            else if (wt + wstride < nwt) issue_loads(wt + wstride, 0);
+            wave_sync2();
+
+            // ---- the chain: TP pair steps, two groups of eight phases ----
+            v16i acc[2];
+            {
+                const v16i zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+                static_for<0, TP>([&](auto uc) {
+                    constexpr int u = decltype(uc)::value;
+                    const uint32_t W = *reinterpret_cast<const uint32_t*>(rb + 4 * (2 * u + ((2 * u) >> LSH)));
+                    const v4i lo = {(int)(W & K1), (int)(W & (K1 << 1)), (int)(W & (K1 << 2)), (int)(W & (K1 << 3))};
+                    const v4i hi = {(int)(W & (K1 << 4)), (int)(W & (K1 << 5)), (int)(W & (K1 << 6)), (int)(W & (K1 << 7))};
+                    static_for<0, 2>([&](auto gc) {
+                        constexpr int g = decltype(gc)::value;
+                        constexpr int pp = u - MB * g;
+                        if constexpr (pp >= 0 && pp < NPG) {
+                            const v4i F0 = tp[64 * (2 * pp)], F1 = tp[64 * (2 * pp + 1)];
+                            if constexpr (pp == 0) acc[g] = __builtin_amdgcn_mfma_i32_32x32x32_i8(F0, lo, zero, 0, 0, 0);
+                            else acc[g] = __builtin_amdgcn_mfma_i32_32x32x32_i8(F0, lo, acc[g], 0, 0, 0);
+                            acc[g] = __builtin_amdgcn_mfma_i32_32x32x32_i8(F1, hi, acc[g], 0, 0, 0);
+                        }
+                    });
+                });
+            }
+
+            // ---- epilogue: lane (r, h) owns outputs 16r + 8g + 4h + k of the tile, k = 0..3 ----
+            const uint32_t nl_base = wt * (uint32_t)M2_TILE + 16u * r + 4u * h;      // + 8g + k
+            auto recombine = [&](const v16i& A, int k, auto wide_tag) -> double {
+                constexpr bool WIDE = decltype(wide_tag)::value;
+                double accd;
+                if constexpr (WIDE) {
+                    accd = fma((double)A[4 * k + 3], 16777216.0,
+                               fma((double)A[4 * k + 2], 65536.0, fma((double)A[4 * k + 1], 256.0, (double)A[4 * k])));
+                } else {
+                    const int lo = A[4 * k] + (A[4 * k + 1] << 8), hi = A[4 * k + 2] + (A[4 * k + 3] << 8);
+                    accd = fma((double)hi, 65536.0, (double)lo);          // exact: 128 * sum_k q_k b_k
+                }
+                return fma(accd, m.c1, -m.c0);                            // x = y*c0 with ONE rounding
+            };
+            auto noise = [&](uint32_t nl) -> uint32_t {
+                const uint32_t nlo = (uint32_t)j0.n0 + nl;
+                uint32_t z = nlo + rkey[c] + (nlo < rlo0[c] ? rstep[c] : 0u);
+                z ^= z >> 16; z *= 0x7feb352dU;
+                z ^= z >> 15; z *= 0x846ca68bU;
+                z ^= z >> 16;
+                return z;
+            };
+            // one integer-depth sample: dither, round half away from zero, clip
+            auto quant = [&](double x, uint32_t nl, auto kind_tag) -> int32_t {
+                constexpr int KIND = decltype(kind_tag)::value;
+                double q;
+                if constexpr (KIND == 1 || KIND == 2) {
+                    const uint32_t z = noise(nl);
+                    const uint32_t term = KIND == 1 ? (z & 0xFFFFu) + (z >> 16) + 1u : 2u * (z >> 16) + 1u;
+                    q = x + fma((double)term, m.dmul, m.dadd);
+                } else {
+                    q = x + 0.0;                                          // what quantise_int() does for "none" (a -0 becomes +0)
+                }
+                int32_t ri, o;
+                const double t = q + copysign(0.5, q);
+                asm("v_cvt_i32_f64 %0, %1" : "=v"(ri) : "v"(t));         // truncates toward zero, saturates
+                const int32_t qmax_v = m.qmax_i;
+                asm("v_med3_i32 %0, %1, %2, %3" : "=v"(o) : "v"(ri), "s"(m.qmin_i), "v"(qmax_v));
+                return o;
+            };
+            // all-integer variant for unit gain (level 0 dB): x = v * 2^-F LSB with v = sum q s an integer, the
+            // dither term an integer number of 2^-16 LSB -- the same real numbers, no f64 instruction.
+            //   z = v*2^(16-F) + dterm   (units of 2^-16 LSB, dterm = t - 65535 (T) | 2*hi16 - 65535 ... (R))
+            //   r = round half away from zero of z / 65536
+            auto quant_int = [&](const v16i& A, int k, uint32_t nl, auto kind_tag, uint32_t& vabs) -> int32_t {
+                constexpr int KIND = decltype(kind_tag)::value;
+                // 128*sum q b = t0 + 65536*t1 with t0 a multiple of 128; v = 2*sum q b - 2^S (wraps are harmless: |v| < 2^31)
+                const int32_t t0 = A[4 * k] + (A[4 * k + 1] << 8);
+                const uint32_t t1 = (uint32_t)A[4 * k + 2] + ((uint32_t)A[4 * k + 3] << 8);
+                const int32_t v = (int32_t)((uint32_t)(t0 >> 6) + (t1 << 10) - (1u << a.scale_bits));
+                vabs = (uint32_t)(v < 0 ? -v : v);
+                const int F = m.fbits;                                    // 0 < F <= 16 on this path
+                const int32_t vh = v >> F;                                // floor(x)
+                const uint32_t vl = (uint32_t)v & ((1u << F) - 1u);       // its fraction, F bits
+                int32_t rr;
+                if constexpr (KIND == 2) {
+                    // units of 2^-17 LSB: (2*hi16 + 1)*2^-17 - 1/2
+                    const uint32_t z = noise(nl);
+                    const int32_t w = (int32_t)(vl << (17 - F)) + (int32_t)(2u * (z >> 16) + 1u) - 65536;
+                    const int32_t neg = (vh + (w >> 17)) >> 31;           // -1 when x + d < 0
+                    rr = vh + ((w + 65536 + neg) >> 17);
+                } else {
+                    // units of 2^-16 LSB: (lo16 + hi16 + 1)*2^-16 - 1, or nothing
+                    int32_t w = (int32_t)(vl << (16 - F));
+                    if constexpr (KIND == 1) {
+                        const uint32_t z = noise(nl);
+                        w += (int32_t)((z & 0xFFFFu) + (z >> 16)) - 65535;
+                    }
+                    const int32_t neg = (vh + (w >> 16)) >> 31;
+                    rr = vh + ((w + 32768 + neg) >> 16);
+                }
+                int32_t o;
+                const int32_t qmax_v = m.qmax_i;
+                asm("v_med3_i32 %0, %1, %2, %3" : "=v"(o) : "v"(rr), "s"(m.qmin_i), "v"(qmax_v));
+                return o;
+            };
+
+            if (reg_store) {
+                // Stereo 24-bit, whole tile: no LDS round trip.  Per group the lane owns 4 consecutive frames
+                // of both channels = 24 contiguous output bytes.
+                auto body = [&](auto kind_tag, auto intq_tag) {
+                    constexpr bool INTQ = decltype(intq_tag)::value;
+                    uint32_t cur[8];
+                    if constexpr (INTQ) {
+                        uint32_t vmax = 0;
+#pragma unroll
+                        for (int g = 0; g < 2; ++g)
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) {
+                                uint32_t va;
+                                cur[4 * g + k] = (uint32_t)quant_int(acc[g], k, nl_base + 8u * g + k, kind_tag, va);
+                                vmax = max(vmax, va);
+                            }
+                        // |x| = |v| * 2^-F exactly
+                        const double px = ldexp((double)vmax, -m.fbits);
+                        pk[c] = fmax(pk[c], px);
+                    } else {
+#pragma unroll
+                        for (int g = 0; g < 2; ++g)
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) {
+                                const double x = recombine(acc[g], k, std::false_type{});
+                                asm("v_max_f64 %0, %1, |%2|" : "=v"(pk[c]) : "v"(pk[c]), "v"(x));
+                                cur[4 * g + k] = (uint32_t)quant(x, nl_base + 8u * g + k, kind_tag);
+                            }
+                    }
+                    if (c == 0) {
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) held[i] = cur[i];
+                    } else {
+                        uint8_t* gout = reinterpret_cast<uint8_t*>(j0.out) + (size_t)wt * (M2_TILE * 6) + 96u * r + 24u * h;
+#pragma unroll
+                        for (int g = 0; g < 2; ++g) {
+                            // frames k, k+1 -> 12 bytes: [L0 L1 L2 R0 | R1 R2 L0' L1' | L2' R0' R1' R2']
+                            const uint32_t La = held[4 * g], Ra = cur[4 * g], Lb = held[4 * g + 1], Rb = cur[4 * g + 1];
+                            const uint32_t Lc = held[4 * g + 2], Rc = cur[4 * g + 2], Ld = held[4 * g + 3], Rd = cur[4 * g + 3];
+                            const u32x4 o4 = {__builtin_amdgcn_perm(Ra, La, 0x04020100u), __builtin_amdgcn_perm(Lb, Ra, 0x05040201u),
+                                              __builtin_amdgcn_perm(Rb, Lb, 0x06050402u), __builtin_amdgcn_perm(Rc, Lc, 0x04020100u)};
+                            const u32x2 o2 = {__builtin_amdgcn_perm(Ld, Rc, 0x05040201u), __builtin_amdgcn_perm(Rd, Ld, 0x06050402u)};
+                            *reinterpret_cast<D2D_GLOBAL u32x4*>(as_global(gout + 48 * g)) = o4;
+                            *reinterpret_cast<D2D_GLOBAL u32x2*>(as_global(gout + 48 * g + 16)) = o2;
+                        }
+                    }
+                };
+                auto by_kind = [&](auto intq_tag) {
+                    if (m.dkind == 1) body(std::integral_constant<int, 1>{}, intq_tag);
+                    else if (m.dkind == 2) body(std::integral_constant<int, 2>{}, intq_tag);
+                    else body(std::integral_constant<int, 0>{}, intq_tag);
+                };
+                if (m.intq) by_kind(std::true_type{}); else by_kind(std::false_type{});
+            } else {
+                // every other format: through the wave's LDS out-slice (or straight to the stage-A scratch)
+                auto finish = [&](auto full_tag, auto wide_tag, auto scratch_tag, auto kind_tag) {
+                    constexpr bool FULL = decltype(full_tag)::value;
+                    constexpr bool SCRATCH = decltype(scratch_tag)::value;
+                    constexpr int KIND = decltype(kind_tag)::value;       // 0 none, 1 triangular, 2 rectangular, 3 float FPD
+#pragma unroll
+                    for (int g = 0; g < 2; ++g) {
+                        double xv[4];
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) xv[k] = recombine(acc[g], k, wide_tag);
+                        const uint32_t fl0 = 16u * r + 8u * g + 4u * h;                  // frame inside the tile
+                        const uint32_t nl0 = wt * (uint32_t)M2_TILE + fl0;
+                        if constexpr (SCRATCH) {
+                            // stage A of the 48k cascade / input of the noise-shaping pass: the exact integers y*2^S
+                            if (FULL || nl0 + 3 < j0.nout) {
+                                *reinterpret_cast<D2D_GLOBAL i32x4*>(as_global(jobs[c].xs + nl0)) =
+                                    i32x4{(int32_t)xv[0], (int32_t)xv[1], (int32_t)xv[2], (int32_t)xv[3]};
+                            } else {
+#pragma unroll
+                                for (int k = 0; k < 4; ++k)
+                                    if (nl0 + k < j0.nout) as_global(jobs[c].xs)[nl0 + k] = (int32_t)xv[k];
+                            }
+                        } else {
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) {
+                                const bool ok = FULL || (nl0 + k < j0.nout);
+                                const double cand = ok ? xv[k] : 0.0;
+                                asm("v_max_f64 %0, %1, |%2|" : "=v"(pk[c]) : "v"(pk[c]), "v"(cand));
+                            }
+                            if (a.epi.bits == 32) {
+#pragma unroll
+                                for (int k = 0; k < 4; ++k)
+                                    *reinterpret_cast<float*>(outw + (size_t)((fl0 + k) * C + c) * 4) =
+                                        KIND == 3 ? finish_f32(a.epi, xv[k], noise(nl0 + k)) : (float)xv[k];
+                            } else {
+                                int32_t iv[4];
+#pragma unroll
+                                for (int k = 0; k < 4; ++k) {
+                                    if constexpr (KIND == 1) iv[k] = quant(xv[k], nl0 + k, std::integral_constant<int, 1>{}) << m.qsh;
+                                    else if constexpr (KIND == 2) iv[k] = quant(xv[k], nl0 + k, std::integral_constant<int, 2>{}) << m.qsh;
+                                    else iv[k] = quant(xv[k], nl0 + k, std::integral_constant<int, 0>{}) << m.qsh;
+                                }
+                                if (sb == 2) {
+#pragma unroll
+                                    for (int k = 0; k < 4; ++k)
+                                        *reinterpret_cast<uint16_t*>(outw + (size_t)((fl0 + k) * C + c) * 2) = (uint16_t)iv[k];
+                                } else {
+#pragma unroll
+                                    for (int k = 0; k < 4; ++k) {
+                                        uint8_t* p = outw + (size_t)((fl0 + k) * C + c) * 3;
+                                        p[0] = (uint8_t)iv[k]; p[1] = (uint8_t)(iv[k] >> 8); p[2] = (uint8_t)(iv[k] >> 16);
+                                    }
+                                }
+                            }
+                        }
+                    }
+                };
+                auto kinds = [&](auto full_tag, auto wide_tag) {
+                    using K0 = std::integral_constant<int, 0>;
+                    if (a.to_scratch) { finish(full_tag, wide_tag, std::true_type{}, K0{}); return; }
+                    const uint32_t kind = a.epi.bits == 32 ? (a.epi.dither == 'F' ? 3u : 0u) : m.dkind;
+                    if (kind == 1) finish(full_tag, wide_tag, std::false_type{}, std::integral_constant<int, 1>{});
+                    else if (kind == 2) finish(full_tag, wide_tag, std::false_type{}, std::integral_constant<int, 2>{});
+                    else if (kind == 3) finish(full_tag, wide_tag, std::false_type{}, std::integral_constant<int, 3>{});
+                    else finish(full_tag, wide_tag, std::false_type{}, K0{});
+                };
+                auto wides = [&](auto full_tag) { if (m.wide) kinds(full_tag, std::true_type{}); else kinds(full_tag, std::false_type{}); };
+                if (full) wides(std::true_type{}); else wides(std::false_type{});
+            }
+        });
+        if (!a.to_scratch && !reg_store) {
+            wave_sync2();
+            // the wave-tile's interleaved frames: LDS -> HBM, 16 bytes per lane per store
+            const uint32_t left = j0.nout - wt * (uint32_t)M2_TILE;
+            const uint32_t nfr = left < (uint32_t)M2_TILE ? left : (uint32_t)M2_TILE;
+            if (m.ngroups == 1) {
+                const uint32_t nb = nfr * fbytes;
+                uint8_t* g = reinterpret_cast<uint8_t*>(j0.out) + (size_t)wt * M2_TILE * fbytes;
+                const uint32_t nb16 = nb & ~15u;
+                for (uint32_t i = lane * 16; i < nb16; i += 64 * 16)
+                    *reinterpret_cast<D2D_GLOBAL u32x4*>(as_global(g + i)) = *reinterpret_cast<const u32x4*>(outw + i);
+                for (uint32_t i = nb16 + lane; i < nb; i += 64) as_global(g)[i] = outw[i];
+            } else {
+                // this group's `fbytes` bytes of every frame sit sb*cbase bytes into the file's frame
+                const uint32_t gstride = sb * Cs;
+                uint8_t* g = reinterpret_cast<uint8_t*>(j0.out) + (size_t)wt * M2_TILE * gstride + sb * cbase;
+                for (uint32_t fr = lane; fr < nfr; fr += 64)
+                    for (uint32_t b = 0; b < fbytes; ++b) as_global(g)[(size_t)fr * gstride + b] = outw[fr * fbytes + b];
+            }
+        }
+    }
+    if (!a.to_scratch) {
+        // peak meter: |x| was tracked in the scaled domain; undo the power-of-two part exactly
+        const double unscale = a.epi.bits == 32 ? 1.0 : 1.0 / (double)(1u << (a.epi.bits - 1));
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+            if ((uint32_t)c >= C) continue;
+            double p = pk[c] * unscale;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) p = fmax(p, __shfl_xor(p, o));
+            if (lane == 0 && p > 0.0)
+                atomicMax(reinterpret_cast<unsigned long long*>(jobs[c].peak), (unsigned long long)__double_as_longlong(p));
+        }
+    }
+}
+
+// ---- host side -------------------------------------------------------------------------------
+
+int mfma2_pairs(int M, int N) { return (N + 7 * M + 24 + 63) / 64; }
+
+static inline int8_t limb_of2(int64_t v, int l) {
+    // balanced base-256 digits: v = d0 + d1*2^8 + d2*2^16 + d3*2^24, every d in [-128, 127]
+    int8_t dgt = 0;
+    for (int i = 0; i <= l; ++i) {
+        int64_t dd = ((v + 128) & 255) - 128;
+        dgt = (int8_t)dd;
+        v = (v - dd) / 256;
+    }
+    return dgt;
+}
+
+// Tap fragments [4 byte shifts][2*NPG][64 lanes][16 bytes].  Fragment 2*pp + n serves pair step pp of a
+// group's window, bit positions 4n .. 4n+3 of every byte.  Lane l supplies matrix row (l & 31) =
+// 4*slot + limb for the K slots of lane half hh = l >> 5, i.e. the staged dword 2*pp + hh of the window;
+// slot j of the lane = byte (j & 3), plane (j >> 2) -> bit position p = 4n + (j >> 2) of that byte,
+// which arrives as 2^p (p = 7: -128): the table holds q * 2^(7-p), negated for p = 7.
+std::vector<int8_t> build_mfma2_tables(const d2d_filter_def& f, bool msb_first) {
+    const int NPG = mfma2_pairs(f.M, f.ntaps);
+    const size_t per = (size_t)(2 * NPG) * 64 * 16;
+    std::vector<int8_t> t(4 * per, 0);
+    for (int sh = 0; sh < 4; ++sh)                                  // window starts `sh` bytes into its first dword
+        for (int fr = 0; fr < 2 * NPG; ++fr)
+            for (int l = 0; l < 64; ++l) {
+                const int pp = fr >> 1, n = fr & 1;
+                const int row = l & 31, hh = l >> 5, limb = row & 3;
+                // D row i lands in lane half (i >> 2) & 1, register group i >> 3: give that slot output
+                // phase 4*half + group, so lane (r, half) owns the four CONSECUTIVE outputs 4*half + k of a group
+                const int ph = 4 * ((row >> 2) & 1) + (row >> 3);
+                for (int j = 0; j < 16; ++j) {
+                    const int p = 4 * n + (j >> 2);
+                    const int wb = 32 * (2 * pp + hh) + 8 * (j & 3) + p;                     // bit of the staged window
+                    const int tau = (msb_first ? (wb & ~7) + 7 - (wb & 7) : wb) - 8 * sh;   // its time index in the window
+                    const int tap = tau - ph * f.M;
+                    int8_t v = 0;
+                    if (tau >= 0 && tap >= 0 && tap < f.ntaps) {
+                        int64_t q = tap_q(f, tap);
+                        q = p == 7 ? -q : q * (int64_t)(1 << (7 - p));
+                        v = limb_of2(q, limb);
+                    }
+                    t[sh * per + ((size_t)fr * 64 + l) * 16 + j] = v;
+                }
+            }
+    return t;
+}
+
+// (MB, NPG) pairs with a compiled kernel
+#ifdef D2D_M2_DEV
+#define D2D_M2_SHAPES(X) X(4, 13)
+#else
+#define D2D_M2_SHAPES(X) X(1, 3) X(1, 4) X(2, 5) X(2, 6) X(2, 7) X(4, 10) X(4, 12) X(4, 13) X(8, 19) X(8, 24) X(8, 25)
+#endif
+
+bool mfma2_supported(int M, int N) {
+    const int MB = M / 8, NPG = mfma2_pairs(M, N);
+#define X(mb, npg) if (MB == mb && NPG == npg) return true;
+    D2D_M2_SHAPES(X)
+#undef X
+    return false;
+}
+
+static void mfma2_geometry(const FirArgs& a, int MB, int NPG, Mfma2Args& m, size_t& smem) {
+    m.ngroups = a.epi.channels <= 2 ? 1u : (a.epi.channels + 1u) / 2u;
+    const uint32_t C = a.epi.channels <= 2 ? a.epi.channels : 2u;
+    m.f = a;
+    m.c0 = a.to_scratch ? ldexp(1.0, a.scale_bits) : (a.epi.bits == 32 ? a.epi.gain : a.epi.scale);   // scratch: the integer y*2^S
+    m.c1 = ldexp(m.c0, 1 - a.scale_bits - 7);     // exact: a power-of-two multiple of c0
+    m.dkind = a.epi.dither == 'T' ? 1u : (a.epi.dither == 'R' ? 2u : 0u);
+    m.dmul = a.epi.dither == 'T' ? 0x1p-16 : (a.epi.dither == 'R' ? 0x1p-17 : 0.0);
+    m.dadd = a.epi.dither == 'T' ? -1.0 : (a.epi.dither == 'R' ? -0.5 : 0.0);
+    m.qsh = a.epi.bits == 20 ? 4u : 0u;
+    m.qmin_i = a.epi.bits == 32 ? 0 : -(1 << (a.epi.bits - 1)); m.qmax_i = a.epi.bits == 32 ? 0 : (1 << (a.epi.bits - 1)) - 1;
+    // |limb sum| <= (bytes of a group's window) * 255 * 128; below 2^23 the pairs recombine in int32
+    m.wide = (uint64_t)NPG * 8u * 255u * 128u >= (1u << 23) ? 1u : 0u;
+    m.fbits = a.scale_bits - ((int)a.epi.bits - 1);
+    static const char* noint = getenv("D2D_NO_INTQ");
+    m.intq = (!noint && !a.to_scratch && a.epi.bits != 32 && a.epi.gain == 1.0 && !m.wide && m.fbits > 0 && m.fbits <= 16) ? 1u : 0u;
+    m.off_waves = (uint32_t)(2 * NPG) * 1024u;
+    m.off_out = (uint32_t)m2_stream_bytes(MB, NPG);
+    m.wave_lds = m.off_out + (((uint32_t)M2_TILE * C * a.epi.sample_bytes + 15u) & ~15u);
+    static const char* wenv = getenv("D2D_MFMA_WAVES");   // diagnostic override
+    m.nwaves = wenv ? (uint32_t)atoi(wenv) : 16u;
+    if (m.nwaves < 1 || m.nwaves > 16) m.nwaves = 16;
+    // largest block that fits the CU's LDS, keeping the waves evenly spread over the four SIMDs
+    while (m.nwaves > 1 && (size_t)m.off_waves + (size_t)m.nwaves * m.wave_lds > 160 * 1024)
+        m.nwaves = m.nwaves > 12 ? 12 : m.nwaves > 8 ? 8 : m.nwaves > 4 ? 4 : m.nwaves >> 1;
+    smem = (size_t)m.off_waves + (size_t)m.nwaves * m.wave_lds;
+}
+
+size_t mfma2_smem_bytes(int M, int N, uint32_t channels, uint32_t sample_bytes, uint32_t* waves_per_block) {
+    FirArgs a{};
+    a.epi.channels = channels; a.epi.sample_bytes = sample_bytes; a.epi.bits = 24;
+    Mfma2Args m{}; size_t smem = 0;
+    mfma2_geometry(a, M / 8, mfma2_pairs(M, N), m, smem);
+    if (waves_per_block) *waves_per_block = m.nwaves;
+    return smem;
+}
+
+template <int MB, int NPG, int CH>
+static hipError_t launch_mfma2_t(Mfma2Args& m, size_t smem, uint32_t nwt_max, uint32_t nrows, hipStream_t s) {
+    static KernelPrep prep;
+    int dev = 0;
+    const void* fn = reinterpret_cast<const void*>(&d2d_fir_mfma2_kernel<MB, NPG, CH>);
+    hipError_t e = prep.max_dynamic_lds(fn, 160 * 1024, &dev);
+    if (e != hipSuccess) return e;
+    int blocks_per_cu, ncu;
+    {
+        std::lock_guard<std::mutex> g(prep.mu);
+        if (prep.blocks_per_cu[dev] == 0 || smem != prep.smem_seen[dev] || m.nwaves != prep.nwaves_seen[dev]) {
+            hipDeviceProp_t prop;
+            if ((e = hipGetDeviceProperties(&prop, dev)) != hipSuccess) return e;
+            // the register file may admit fewer waves than LDS does: shrink the block until one fits
+            int nb = 0;
+            for (;;) {
+                e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, d2d_fir_mfma2_kernel<MB, NPG, CH>, (int)(64 * m.nwaves), smem);
+                if (e != hipSuccess) return e;
+                if (nb >= 1 || m.nwaves <= 4) break;
+                m.nwaves -= 4;
+                smem = (size_t)m.off_waves + (size_t)m.nwaves * m.wave_lds;
+            }
+            prep.ncu[dev] = prop.multiProcessorCount;
+            prep.blocks_per_cu[dev] = nb < 1 ? 1 : nb;
+            prep.smem_seen[dev] = smem; prep.nwaves_seen[dev] = m.nwaves;
+            prep.smem_used[dev] = smem;
+        }
+        blocks_per_cu = prep.blocks_per_cu[dev]; ncu = prep.ncu[dev];
+        m.nwaves = prep.nwaves_seen[dev]; smem = prep.smem_used[dev];
+    }
+    // every wave loops over its share of the wave-tiles: launch what is resident at once
+    uint32_t gx = (uint32_t)(ncu * blocks_per_cu) / nrows;
+    if (gx < 1) gx = 1;
+    const uint32_t need = (nwt_max + m.nwaves - 1) / m.nwaves;
+    if (gx > need) gx = need;
+    hipLaunchKernelGGL((d2d_fir_mfma2_kernel<MB, NPG, CH>), dim3(gx, nrows), dim3(64 * m.nwaves), smem, s, m);
+    return hipGetLastError();
+}
+
+hipError_t launch_fir_mfma2(const FirArgs& a, int M, int N, uint32_t max_nout, uint32_t nstreams, hipStream_t s) {
+    if (nstreams == 0 || max_nout == 0) return hipSuccess;
+    const uint32_t C = a.epi.channels;
+    const int MB = M / 8, NPG = mfma2_pairs(M, N);
+    Mfma2Args m{};
+    size_t smem = 0;
+    mfma2_geometry(a, MB, NPG, m, smem);
+    const uint32_t nrows = (nstreams / C) * m.ngroups;       // grid rows: one per (file, channel group)
+    if (smem > 160 * 1024) return hipErrorInvalidValue;
+    const uint32_t nwt = (max_nout + (M2_TILE - 1)) / M2_TILE;
+#define X(mb, npg)                                                                                  \
+    if (MB == mb && NPG == npg)                                                                     \
+        return C == 1 ? launch_mfma2_t<mb, npg, 1>(m, smem, nwt, nrows, s) : launch_mfma2_t<mb, npg, 2>(m, smem, nwt, nrows, s);
+    D2D_M2_SHAPES(X)
+#undef X
+    return hipErrorInvalidValue;
+}
+
+}  // namespace d2d

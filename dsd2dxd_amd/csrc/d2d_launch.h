@@ -18,6 +18,7 @@ struct KernelPrep {
     // occupancy cache of the persistent MFMA launch
     int blocks_per_cu[MAX_DEV] = {}, ncu[MAX_DEV] = {};
     size_t smem_seen[MAX_DEV] = {};
+    size_t smem_used[MAX_DEV] = {};
     uint32_t nwaves_seen[MAX_DEV] = {};
 
     hipError_t max_dynamic_lds(const void* fn, int bytes, int* dev_out = nullptr) {

@@ -27,4 +27,11 @@ hipError_t launch_fir_mfma(const FirArgs& a, const MfmaLayout& g, uint32_t max_n
 const char* mfma_kernel_name(const MfmaLayout& g);
 void mfma_debug_stamps(unsigned long long out[8]);   // diagnostic (D2D_DBG=16)
 
+// second-generation kernel (d2d_kernels_mfma2.hip): two phase groups per matrix column
+int mfma2_pairs(int M, int N);
+bool mfma2_supported(int M, int N);
+size_t mfma2_smem_bytes(int M, int N, uint32_t channels, uint32_t sample_bytes, uint32_t* waves_per_block);
+std::vector<int8_t> build_mfma2_tables(const d2d_filter_def& f, bool msb_first);
+hipError_t launch_fir_mfma2(const FirArgs& a, int M, int N, uint32_t max_nout, uint32_t nstreams, hipStream_t s);
+
 }  // namespace d2d
