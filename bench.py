@@ -8,14 +8,24 @@ converts `--files` files of `--seconds` seconds (default 64 x 60 s = config 4's 
 8 ways); files are independent, so there is no data-path collective -- RCCL only broadcasts the
 filter tables once, before the timed region.
 
-Prints ONE JSON line (rank 0).  `roofline` is for the FIR kernel, timed with HIP events on its launch
-stream inside the timed region; `cpu_baseline` is the repo's own CPU restatement (oracle/, "port" --
-the reference's Rust core is absent from the checkout and cannot be built here) on a bounded sample.
+`python bench.py --gpus N` with no WORLD_SIZE in the environment starts the N ranks itself (child
+processes, one per GPU, rendezvous on 127.0.0.1) before anything touches the GPU; under
+`torch.distributed.run` the ranks already exist and it just joins them.
+
+Prints ONE JSON line (rank 0).  The timed loop of K steps is repeated `--reps` times; `value` and
+`ms_per_step` are the median repetition, `repetitions` lists them all.  `roofline` is timed with HIP
+events on the launch stream inside the timed region: around the FIR launch when that kernel is the
+whole step, around every kernel of the step otherwise (`roofline.scope`).  `cpu_baseline` is the repo's
+own CPU restatement (oracle/, "port" -- the reference's Rust core is absent from the checkout and cannot
+be built here) on a bounded sample; `pcie_inclusive` is the same batch from pinned host memory.
 """
 import argparse
 import ctypes as C
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 from concurrent.futures import ThreadPoolExecutor
@@ -41,6 +51,41 @@ WORKLOADS = {
     "dsd512_to_96k_s24_8ch": (8, 96000, 24, "T", 8, 235.2 / 8 + 3),      # config 5: byte-interleaved MSB-first
 }
 LAYOUTS = {"dsd512_to_96k_s24_8ch": ("I", "M", 1)}                       # default: planar 4096 LSB-first
+
+
+REF_SCREENSHOT_MSAMPLES_PER_WORKER = 17.6   # /root/reference/asset/progress.jpg: 50x realtime, stereo 176.4 kHz
+
+
+def kernel_source_hash():
+    """sha256[:16] over the kernel sources: pmc_traffic.json entries are only cited for the code they were taken on"""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "dsd2dxd_amd", "csrc")
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hip", ".h")) or name == "d2d_engine.cpp":
+            with open(os.path.join(d, name), "rb") as f:
+                h.update(name.encode() + b"\0" + f.read())
+    return h.hexdigest()[:16]
+
+
+def spawn_ranks(n):
+    """--gpus N without a launcher: start N copies of this script, one per GPU, from a parent that never
+    touches the GPU (a process that has initialised HIP must not be replaced or forked on this pool).  Rank 0's
+    JSON line is the parent's output; the parent exits with the worst child code."""
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out0, _ = procs[0].communicate()
+    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    for line in out0.decode().splitlines():            # rank 0's JSON line only (gloo chats on stdout)
+        if line.startswith("{"):
+            print(line)
+    sys.stdout.flush()
+    return max(abs(rc) for rc in rcs)
 
 
 def make_files(n_files, bytes_per_channel, dsd_rate, distinct, rank, threads, channels=2, fmt="P", endian="L", block=4096):
@@ -106,10 +151,14 @@ def main():
     ap.add_argument("--shard", default="files", choices=["files", "channels"],
                     help="files: every rank converts its own files (weak scaling, the default).  channels: every rank holds the SAME "
                          "multichannel files and converts its channel range (BASELINE config 5: one stream split by channel; strong scaling)")
+    ap.add_argument("--reps", type=int, default=5, help="repetitions of the timed K-step loop (median reported)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--pcie", action="store_true", help="also time the host-resident batch (pinned host in/out, upload/convert/download overlapped); reported as an extra pcie_inclusive object, never as value")
+    ap.add_argument("--no-pcie", action="store_true", help="skip the host-resident batch (pinned host in/out, upload/convert/download overlapped) that is reported as the extra pcie_inclusive object, never as value")
     ap.add_argument("--cpu-budget", type=float, default=12.0, help="seconds of CPU-baseline work")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus))
 
     import torch
     import torch.distributed as dist
@@ -118,7 +167,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     # one process per GPU over RCCL ("nccl" IS RCCL on ROCm).  D2D_BENCH_BACKEND=gloo is a rehearsal
     # mode for boxes with fewer GPUs than ranks: same protocol, collectives on host tensors, ranks
@@ -200,24 +249,29 @@ def main():
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
-    eng.profile_read()
+    eng.profile_read_all()
     eng.profile_enable(True)
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    fir_ms, launches = eng.profile_read()
+    dts = []
+    for _ in range(max(1, args.reps)):
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device=cdev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        dts.append(dt)
+    fir_ms, step_ms, launches = eng.profile_read_all()
     eng.profile_enable(False)
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=cdev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dts_sorted = sorted(dts)
+    dt = dts_sorted[len(dts_sorted) // 2]                 # the median repetition is the reported one
 
     samples_per_step_rank = frames * ch_count * args.files
     if world > 1 and args.shard == "channels":
@@ -227,14 +281,21 @@ def main():
     else:
         total_samples = samples_per_step_rank * args.steps * world
     value = total_samples / dt / 1e6
-    fir_s = fir_ms / 1e3 / max(1, launches)
+    fir_s = fir_ms / 1e3 / max(1, launches)               # the FIR kernel alone, per launch (mean over all repetitions)
+    step_s = step_ms / 1e3 / max(1, launches)             # every kernel of a step
+    # the FIR kernel is "the dominant kernel" only when it IS the step; cascades, the noise-shaping pass and the
+    # de-interleave pre-pass are priced with the whole step's device time
+    scope = "kernel" if fir_s >= 0.95 * step_s else "step"
+    roof_s = fir_s if scope == "kernel" else step_s
     alg_bytes = samples_per_step_rank * bytes_per_sample      # per launch (one launch = one step of one rank)
-    achieved = alg_bytes / fir_s / 1e9 if fir_s > 0 else 0.0
+    achieved = alg_bytes / roof_s / 1e9 if roof_s > 0 else 0.0
 
     out = {
         "metric": "output PCM Msamples/s, DSD64->88.2k stereo" if args.workload.startswith("dsd64_to_88k2") else f"output PCM Msamples/s, {args.workload}",
         "value": round(value, 3), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak" if args.shard == "files" else "strong",
+        "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True,
+        "repetitions": {"n": len(dts), "ms_per_step_min": round(dts_sorted[0] / args.steps * 1e3, 4), "ms_per_step_max": round(dts_sorted[-1] / args.steps * 1e3, 4),
+                        "ms_per_step_all": [round(x / args.steps * 1e3, 4) for x in dts]}, "scaling": "weak" if args.shard == "files" else "strong",
         "vs_baseline": None, "dtype": "f64", "data": "synthetic (2nd-order 1-bit modulator: 1 kHz-family sines at 0.352 FS and pink noise at ~0.1 RMS; %d distinct files per rank%s)" % (min(args.distinct, args.files), "" if args.distinct >= args.files else " tiled to %d" % args.files),
         "config": {"workload": f"{args.workload}: {args.files} files/GPU x {blocks * 4096 * 8 / (DSD64 * dsd_rate):.1f} s, {'planar 4096-B LSB-first' if fmt == 'P' else 'byte-interleaved MSB-first'} {channels} ch -> {bits}-bit {out_rate} Hz, dither {dither}, filter E ({eng.info()['ntaps']} taps, M={M:g})",
                    "files_per_gpu": args.files, "seconds_per_file": round(blocks * 4096 * 8 / (DSD64 * dsd_rate), 3),
@@ -242,22 +303,26 @@ def main():
                                    f"channels of every file split over {world} GPU(s) ({ch_count} of {channels} on rank 0), no data-path collective"), "kernel": eng.kernel_name()},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
-                     "kernel": eng.kernel_name(), "kernel_ms": round(fir_s * 1e3, 4),
+                     "scope": scope, "kernel": eng.kernel_name() if scope == "kernel" else "every kernel of a step (FIR: %s)" % eng.kernel_name(),
+                     "kernel_ms": round(roof_s * 1e3, 4), "fir_kernel_ms": round(fir_s * 1e3, 4), "step_kernels_ms": round(step_s * 1e3, 4),
                      "algorithmic_bytes_per_launch": int(alg_bytes), "bytes_per_output_sample": bytes_per_sample},
     }
-    # PMC traffic is collected in separate rocprofv3 --pmc passes (profiles/); bench.py only cites it
+    # PMC traffic is collected in separate rocprofv3 --pmc passes (tools/prof.sh -> profiles/); bench.py only cites an
+    # entry taken on exactly these kernel sources and this workload size, otherwise traffic stays null
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as fjs:
             pmc = json.load(fjs)
         ent = pmc.get(eng.kernel_name(), {}).get(args.workload)
-        if ent and ent.get("files_per_gpu") == args.files and abs(ent.get("seconds_per_file", 0) - out["config"]["seconds_per_file"]) < 1e-3:
+        if (ent and ent.get("kernel_src_sha16") == kernel_source_hash() and ent.get("files_per_gpu") == args.files
+                and abs(ent.get("seconds_per_file", 0) - out["config"]["seconds_per_file"]) < 1e-3 and scope == "kernel"):
             out["roofline"]["traffic"] = ent["hbm_bytes_per_launch"]
     except Exception:
         pass
 
-    if args.pcie and rank == 0:
+    if not args.no_pcie:
         # end-to-end from pinned host memory: d2d_translate_batch_host (three streams, double-buffered
-        # staging).  A separate engine so the timed engine's state is untouched.
+        # staging), every rank at once on its own GPU and link.  A separate engine so the timed engine's
+        # state is untouched.
         e2 = d.Engine(n_files=args.files, kernel=kernel, device=local_dev, **kw)
         h_in = {}
         for b in files:
@@ -272,20 +337,28 @@ def main():
             hios[f].pcm_capacity_bytes = frames * fb
         e2.translate_batch_host(hios, 0)                         # warm-up (allocates the staging)
         reps = 2
+        if world > 1:
+            dist.barrier()
         t1 = time.perf_counter()
         for _ in range(reps):
             e2.translate_batch_host(hios, 0)
         dth = (time.perf_counter() - t1) / reps
+        if world > 1:
+            t = torch.tensor([dth], dtype=torch.float64, device=cdev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dth = float(t.item())
         hb = args.files * (bpc * channels + frames * fb)
-        out["pcie_inclusive"] = {"value": round(samples_per_step_rank / dth / 1e6, 3), "unit": "Msamples/s", "ms_per_step": round(dth * 1e3, 3),
-                                 "host_bytes_per_step": int(hb), "link_GBps_both_ways": round(hb / dth / 1e9, 2),
-                                 "note": "pinned host buffers -> pinned host buffers through d2d_translate_batch_host; 1 GPU"}
+        out["pcie_inclusive"] = {"value": round(total_samples / args.steps / dth / 1e6, 3), "unit": "Msamples/s", "ms_per_step": round(dth * 1e3, 3),
+                                 "host_bytes_per_step_per_gpu": int(hb), "link_GBps_both_ways_per_gpu": round(hb / dth / 1e9, 2),
+                                 "note": "pinned host buffers -> pinned host buffers through d2d_translate_batch_host, all %d GPU(s) at once; never the reported value" % world}
         del e2
 
     if rank == 0 and not args.no_cpu_baseline:
         threads = max(1, ncpu // 2)
         v, n, secs = cpu_baseline(kw, files, threads, args.cpu_budget)
         out["cpu_baseline"] = {"value": round(v, 3), "unit": "Msamples/s", "cores": threads, "kind": "port",
+                               "per_thread": round(v / threads, 3),
+                               "reference_screenshot_per_worker": REF_SCREENSHOT_MSAMPLES_PER_WORKER,
                                "sample": f"{threads} streams of the same workload (one file per thread, threads = logical cores/2 as src/main.rs:148-155), {n} output samples in {secs:.1f} s; oracle/d2d_oracle.c byte-LUT f64, gcc -O3 -march=native"}
     elif rank == 0:
         out["cpu_baseline"] = None

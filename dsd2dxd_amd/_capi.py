@@ -50,7 +50,7 @@ EXPORTS = ["d2d_create", "d2d_create_error", "d2d_destroy", "d2d_reset", "d2d_la
            "d2d_translate_batch_host",
            "d2d_peak", "d2d_peak_dbfs", "d2d_convert_stream", "d2d_tables_bytes",
            "d2d_tables_export_device", "d2d_tables_import_device", "d2d_get_info", "d2d_kernel_name",
-           "d2d_profile_enable", "d2d_profile_read"]
+           "d2d_profile_enable", "d2d_profile_read", "d2d_profile_read_all"]
 
 _lib = None
 
@@ -101,6 +101,7 @@ def lib():
     L.d2d_kernel_name.restype = C.c_char_p
     L.d2d_profile_enable.argtypes = [C.c_void_p, C.c_int]
     L.d2d_profile_read.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
+    L.d2d_profile_read_all.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
     _lib = L
     return L
 
@@ -206,6 +207,12 @@ class Engine:
         ms, n = C.c_double(), C.c_uint64()
         self._check(lib().d2d_profile_read(self._h, C.byref(ms), C.byref(n)))
         return ms.value, n.value
+
+    def profile_read_all(self):
+        """(FIR kernel ms, whole-call kernels ms, launches) since the last read"""
+        fir, step, n = C.c_double(), C.c_double(), C.c_uint64()
+        self._check(lib().d2d_profile_read_all(self._h, C.byref(fir), C.byref(step), C.byref(n)))
+        return fir.value, step.value, n.value
 
     def tables_bytes(self):
         return lib().d2d_tables_bytes(self._h)

@@ -76,7 +76,8 @@ struct d2d_engine {
     hipStream_t last_stream = nullptr;
     // measurement
     bool profiling = false;
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_pool; size_t prof_used = 0;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_pool; size_t prof_used = 0;     // around the FIR launch
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> step_pool; size_t step_used = 0;     // around every kernel of a batch call
     // staging for d2d_translate (host pointers)
     uint8_t* d_in = nullptr; size_t d_in_cap = 0;
     // planar copies of byte-interleaved inputs (one slice per file), see d2d_deinterleave_kernel
@@ -152,6 +153,7 @@ static void free_device(d2d_engine* e) {
     for (int i = 0; i < 6; ++i) if (e->hb_ev[i]) hipEventDestroy(e->hb_ev[i]);
     for (int b = 0; b < 2; ++b) { if (e->hb_in[b]) hipFree(e->hb_in[b]); if (e->hb_out[b]) hipFree(e->hb_out[b]); }
     for (auto& pr : e->prof_pool) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
+    for (auto& pr : e->step_pool) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
 }
 
 static int reset_state(d2d_engine* e) {
@@ -229,7 +231,7 @@ int d2d_create(const d2d_params* params, uint32_t n_files, d2d_engine** out) {
     if (e->kernel == D2D_KERNEL_MFMA && !mfma_ok) {
         g_create_error = "MFMA kernel does not support this configuration (decimation or LDS budget)"; delete e; return D2D_ERR_PARAM;
     }
-    e->keep = (uint32_t)std::max(e->Wb + e->Mb, (int)mfma_keep_bytes(e->mfma, e->Mb));
+    e->keep = (uint32_t)(e->Wb + e->Mb);
     e->keep = (e->keep + 15u) & ~15u;
 
     // ---- device side: fail loudly when there is no GPU ----
@@ -406,6 +408,17 @@ int d2d_translate_batch_device(d2d_engine* e, d2d_file_io* io, uint32_t n_files,
     HIPCHK(e, hipEventRecord(e->job_ev[slot], s));
     e->job_ev_used[slot] = true;
 
+    std::pair<hipEvent_t, hipEvent_t>* ps = nullptr;
+    if (e->profiling && max_nx) {
+        if (e->step_used == e->step_pool.size()) {
+            std::pair<hipEvent_t, hipEvent_t> n{};
+            HIPCHK(e, hipEventCreate(&n.first));
+            HIPCHK(e, hipEventCreate(&n.second));
+            e->step_pool.push_back(n);
+        }
+        ps = &e->step_pool[e->step_used++];
+        HIPCHK(e, hipEventRecord(ps->first, s));
+    }
     if (e->deinterleave) HIPCHK(e, launch_deinterleave(e->d_jobs, n_files, e->Cin, C, max_L, s));
 
     FirArgs a{};
@@ -418,6 +431,11 @@ int d2d_translate_batch_device(d2d_engine* e, d2d_file_io* io, uint32_t n_files,
     a.ksteps = (uint32_t)e->mfma.ksteps;
     a.scale_bits = e->S;
     a.in_channels = e->Cin;
+    {
+        uint64_t sa = 0;
+        for (int j = 0; j < e->N; ++j) { const int64_t q = tap_q(*e->fc.fir, j); sa += (uint64_t)(q < 0 ? -q : q); }
+        a.sum_abs_q = sa;
+    }
     a.epi = e->epi;
     std::pair<hipEvent_t, hipEvent_t>* pe = nullptr;
     if (e->profiling && max_nx) {
@@ -455,6 +473,7 @@ int d2d_translate_batch_device(d2d_engine* e, d2d_file_io* io, uint32_t n_files,
         HIPCHK(e, launch_xhist(e->d_jobs, e->nstreams, r.P, s));
     }
     HIPCHK(e, launch_history(e->d_jobs, e->nstreams, e->Cin, e->B, e->keep, s));
+    if (ps) HIPCHK(e, hipEventRecord(ps->second, s));
     e->hist_cur = cur ^ 1;
     for (uint32_t f = 0; f < n_files; ++f) {
         FileState& st = e->files[f];
@@ -512,8 +531,10 @@ int d2d_translate_batch_host(d2d_engine* e, d2d_file_io* io, uint32_t n_files, s
     const uint32_t C = e->Cin;                       // the uploads move whole input frames
     const size_t fb = d2d_frame_bytes(e);
     if (slice == 0) slice = 4u << 20;
-    if (e->B > 1) slice = std::max<size_t>(e->B, slice / e->B * e->B);       // whole planar blocks per slice
-    slice = (slice + 15) & ~(size_t)15;
+    // whole planar blocks per slice, for ANY block size (-s takes any value, src/main.rs:75-78): every slice then
+    // starts on a block-group boundary, which is what the kernels' addressing of a call assumes.  (No rounding to 16
+    // bytes: the staging buffers are 256-byte aligned per file whatever the slice length.)
+    if (e->B > 1) slice = std::max<size_t>(e->B, slice / e->B * e->B);
     size_t max_L = 0;
     for (uint32_t f = 0; f < n_files; ++f) {
         if (io[f].bytes_per_channel && !io[f].dsd) return e->fail(D2D_ERR_PARAM, "null dsd pointer");
@@ -703,6 +724,21 @@ int d2d_profile_read(d2d_engine* e, double* ms_total, uint64_t* launches) {
     return D2D_OK;
 }
 
+int d2d_profile_read_all(d2d_engine* e, double* fir_ms_total, double* step_ms_total, uint64_t* launches) {
+    if (!e) return D2D_ERR_PARAM;
+    HIPCHK(e, hipSetDevice(e->p.device));
+    double tot = 0.0;
+    for (size_t i = 0; i < e->step_used; ++i) {
+        HIPCHK(e, hipEventSynchronize(e->step_pool[i].second));
+        float ms = 0.f;
+        HIPCHK(e, hipEventElapsedTime(&ms, e->step_pool[i].first, e->step_pool[i].second));
+        tot += ms;
+    }
+    if (step_ms_total) *step_ms_total = tot;
+    e->step_used = 0;
+    return d2d_profile_read(e, fir_ms_total, launches);
+}
+
 size_t d2d_tables_bytes(const d2d_engine* e) {
     return e ? sizeof(TableBlobHeader) + ((e->fir_table_bytes + 15) & ~(size_t)15) + e->resamp_bytes : 0;
 }
@@ -760,6 +796,7 @@ int d2d_get_info(const d2d_engine* e, d2d_info* out) {
 
 // diagnostic, not part of the public header: per-phase wave-cycle sums of the MFMA kernel (D2D_DBG=16)
 void d2d_debug_stamps(unsigned long long* out8) { hipDeviceSynchronize(); mfma_debug_stamps(out8); }
+void d2d_debug_stamps2(unsigned long long* out8) { hipDeviceSynchronize(); mfma2_debug_stamps(out8); }
 
 const char* d2d_kernel_name(const d2d_engine* e) {
     if (!e) return "";

@@ -59,6 +59,7 @@ struct FirArgs {
     uint32_t ksteps;           // MFMA: K steps
     int32_t  scale_bits;       // S of the tap table (h = q * 2^-S)
     uint32_t in_channels;      // channels of the input layout (epi.channels = channels of the output frame; fewer for a channel subset)
+    uint64_t sum_abs_q;        // sum |q_j| of the tap table (bounds |y*2^S|)
     Epilogue epi;
 };
 

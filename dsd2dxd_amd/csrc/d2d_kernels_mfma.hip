@@ -587,8 +587,6 @@ MfmaLayout mfma_layout(int M, int N) {
     return g;
 }
 
-uint32_t mfma_keep_bytes(const MfmaLayout&, int) { return 0; }
-
 static inline int8_t limb_of(int64_t v, int l) {
     // balanced base-256 digits: v = d0 + d1*2^8 + d2*2^16 + d3*2^24, every d in [-128, 127]
     int8_t dgt = 0;

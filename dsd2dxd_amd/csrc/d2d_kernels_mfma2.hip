@@ -61,7 +61,16 @@ struct Mfma2Args {
     uint32_t ngroups;     // channel groups per file: 1 for mono/stereo, else one block row per channel PAIR
     uint32_t intq;        // 1: unit gain at an integer depth -- the all-integer requantiser applies
     int32_t  fbits;       // intq: x = v * 2^-fbits LSB (v = sum q s), fbits = S - (bits - 1)
+    uint32_t dbg;         // diagnostic ablation mask (make DIAG=1, env D2D_DBG): 1 no chain, 2 no epilogue, 4 no staging
 };
+
+#ifndef D2D_DIAG
+#define D2D_DIAG 0
+#endif
+
+#if D2D_DIAG
+__device__ unsigned long long d2d_m2_stamps[8];
+#endif
 
 constexpr int M2_TILE = 512;          // outputs per wave-tile and channel
 
@@ -100,9 +109,11 @@ __device__ __noinline__ u32x4 gather_chunk(const StreamJob* job, uint32_t C, uin
 }
 
 #ifndef D2D_M2_THREADS
-#define D2D_M2_THREADS 1024
+#define D2D_M2_THREADS 768
 #endif
-template <int MB, int NPG, int CH>
+// EPI: 0 = any format through the wave's LDS out-slice, 1 = stereo 24-bit packed in registers, 2 = the exact integers y*2^S to the
+// stage-A scratch (48k cascade, noise-shaping pass)
+template <int MB, int NPG, int CH, int EPI>
 __global__ __launch_bounds__(D2D_M2_THREADS) void d2d_fir_mfma2_kernel(Mfma2Args m) {
     using G = M2Geom<MB>;
     constexpr int RS = G::RS, LSH = G::LSH;
@@ -110,6 +121,7 @@ __global__ __launch_bounds__(D2D_M2_THREADS) void d2d_fir_mfma2_kernel(Mfma2Args
     constexpr int NCHK = m2_chunks(MB, NPG);
     constexpr int PF = m2_pf(MB, NPG);
     const FirArgs& a = m.f;
+    const uint32_t dbg = D2D_DIAG ? m.dbg : 0u;
     extern __shared__ __align__(16) unsigned char smem[];
     // A block serves one channel group of one file: all channels for mono/stereo, one channel PAIR
     // otherwise.  Ct = channels of the file (input layout), Cs = channels the engine converts = width of
@@ -208,7 +220,18 @@ __global__ __launch_bounds__(D2D_M2_THREADS) void d2d_fir_mfma2_kernel(Mfma2Args
     // this lane's row window: staged dwords RS*r + 2u + h, u = 0 .. TP-1, padded by one dword per RS
     const uint8_t* rb = wbase + 4u * ((RS + 1) * r + h);
     const v4i* tp = reinterpret_cast<const v4i*>(smem) + lane;      // fragment f: tp[64 * f]
+#ifdef D2D_M2_TAPREG
+    v4i tapreg[2 * NPG];                                            // the whole tap table of this lane, resident
+#pragma unroll
+    for (int f = 0; f < 2 * NPG; ++f) tapreg[f] = tp[64 * f];
+#endif
     const uint32_t K1 = 0x01010101u;
+#ifndef D2D_M2_NO_VMASK
+    // the eight plane masks parked in VGPRs: a VOP2 with only VGPR operands is the cheapest encoding to issue
+    uint32_t km[8];
+#pragma unroll
+    for (int p_ = 0; p_ < 8; ++p_) { km[p_] = K1 << p_; asm volatile("" : "+v"(km[p_])); }
+#endif
 
     // dither keys of the block's channels (uniform)
     uint32_t rkey[CH], rstep[CH], rlo0[CH];
@@ -223,36 +246,99 @@ __global__ __launch_bounds__(D2D_M2_THREADS) void d2d_fir_mfma2_kernel(Mfma2Args
 
     uint32_t wt = blockIdx.x * m.nwaves + wave;
     if (wt < nwt) issue_loads(wt, 0);
+#if D2D_DIAG
+    if (dbg & 8) {      // static priority by the wave's slot on its SIMD (waves w, w+4, w+8, w+12 share one)
+        const uint32_t slot = wave >> 2;
+        if (slot == 1) __builtin_amdgcn_s_setprio(1); else if (slot == 2) __builtin_amdgcn_s_setprio(2); else if (slot == 3) __builtin_amdgcn_s_setprio(3);
+    }
+    if (dbg & 32) {     // one-off start offset per slot
+        const uint32_t slot = wave >> 2;
+        for (uint32_t i = 0; i < slot * (dbg >> 8); ++i) __builtin_amdgcn_s_sleep(32);
+    }
+#endif
 
-    const bool reg_store_cfg = CH == 2 && C == 2 && Cs == 2 && sb == 3 && m.qsh == 0 && !m.wide && !a.to_scratch;
+    static_assert(EPI != 1 || CH == 2, "the register-packed epilogue is the stereo one");
+#if D2D_DIAG
+    unsigned long long st_sum[6] = {0, 0, 0, 0, 0, 0}, st_last = 0;
+    auto stamp = [&](int slot) {
+        if (dbg & 256) {
+            const unsigned long long t = __builtin_amdgcn_s_memtime();
+            if (slot >= 0) st_sum[slot] += t - st_last;
+            st_last = t;
+        }
+    };
+    stamp(-1);
+#else
+    auto stamp = [](int) {};
+#endif
+    // constants of the all-integer epilogue, parked in VGPRs (opaque to the compiler so that they stay there)
+    int32_t kF = m.fbits;
+    uint32_t kSh = 16u - (uint32_t)m.fbits, kSh17 = 17u - (uint32_t)m.fbits, kMask = (1u << m.fbits) - 1u;
+    uint32_t kC1 = 0x7feb352dU, kC2 = 0x846ca68bU, kTm = (uint32_t)-32767;
+    int32_t kBiasH = (int32_t)(1u << (a.scale_bits - m.fbits));
+    // |x| <= qmax - 2 LSB keeps x + d inside the range whatever the dither: v0 within 2^S -+ (qmax - 2) * 2^F
+    int32_t kHiSafe = (int32_t)((1u << a.scale_bits) + (((uint32_t)m.qmax_i - 2u) << m.fbits)), kLoSafe = (int32_t)((1u << a.scale_bits) - (((uint32_t)m.qmax_i - 2u) << m.fbits));
+    asm volatile("" : "+v"(kF), "+v"(kSh), "+v"(kSh17), "+v"(kMask), "+v"(kC1), "+v"(kC2), "+v"(kTm), "+v"(kBiasH), "+v"(kHiSafe), "+v"(kLoSafe));
+    const uint32_t lane_fr = 16u * r + 4u * h;              // the lane's first frame inside a tile
+    int32_t vmn[CH], vmx[CH];                               // running extremes of v0 = v + 2^S on the fast path
+#pragma unroll
+    for (int c = 0; c < CH; ++c) { vmn[c] = 1 << a.scale_bits; vmx[c] = 1 << a.scale_bits; }
+    // EPI 1: a full tile's packed frames
+    u32x4 pend4[2]; u32x2 pend2[2];
+    auto flush_pending = [&](uint32_t pend_wt) {
+        uint8_t* gout = reinterpret_cast<uint8_t*>(j0.out) + (size_t)pend_wt * (M2_TILE * 6) + 96u * r + 24u * h;
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            if (dbg & 64) { asm volatile("" :: "v"(pend4[g]), "v"(pend2[g])); continue; }
+            *reinterpret_cast<D2D_GLOBAL u32x4*>(as_global(gout + 48 * g)) = pend4[g];
+            *reinterpret_cast<D2D_GLOBAL u32x2*>(as_global(gout + 48 * g + 16)) = pend2[g];
+        }
+    };
     for (; wt < nwt; wt += wstride) {
         const bool full = wt * (uint32_t)M2_TILE + (uint32_t)M2_TILE <= j0.nout;
-        const bool reg_store = reg_store_cfg && full;
-        uint32_t held[8];                                   // channel 0's eight samples of the register-store path
+        uint32_t held[8];                                   // EPI 1: channel 0's eight samples
         static_for<0, CH>([&](auto cc_) {
             constexpr int c = decltype(cc_)::value;
             if ((uint32_t)c >= C) return;
             wave_sync2();                                   // the previous chain's reads are done (same wave: in order)
-            write_lds();
-            // next unit's bytes: in flight during this chain
-            if ((uint32_t)c + 1 < C) issue_loads(wt, c + 1);
-            else if (wt + wstride < nwt) issue_loads(wt + wstride, 0);
+            if (!(dbg & 4)) {
+                write_lds();
+                // next unit's bytes: in flight during this chain
+                if ((uint32_t)c + 1 < C) issue_loads(wt, c + 1);
+                else if (wt + wstride < nwt) issue_loads(wt + wstride, 0);
+            }
             wave_sync2();
+            stamp(0);
 
             // ---- the chain: TP pair steps, two groups of eight phases ----
+#if D2D_DIAG
+            if (dbg & 16) __builtin_amdgcn_s_setprio(3);
+#endif
             v16i acc[2];
-            {
+            if (dbg & 1) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) { acc[0][i] = (int)(lane * 128u * (i & 1)); acc[1][i] = (int)(r * 256u * (i & 1)); }
+            } else {
                 const v16i zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
                 static_for<0, TP>([&](auto uc) {
                     constexpr int u = decltype(uc)::value;
                     const uint32_t W = *reinterpret_cast<const uint32_t*>(rb + 4 * (2 * u + ((2 * u) >> LSH)));
+#ifndef D2D_M2_NO_VMASK
+                    const v4i lo = {(int)(W & km[0]), (int)(W & km[1]), (int)(W & km[2]), (int)(W & km[3])};
+                    const v4i hi = {(int)(W & km[4]), (int)(W & km[5]), (int)(W & km[6]), (int)(W & km[7])};
+#else
                     const v4i lo = {(int)(W & K1), (int)(W & (K1 << 1)), (int)(W & (K1 << 2)), (int)(W & (K1 << 3))};
                     const v4i hi = {(int)(W & (K1 << 4)), (int)(W & (K1 << 5)), (int)(W & (K1 << 6)), (int)(W & (K1 << 7))};
+#endif
                     static_for<0, 2>([&](auto gc) {
                         constexpr int g = decltype(gc)::value;
                         constexpr int pp = u - MB * g;
                         if constexpr (pp >= 0 && pp < NPG) {
+#ifdef D2D_M2_TAPREG
+                            const v4i F0 = tapreg[2 * pp], F1 = tapreg[2 * pp + 1];
+#else
                             const v4i F0 = tp[64 * (2 * pp)], F1 = tp[64 * (2 * pp + 1)];
+#endif
                             if constexpr (pp == 0) acc[g] = __builtin_amdgcn_mfma_i32_32x32x32_i8(F0, lo, zero, 0, 0, 0);
                             else acc[g] = __builtin_amdgcn_mfma_i32_32x32x32_i8(F0, lo, acc[g], 0, 0, 0);
                             acc[g] = __builtin_amdgcn_mfma_i32_32x32x32_i8(F1, hi, acc[g], 0, 0, 0);
@@ -261,6 +347,13 @@ __global__ __launch_bounds__(D2D_M2_THREADS) void d2d_fir_mfma2_kernel(Mfma2Args
                 });
             }
 
+#if D2D_DIAG
+            if (dbg & 16) { asm volatile("" :: "v"(acc[0][15]), "v"(acc[1][15])); __builtin_amdgcn_s_setprio(0); }
+#endif
+#if D2D_DIAG
+            if (dbg & 256) { asm volatile("" :: "v"(acc[0][15]), "v"(acc[1][15])); }
+#endif
+            stamp(1);
             // ---- epilogue: lane (r, h) owns outputs 16r + 8g + 4h + k of the tile, k = 0..3 ----
             const uint32_t nl_base = wt * (uint32_t)M2_TILE + 16u * r + 4u * h;      // + 8g + k
             auto recombine = [&](const v16i& A, int k, auto wide_tag) -> double {
@@ -338,50 +431,123 @@ __global__ __launch_bounds__(D2D_M2_THREADS) void d2d_fir_mfma2_kernel(Mfma2Args
                 return o;
             };
 
-            if (reg_store) {
-                // Stereo 24-bit, whole tile: no LDS round trip.  Per group the lane owns 4 consecutive frames
-                // of both channels = 24 contiguous output bytes.
+
+            if (dbg & 2) {
+                if (acc[0][0] == 0x12345 && acc[1][5] == 77 && acc[0][9] + acc[1][13] + acc[0][15] + acc[1][2] == 99) outw[lane] = 1;
+            } else if constexpr (EPI == 1) {
+                // Stereo 24-bit: no LDS round trip.  Per group the lane owns 4 consecutive frames of both
+                // channels = 24 contiguous output bytes.
                 auto body = [&](auto kind_tag, auto intq_tag) {
                     constexpr bool INTQ = decltype(intq_tag)::value;
                     uint32_t cur[8];
                     if constexpr (INTQ) {
-                        uint32_t vmax = 0;
+                        constexpr int KIND = decltype(kind_tag)::value;
+                        // Fast form: whole tile, no clip possible (running extremes of v inside the safe range), the
+                        // dither counter does not wrap inside the tile, no exact rounding tie in any lane.  Anything
+                        // else recomputes the tile with the general per-sample code below.  All constants sit in
+                        // VGPRs: a VOP2 with only VGPR operands issues at twice the rate of a VOP3 or of one that
+                        // reads an SGPR (tools/ubench/issue_rate.hip).
+                        const uint32_t first = (uint32_t)j0.n0 + wt * (uint32_t)M2_TILE;      // lo32 of the tile's first output index
+                        bool slow = !full || first > 0xFFFFFFFFu - (uint32_t)M2_TILE;
+                        if (!slow) {
+                            const uint32_t key_eff = rkey[c] + (first < rlo0[c] ? rstep[c] : 0u);
+                            const uint32_t zb = first + key_eff + lane_fr;                  // + 8g + k
+                            uint32_t anytie = 0;
 #pragma unroll
-                        for (int g = 0; g < 2; ++g)
+                            for (int g = 0; g < 2; ++g)
 #pragma unroll
-                            for (int k = 0; k < 4; ++k) {
-                                uint32_t va;
-                                cur[4 * g + k] = (uint32_t)quant_int(acc[g], k, nl_base + 8u * g + k, kind_tag, va);
-                                vmax = max(vmax, va);
-                            }
-                        // |x| = |v| * 2^-F exactly
-                        const double px = ldexp((double)vmax, -m.fbits);
-                        pk[c] = fmax(pk[c], px);
+                                for (int k = 0; k < 4; ++k) {
+                                    const v16i& A = acc[g];
+                                    // v0 = 2*sum q b = (A0 >> 6) + 4*A1 + 2^10*A2 + 2^18*A3  (A0 is a multiple of 128)
+                                    // (negative taps can take it below zero: signed, |v0 - 2^S| <= sum|q| keeps it inside int32)
+                                    uint32_t u0 = (uint32_t)(A[4 * k] >> 6);
+                                    u0 = ((uint32_t)A[4 * k + 1] << 2) + u0;
+                                    u0 = ((uint32_t)A[4 * k + 2] << 10) + u0;
+                                    u0 = ((uint32_t)A[4 * k + 3] << 18) + u0;
+                                    const int32_t v0 = (int32_t)u0;
+                                    vmn[c] = min(vmn[c], v0); vmx[c] = max(vmx[c], v0);
+                                    const uint32_t vhb = (uint32_t)(v0 >> kF);             // floor(x) + 2^(S-F)
+                                    const uint32_t vl = u0 & kMask;                        // fraction of x, F bits
+                                    int32_t cc;
+                                    if constexpr (KIND == 0) {
+                                        const int32_t w = (int32_t)((vl << kSh) + 32768u);
+                                        anytie |= (uint32_t)((w & 0xFFFF) == 0);
+                                        cc = w >> 16;
+                                    } else {
+                                        uint32_t z = zb + (uint32_t)(8 * g + k);
+                                        if (!(dbg & 128)) {
+                                        z ^= z >> 16; z *= kC1;
+                                        z ^= z >> 15; z *= kC2;
+                                        z ^= z >> 16;
+                                        }
+                                        if constexpr (KIND == 1) {
+                                            // units of 2^-16 LSB: x + (lo16 + hi16 + 1)*2^-16 - 1 + 1/2
+                                            const int32_t w = (int32_t)((vl << kSh) + __builtin_amdgcn_sad_u16(z, 0u, kTm));
+                                            anytie |= (uint32_t)((w & 0xFFFF) == 0);
+                                            cc = w >> 16;
+                                        } else {
+                                            // units of 2^-17 LSB: x + (2*hi16 + 1)*2^-17 - 1/2 + 1/2: odd, never a tie
+                                            const int32_t w = (int32_t)((vl << kSh17) + ((z >> 15) | 1u));
+                                            cc = w >> 17;
+                                        }
+                                    }
+                                    cur[4 * g + k] = (uint32_t)((int32_t)(vhb + (uint32_t)cc) - kBiasH);
+                                }
+                            // clip or tie anywhere in the wave: redo the tile the careful way
+                            slow = __builtin_amdgcn_ballot_w64(anytie != 0 || vmx[c] > kHiSafe || vmn[c] < kLoSafe) != 0;
+                        }
+                        if (slow) {
+                            uint32_t vmax = 0;
+#pragma unroll
+                            for (int g = 0; g < 2; ++g)
+#pragma unroll
+                                for (int k = 0; k < 4; ++k) {
+                                    uint32_t va;
+                                    cur[4 * g + k] = (uint32_t)quant_int(acc[g], k, nl_base + 8u * g + k, kind_tag, va);
+                                    vmax = max(vmax, full || nl_base + 8u * g + k < j0.nout ? va : 0u);
+                                }
+                            pk[c] = fmax(pk[c], ldexp((double)vmax, -m.fbits));   // |x| = |v| * 2^-F exactly
+                        }
                     } else {
 #pragma unroll
                         for (int g = 0; g < 2; ++g)
 #pragma unroll
                             for (int k = 0; k < 4; ++k) {
                                 const double x = recombine(acc[g], k, std::false_type{});
-                                asm("v_max_f64 %0, %1, |%2|" : "=v"(pk[c]) : "v"(pk[c]), "v"(x));
+                                const double cand = full || nl_base + 8u * g + k < j0.nout ? x : 0.0;
+                                asm("v_max_f64 %0, %1, |%2|" : "=v"(pk[c]) : "v"(pk[c]), "v"(cand));
                                 cur[4 * g + k] = (uint32_t)quant(x, nl_base + 8u * g + k, kind_tag);
                             }
                     }
-                    if (c == 0) {
+                    if constexpr (c == 0) {
 #pragma unroll
                         for (int i = 0; i < 8; ++i) held[i] = cur[i];
                     } else {
-                        uint8_t* gout = reinterpret_cast<uint8_t*>(j0.out) + (size_t)wt * (M2_TILE * 6) + 96u * r + 24u * h;
+                        if (full) {
 #pragma unroll
-                        for (int g = 0; g < 2; ++g) {
-                            // frames k, k+1 -> 12 bytes: [L0 L1 L2 R0 | R1 R2 L0' L1' | L2' R0' R1' R2']
-                            const uint32_t La = held[4 * g], Ra = cur[4 * g], Lb = held[4 * g + 1], Rb = cur[4 * g + 1];
-                            const uint32_t Lc = held[4 * g + 2], Rc = cur[4 * g + 2], Ld = held[4 * g + 3], Rd = cur[4 * g + 3];
-                            const u32x4 o4 = {__builtin_amdgcn_perm(Ra, La, 0x04020100u), __builtin_amdgcn_perm(Lb, Ra, 0x05040201u),
-                                              __builtin_amdgcn_perm(Rb, Lb, 0x06050402u), __builtin_amdgcn_perm(Rc, Lc, 0x04020100u)};
-                            const u32x2 o2 = {__builtin_amdgcn_perm(Ld, Rc, 0x05040201u), __builtin_amdgcn_perm(Rd, Ld, 0x06050402u)};
-                            *reinterpret_cast<D2D_GLOBAL u32x4*>(as_global(gout + 48 * g)) = o4;
-                            *reinterpret_cast<D2D_GLOBAL u32x2*>(as_global(gout + 48 * g + 16)) = o2;
+                            for (int g = 0; g < 2; ++g) {
+                                // frames k, k+1 -> 12 bytes: [L0 L1 L2 R0 | R1 R2 L0' L1' | L2' R0' R1' R2']
+                                const uint32_t La = held[4 * g], Ra = cur[4 * g], Lb = held[4 * g + 1], Rb = cur[4 * g + 1];
+                                const uint32_t Lc = held[4 * g + 2], Rc = cur[4 * g + 2], Ld = held[4 * g + 3], Rd = cur[4 * g + 3];
+                                pend4[g] = u32x4{__builtin_amdgcn_perm(Ra, La, 0x04020100u), __builtin_amdgcn_perm(Lb, Ra, 0x05040201u),
+                                                 __builtin_amdgcn_perm(Rb, Lb, 0x06050402u), __builtin_amdgcn_perm(Rc, Lc, 0x04020100u)};
+                                pend2[g] = u32x2{__builtin_amdgcn_perm(Ld, Rc, 0x05040201u), __builtin_amdgcn_perm(Rd, Ld, 0x06050402u)};
+                            }
+                            flush_pending(wt);
+                        } else {
+                            // the file's last, partial tile: frame by frame, three 2-byte stores each
+                            uint8_t* gout = reinterpret_cast<uint8_t*>(j0.out) + (size_t)wt * (M2_TILE * 6) + 96u * r + 24u * h;
+#pragma unroll 1
+                            for (int i = 0; i < 8; ++i) {
+                                const uint32_t g = (uint32_t)i >> 2, k = (uint32_t)i & 3u;
+                                if (nl_base + 8u * g + k < j0.nout) {
+                                    uint32_t L = 0, R = 0;
+#pragma unroll
+                                    for (int q = 0; q < 8; ++q) { L = i == q ? held[q] : L; R = i == q ? cur[q] : R; }
+                                    D2D_GLOBAL uint16_t* p16 = reinterpret_cast<D2D_GLOBAL uint16_t*>(as_global(gout + 48u * g + 6u * k));
+                                    p16[0] = (uint16_t)L; p16[1] = (uint16_t)(((L >> 16) & 0xFFu) | (R << 8)); p16[2] = (uint16_t)(R >> 8);
+                                }
+                            }
                         }
                     }
                 };
@@ -392,10 +558,9 @@ __global__ __launch_bounds__(D2D_M2_THREADS) void d2d_fir_mfma2_kernel(Mfma2Args
                 };
                 if (m.intq) by_kind(std::true_type{}); else by_kind(std::false_type{});
             } else {
-                // every other format: through the wave's LDS out-slice (or straight to the stage-A scratch)
-                auto finish = [&](auto full_tag, auto wide_tag, auto scratch_tag, auto kind_tag) {
+                // EPI 0: through the wave's LDS out-slice; EPI 2: straight to the stage-A scratch
+                auto finish = [&](auto full_tag, auto wide_tag, auto kind_tag) {
                     constexpr bool FULL = decltype(full_tag)::value;
-                    constexpr bool SCRATCH = decltype(scratch_tag)::value;
                     constexpr int KIND = decltype(kind_tag)::value;       // 0 none, 1 triangular, 2 rectangular, 3 float FPD
 #pragma unroll
                     for (int g = 0; g < 2; ++g) {
@@ -404,7 +569,7 @@ __global__ __launch_bounds__(D2D_M2_THREADS) void d2d_fir_mfma2_kernel(Mfma2Args
                         for (int k = 0; k < 4; ++k) xv[k] = recombine(acc[g], k, wide_tag);
                         const uint32_t fl0 = 16u * r + 8u * g + 4u * h;                  // frame inside the tile
                         const uint32_t nl0 = wt * (uint32_t)M2_TILE + fl0;
-                        if constexpr (SCRATCH) {
+                        if constexpr (EPI == 2) {
                             // stage A of the 48k cascade / input of the noise-shaping pass: the exact integers y*2^S
                             if (FULL || nl0 + 3 < j0.nout) {
                                 *reinterpret_cast<D2D_GLOBAL i32x4*>(as_global(jobs[c].xs + nl0)) =
@@ -451,18 +616,19 @@ __global__ __launch_bounds__(D2D_M2_THREADS) void d2d_fir_mfma2_kernel(Mfma2Args
                 };
                 auto kinds = [&](auto full_tag, auto wide_tag) {
                     using K0 = std::integral_constant<int, 0>;
-                    if (a.to_scratch) { finish(full_tag, wide_tag, std::true_type{}, K0{}); return; }
+                    if constexpr (EPI == 2) { finish(full_tag, wide_tag, K0{}); return; }
                     const uint32_t kind = a.epi.bits == 32 ? (a.epi.dither == 'F' ? 3u : 0u) : m.dkind;
-                    if (kind == 1) finish(full_tag, wide_tag, std::false_type{}, std::integral_constant<int, 1>{});
-                    else if (kind == 2) finish(full_tag, wide_tag, std::false_type{}, std::integral_constant<int, 2>{});
-                    else if (kind == 3) finish(full_tag, wide_tag, std::false_type{}, std::integral_constant<int, 3>{});
-                    else finish(full_tag, wide_tag, std::false_type{}, K0{});
+                    if (kind == 1) finish(full_tag, wide_tag, std::integral_constant<int, 1>{});
+                    else if (kind == 2) finish(full_tag, wide_tag, std::integral_constant<int, 2>{});
+                    else if (kind == 3) finish(full_tag, wide_tag, std::integral_constant<int, 3>{});
+                    else finish(full_tag, wide_tag, K0{});
                 };
                 auto wides = [&](auto full_tag) { if (m.wide) kinds(full_tag, std::true_type{}); else kinds(full_tag, std::false_type{}); };
                 if (full) wides(std::true_type{}); else wides(std::false_type{});
             }
+            stamp(2);
         });
-        if (!a.to_scratch && !reg_store) {
+        if (EPI == 0 && !(dbg & 2)) {
             wave_sync2();
             // the wave-tile's interleaved frames: LDS -> HBM, 16 bytes per lane per store
             const uint32_t left = j0.nout - wt * (uint32_t)M2_TILE;
@@ -483,13 +649,23 @@ __global__ __launch_bounds__(D2D_M2_THREADS) void d2d_fir_mfma2_kernel(Mfma2Args
             }
         }
     }
-    if (!a.to_scratch) {
+#if D2D_DIAG
+    if ((dbg & 256) && lane == 0)
+        for (int i = 0; i < 5; ++i) atomicAdd(&d2d_m2_stamps[i], st_sum[i]);
+#endif
+    if (EPI != 2) {
         // peak meter: |x| was tracked in the scaled domain; undo the power-of-two part exactly
         const double unscale = a.epi.bits == 32 ? 1.0 : 1.0 / (double)(1u << (a.epi.bits - 1));
 #pragma unroll
         for (int c = 0; c < CH; ++c) {
             if ((uint32_t)c >= C) continue;
-            double p = pk[c] * unscale;
+            double p = pk[c];
+            if (EPI == 1 && m.intq) {
+                const int32_t b = 1 << a.scale_bits;
+                const int32_t dev = max(vmx[c] - b, b - vmn[c]);
+                p = fmax(p, ldexp((double)dev, -m.fbits));
+            }
+            p *= unscale;
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) p = fmax(p, __shfl_xor(p, o));
             if (lane == 0 && p > 0.0)
@@ -562,6 +738,12 @@ bool mfma2_supported(int M, int N) {
     return false;
 }
 
+// the epilogue flavour of a launch: 2 = the integers for the stage-A scratch, 1 = stereo 24-bit packed in registers, 0 = anything via LDS
+static int mfma2_epilogue(const FirArgs& a, const Mfma2Args& m) {
+    if (a.to_scratch) return 2;
+    return a.epi.channels == 2 && a.epi.sample_bytes == 3 && m.qsh == 0 && !m.wide ? 1 : 0;
+}
+
 static void mfma2_geometry(const FirArgs& a, int MB, int NPG, Mfma2Args& m, size_t& smem) {
     m.ngroups = a.epi.channels <= 2 ? 1u : (a.epi.channels + 1u) / 2u;
     const uint32_t C = a.epi.channels <= 2 ? a.epi.channels : 2u;
@@ -577,16 +759,21 @@ static void mfma2_geometry(const FirArgs& a, int MB, int NPG, Mfma2Args& m, size
     m.wide = (uint64_t)NPG * 8u * 255u * 128u >= (1u << 23) ? 1u : 0u;
     m.fbits = a.scale_bits - ((int)a.epi.bits - 1);
     static const char* noint = getenv("D2D_NO_INTQ");
-    m.intq = (!noint && !a.to_scratch && a.epi.bits != 32 && a.epi.gain == 1.0 && !m.wide && m.fbits > 0 && m.fbits <= 16) ? 1u : 0u;
+    // (the fast form carries v0 = v + 2^S in an int32: 2^S + sum|q| has to stay below 2^31)
+    m.intq = (!noint && !a.to_scratch && a.epi.bits != 32 && a.epi.gain == 1.0 && !m.wide && m.fbits > 0 && m.fbits <= 16 &&
+              a.sum_abs_q != 0 && (1ull << a.scale_bits) + a.sum_abs_q < (1ull << 31)) ? 1u : 0u;
     m.off_waves = (uint32_t)(2 * NPG) * 1024u;
     m.off_out = (uint32_t)m2_stream_bytes(MB, NPG);
-    m.wave_lds = m.off_out + (((uint32_t)M2_TILE * C * a.epi.sample_bytes + 15u) & ~15u);
+    // (only the LDS-staged epilogue needs the output slice)
+    const bool lds_out = mfma2_epilogue(a, m) == 0;
+    m.wave_lds = m.off_out + (lds_out ? (((uint32_t)M2_TILE * C * a.epi.sample_bytes + 15u) & ~15u) : 0u);
+    { static const char* e = getenv("D2D_DBG"); m.dbg = e ? (uint32_t)atoi(e) : 0u; }
     static const char* wenv = getenv("D2D_MFMA_WAVES");   // diagnostic override
-    m.nwaves = wenv ? (uint32_t)atoi(wenv) : 16u;
-    if (m.nwaves < 1 || m.nwaves > 16) m.nwaves = 16;
+    m.nwaves = wenv ? (uint32_t)atoi(wenv) : 12u;
+    if (m.nwaves < 1 || m.nwaves > 12) m.nwaves = 12;
     // largest block that fits the CU's LDS, keeping the waves evenly spread over the four SIMDs
     while (m.nwaves > 1 && (size_t)m.off_waves + (size_t)m.nwaves * m.wave_lds > 160 * 1024)
-        m.nwaves = m.nwaves > 12 ? 12 : m.nwaves > 8 ? 8 : m.nwaves > 4 ? 4 : m.nwaves >> 1;
+        m.nwaves = m.nwaves > 8 ? 8 : m.nwaves > 4 ? 4 : m.nwaves >> 1;
     smem = (size_t)m.off_waves + (size_t)m.nwaves * m.wave_lds;
 }
 
@@ -599,11 +786,11 @@ size_t mfma2_smem_bytes(int M, int N, uint32_t channels, uint32_t sample_bytes, 
     return smem;
 }
 
-template <int MB, int NPG, int CH>
+template <int MB, int NPG, int CH, int EPI>
 static hipError_t launch_mfma2_t(Mfma2Args& m, size_t smem, uint32_t nwt_max, uint32_t nrows, hipStream_t s) {
     static KernelPrep prep;
     int dev = 0;
-    const void* fn = reinterpret_cast<const void*>(&d2d_fir_mfma2_kernel<MB, NPG, CH>);
+    const void* fn = reinterpret_cast<const void*>(&d2d_fir_mfma2_kernel<MB, NPG, CH, EPI>);
     hipError_t e = prep.max_dynamic_lds(fn, 160 * 1024, &dev);
     if (e != hipSuccess) return e;
     int blocks_per_cu, ncu;
@@ -615,7 +802,7 @@ static hipError_t launch_mfma2_t(Mfma2Args& m, size_t smem, uint32_t nwt_max, ui
             // the register file may admit fewer waves than LDS does: shrink the block until one fits
             int nb = 0;
             for (;;) {
-                e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, d2d_fir_mfma2_kernel<MB, NPG, CH>, (int)(64 * m.nwaves), smem);
+                e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, d2d_fir_mfma2_kernel<MB, NPG, CH, EPI>, (int)(64 * m.nwaves), smem);
                 if (e != hipSuccess) return e;
                 if (nb >= 1 || m.nwaves <= 4) break;
                 m.nwaves -= 4;
@@ -634,7 +821,7 @@ static hipError_t launch_mfma2_t(Mfma2Args& m, size_t smem, uint32_t nwt_max, ui
     if (gx < 1) gx = 1;
     const uint32_t need = (nwt_max + m.nwaves - 1) / m.nwaves;
     if (gx > need) gx = need;
-    hipLaunchKernelGGL((d2d_fir_mfma2_kernel<MB, NPG, CH>), dim3(gx, nrows), dim3(64 * m.nwaves), smem, s, m);
+    hipLaunchKernelGGL((d2d_fir_mfma2_kernel<MB, NPG, CH, EPI>), dim3(gx, nrows), dim3(64 * m.nwaves), smem, s, m);
     return hipGetLastError();
 }
 
@@ -648,12 +835,27 @@ hipError_t launch_fir_mfma2(const FirArgs& a, int M, int N, uint32_t max_nout, u
     const uint32_t nrows = (nstreams / C) * m.ngroups;       // grid rows: one per (file, channel group)
     if (smem > 160 * 1024) return hipErrorInvalidValue;
     const uint32_t nwt = (max_nout + (M2_TILE - 1)) / M2_TILE;
+    // the epilogue flavour: the integers for the stage-A scratch, stereo 24-bit packed in registers, or anything via LDS
+    const int epi = mfma2_epilogue(a, m);
 #define X(mb, npg)                                                                                  \
-    if (MB == mb && NPG == npg)                                                                     \
-        return C == 1 ? launch_mfma2_t<mb, npg, 1>(m, smem, nwt, nrows, s) : launch_mfma2_t<mb, npg, 2>(m, smem, nwt, nrows, s);
+    if (MB == mb && NPG == npg) {                                                                   \
+        if (C == 1) return epi == 2 ? launch_mfma2_t<mb, npg, 1, 2>(m, smem, nwt, nrows, s) : launch_mfma2_t<mb, npg, 1, 0>(m, smem, nwt, nrows, s); \
+        return epi == 2 ? launch_mfma2_t<mb, npg, 2, 2>(m, smem, nwt, nrows, s)                      \
+             : epi == 1 ? launch_mfma2_t<mb, npg, 2, 1>(m, smem, nwt, nrows, s) : launch_mfma2_t<mb, npg, 2, 0>(m, smem, nwt, nrows, s); \
+    }
     D2D_M2_SHAPES(X)
 #undef X
     return hipErrorInvalidValue;
 }
+
+#if D2D_DIAG
+void mfma2_debug_stamps(unsigned long long out[8]) {
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(d2d_m2_stamps), sizeof(unsigned long long) * 8);
+    unsigned long long z[8] = {0};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(d2d_m2_stamps), z, sizeof(z));
+}
+#else
+void mfma2_debug_stamps(unsigned long long out[8]) { for (int i = 0; i < 8; ++i) out[i] = 0; }
+#endif
 
 }  // namespace d2d

@@ -20,7 +20,6 @@ struct MfmaLayout {
 
 bool mfma_supported(int M, int N);
 MfmaLayout mfma_layout(int M, int N);
-uint32_t mfma_keep_bytes(const MfmaLayout& g, int Mb);
 size_t mfma_smem_bytes(const MfmaLayout& g, uint32_t channels, uint32_t sample_bytes, uint32_t* waves_per_block);
 std::vector<int8_t> build_mfma_tables(const d2d_filter_def& f, const MfmaLayout& g, bool msb_first);
 hipError_t launch_fir_mfma(const FirArgs& a, const MfmaLayout& g, uint32_t max_nout, uint32_t nstreams, hipStream_t s);
@@ -32,6 +31,7 @@ int mfma2_pairs(int M, int N);
 bool mfma2_supported(int M, int N);
 size_t mfma2_smem_bytes(int M, int N, uint32_t channels, uint32_t sample_bytes, uint32_t* waves_per_block);
 std::vector<int8_t> build_mfma2_tables(const d2d_filter_def& f, bool msb_first);
+void mfma2_debug_stamps(unsigned long long out[8]);   // diagnostic (make DIAG=1, D2D_DBG & 256)
 hipError_t launch_fir_mfma2(const FirArgs& a, int M, int N, uint32_t max_nout, uint32_t nstreams, hipStream_t s);
 
 }  // namespace d2d

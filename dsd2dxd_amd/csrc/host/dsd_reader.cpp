@@ -91,8 +91,13 @@ static std::string probe_dff(FILE* f, DsdInfo& o) {
         uint8_t ch[12];
         fseek(f, (long)pos, SEEK_SET);
         if (fread(ch, 1, 12, f) != 12) break;
-        const uint64_t sz = be64(ch + 4);
+        uint64_t sz = be64(ch + 4);
         const uint64_t body = pos + 12;
+        // a chunk cannot be longer than what is left of the file: clamp before any arithmetic on it (a size near 2^64
+        // would wrap `body + sz` back into the file and walk the same chunks for ever)
+        const bool overlong = sz > fsz - body;
+        const uint64_t sz_claimed = sz;
+        if (overlong) sz = fsz - body;
         if (!memcmp(ch, "PROP", 4)) {
             uint8_t t[4];
             if (fread(t, 1, 4, f) != 4 || memcmp(t, "SND ", 4)) return "DFF: PROP chunk is not SND";
@@ -101,7 +106,8 @@ static std::string probe_dff(FILE* f, DsdInfo& o) {
                 uint8_t sc[12];
                 fseek(f, (long)p, SEEK_SET);
                 if (fread(sc, 1, 12, f) != 12) break;
-                const uint64_t ssz = be64(sc + 4);
+                uint64_t ssz = be64(sc + 4);
+                if (ssz > pend - (p + 12)) ssz = pend - (p + 12);      // same clamp for the sub-chunks
                 if (!memcmp(sc, "FS  ", 4)) {
                     uint8_t v[4];
                     if (fread(v, 1, 4, f) == 4) { o.sample_rate = be32(v); have_fs = true; }
@@ -116,16 +122,18 @@ static std::string probe_dff(FILE* f, DsdInfo& o) {
             }
         } else if (!memcmp(ch, "DSD ", 4)) {
             o.data_offset = body;
-            uint64_t stored = sz;
-            if (body + stored > fsz) { stored = fsz - body; o.warning = "DFF: data chunk longer than the file; using what is there"; }
+            const uint64_t stored = sz;
+            if (overlong) o.warning = "DFF: data chunk longer than the file; using what is there";
             o.data_bytes = stored;
             have_data = true;
         } else if (!memcmp(ch, "ID3 ", 4)) {
             o.metadata_offset = pos;
-            if (body + sz > fsz) { o.metadata_truncated = true; if (o.warning.empty()) o.warning = "DFF: ID3 chunk is truncated; audio is intact"; }
+            if (overlong) { o.metadata_truncated = true; if (o.warning.empty()) o.warning = "DFF: ID3 chunk is truncated; audio is intact"; }
         } else if (!memcmp(ch, "DST ", 4)) {
             return "DFF: compressed (DST) audio is not supported";
         }
+        (void)sz_claimed;
+        if (overlong) break;                                   // nothing can follow a chunk that runs past the end
         pos = body + sz + (sz & 1);
     }
     if (!have_fs || !have_ch || !have_data) return "DFF: missing FS, CHNL or DSD chunk";

@@ -58,7 +58,11 @@ struct WavSink : PcmSink {
         hdr = o;
         return fwrite(h, 1, o, f) == o ? "" : "short write";
     }
-    std::string write(const uint8_t* p, size_t n) override { data += n; return fwrite(p, 1, n, f) == n ? "" : "short write"; }
+    std::string write(const uint8_t* p, size_t n) override {
+        // RIFF sizes are 32-bit: refuse at the first write that cannot be described, not at close() after hours of output
+        if (data + n + hdr + 8 + id3.size() + 2 > 0xFFFFFFFFull) return "WAV output exceeds 4 GiB (RIFF size fields are 32-bit); choose FLAC, a lower rate or depth";
+        data += n; return fwrite(p, 1, n, f) == n ? "" : "short write";
+    }
     std::string close() override {
         if (data & 1) fputc(0, f);
         uint64_t tail = 0;
@@ -112,6 +116,7 @@ struct AiffSink : PcmSink {
     }
     std::string write(const uint8_t* p, size_t n) override {           // little-endian samples -> big-endian
         const size_t sb = bits == 16 ? 2 : (bits == 32 ? 4 : 3);
+        if (data + n + 128 + id3.size() > 0xFFFFFFFFull) return "AIFF output exceeds 4 GiB (FORM size fields are 32-bit); choose FLAC, a lower rate or depth";
         tmp.resize(n);
         for (size_t i = 0; i + sb <= n; i += sb)
             for (size_t k = 0; k < sb; ++k) tmp[i + k] = p[i + sb - 1 - k];
@@ -383,6 +388,7 @@ std::string open_sink(OutputType type, const std::string& path, uint32_t channel
     if (type == OutputType::Stdout) { *out = new RawSink(stdout); return ""; }
     if (type == OutputType::Flac && bit_depth == 32) return "FLAC cannot hold 32-bit float; choose 16, 20 or 24 bits";
     if (type == OutputType::Flac && rate > 655350) return "FLAC cannot describe this sample rate";
+    if (type == OutputType::Flac && channels > 8) return "FLAC holds at most 8 channels";   // 4-bit channel assignment: 8..10 mean stereo decorrelation
     if (type == OutputType::Aiff && bit_depth == 32) return "AIFF cannot hold 32-bit float; use AIFC (C)";
     FILE* f = fopen(path.c_str(), "wb");
     if (!f) return "cannot create " + path;

@@ -195,6 +195,10 @@ const char* d2d_kernel_name(const d2d_engine* e);
  * reference prints per file -- asset/progress.jpg.) */
 int d2d_profile_enable(d2d_engine* e, int on);
 int d2d_profile_read(d2d_engine* e, double* fir_ms_total, uint64_t* launches);
+/* The same, plus the device time of EVERY kernel of the batch calls (de-interleave, FIR, noise-shaping
+ * or stage-B resampler, history carry): a second event pair around the whole call.  The two figures are
+ * the engine's "DSP speed" for single- and multi-kernel configurations. */
+int d2d_profile_read_all(d2d_engine* e, double* fir_ms_total, double* step_ms_total, uint64_t* launches);
 
 #ifdef __cplusplus
 }

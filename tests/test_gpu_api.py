@@ -196,6 +196,29 @@ def test_host_resident_batch_pipeline(engine_lib, oracle_mod, out_rate, fmt, pin
         e2.translate_batch_host(ios, 8192)
 
 
+@pytest.mark.parametrize("block", [100, 4100, 7])
+def test_host_resident_batch_with_odd_block_sizes(engine_lib, oracle_mod, block):
+    """slices of d2d_translate_batch_host must be whole planar blocks for ANY block size (-s takes any
+    value); rounding the slice to 16 bytes afterwards cut blocks in two and mixed the channels."""
+    import torch
+    kw = dict(KW, output_rate=88200, fmt="P", endianness="L", block_size=block)
+    lens = [block * 37 + 11, block * 5, block * 64]
+    files = [pack_layout([random_bytes(n, 160 + i), random_bytes(n, 170 + i)], "P", block) for i, n in enumerate(lens)]
+    e = engine_lib.Engine(n_files=len(lens), kernel=2, **kw)
+    fb = e.frame_bytes
+    want = [oracle_mod.Oracle(**kw).translate(f) for f in files]
+    ins = [torch.from_numpy(f.copy()).pin_memory() for f in files]
+    outs = [torch.zeros(rf * fb + 64, dtype=torch.uint8).pin_memory() for _, rf in want]
+    ios = (engine_lib.FileIO * len(lens))()
+    for i, n in enumerate(lens):
+        ios[i].dsd = ins[i].data_ptr(); ios[i].bytes_per_channel = n
+        ios[i].pcm = outs[i].data_ptr(); ios[i].pcm_capacity_bytes = outs[i].numel()
+    e.translate_batch_host(ios, max(block * 3 + 1, 1000))       # a slice that is NOT a block multiple by itself
+    for i, (r, rf) in enumerate(want):
+        assert ios[i].frames_out == rf, (i, ios[i].frames_out, rf)
+        assert np.array_equal(outs[i][:rf * fb].numpy(), r[:rf * fb]), (block, i)
+
+
 @pytest.mark.parametrize("kernel", [1, 2])
 @pytest.mark.parametrize("out_rate,fmt,bits", [(88200, "I", 24), (96000, "I", 24), (176400, "P", 16), (352800, "P", 32)])
 def test_channel_subsets_reproduce_the_full_conversion(engine_lib, oracle_mod, kernel, out_rate, fmt, bits):

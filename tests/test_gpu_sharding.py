@@ -1,0 +1,72 @@
+"""1 GPU == N GPUs with REAL engines: two engine processes on the one GPU of the test box share a
+batch -- by files (BASELINE config 4's split, /root/reference/src/main.rs:279-300) and by channels of one stream
+(config 5's split) -- with rank 0's table blob broadcast over gloo and imported, exactly as bench.py --gpus N
+does with RCCL.  The union of the shards must equal a single engine's conversion and the oracle's."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _run_ranks(mode, world, tmp_path):
+    port = _free_port()
+    outs = [str(tmp_path / f"{mode}_{r}.npz") for r in range(world)]
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "shard_worker.py"), mode, str(r), str(world), str(port), outs[r]],
+                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(world)]
+    for p in procs:
+        so, se = p.communicate(timeout=240)
+        assert p.returncode == 0, se[-3000:]
+    return [np.load(o) for o in outs]
+
+
+@pytest.mark.timeout(300)
+def test_two_engine_processes_share_a_batch_by_files(engine_lib, oracle_mod, tmp_path):
+    import shard_worker as W
+    from dsd2dxd_amd.shard import shard_range
+    parts = _run_ranks("files", 2, tmp_path)
+    assert "mfma" in str(parts[0]["kernel"])
+    e1 = engine_lib.Engine(n_files=1, kernel=2, **W.KW_FILES)
+    for rank, part in enumerate(parts):
+        b, e = shard_range(W.N_FILES, 2, rank)
+        for i, f in enumerate(range(b, e)):
+            buf = W.file_bytes(f)
+            want, fr = oracle_mod.Oracle(**W.KW_FILES).translate(buf)
+            assert np.array_equal(part["pcm%d" % i], want[:fr * 6]), (rank, f)
+            e1.reset()
+            single, fr1 = e1.translate(buf)
+            assert fr1 == fr and np.array_equal(part["pcm%d" % i], single)
+            assert [e1.peak(c) for c in range(2)] == list(part["peaks"][i])
+
+
+@pytest.mark.timeout(300)
+def test_two_engine_processes_split_one_stream_by_channel(engine_lib, oracle_mod, tmp_path):
+    import shard_worker as W
+    from dsd2dxd_amd.shard import merge_channel_frames, shard_channels
+    parts = _run_ranks("channels", 2, tmp_path)
+    buf = W.stream_bytes()
+    o = oracle_mod.Oracle(**W.KW_CHANNELS)
+    want, fr = o.translate(buf)
+    merged = merge_channel_frames([(*shard_channels(W.CHN, 2, r), parts[r]["pcm0"]) for r in range(2)], 3)
+    assert np.array_equal(merged, want[:fr * W.CHN * 3])
+    full = engine_lib.Engine(n_files=1, kernel=2, **W.KW_CHANNELS)
+    single, fr1 = full.translate(buf)
+    assert fr1 == fr and np.array_equal(merged, single)
+    for r in range(2):
+        first, count = shard_channels(W.CHN, 2, r)
+        assert list(parts[r]["peaks"][0]) == [full.peak(first + c) for c in range(count)] == [o.peak(first + c) for c in range(count)]

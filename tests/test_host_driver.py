@@ -189,17 +189,39 @@ def _flac_decode(path):
 
     def sgn(x, n):
         return x - (1 << n) if x >> (n - 1) else x
+    def crc(data, poly, width):
+        c, top, mask = 0, 1 << (width - 1), (1 << width) - 1
+        for byte in data:
+            c ^= byte << (width - 8)
+            for _ in range(8):
+                c = ((c << 1) ^ poly) & mask if c & top else (c << 1) & mask
+        return c
+    raw = b[mpos:]
     out = []
+    frame_no = 0
     while len(out) < total:
-        assert rd(16) == 0xFFF8
+        f0 = pos // 8                                  # frames start on byte boundaries
+        assert pos % 8 == 0 and rd(16) == 0xFFF8
         bsc = rd(4); rd(4); assert rd(4) == ch - 1; rd(3); rd(1)
+        # the frame number, "UTF-8" coded: consecutive from 0 (fixed block size stream)
         first = rd(8)
-        if first >= 0x80:
-            n = 1 if first < 0xE0 else 2 if first < 0xF0 else 3 if first < 0xF8 else 4
+        if first < 0x80:
+            num = first
+        else:
+            n = 1 if first < 0xE0 else 2 if first < 0xF0 else 3 if first < 0xF8 else 4 if first < 0xFC else 5
+            num = first & (0x3F >> n)
             for _ in range(n):
-                rd(8)
+                c = rd(8)
+                assert c >> 6 == 2
+                num = (num << 6) | (c & 0x3F)
+        assert num == frame_no, (num, frame_no)
+        frame_no += 1
         n = 4096 if bsc == 0xC else rd(16) + 1
+        # CRC-8 (x^8 + x^2 + x + 1) over the frame header up to here
+        assert pos % 8 == 0
         rd(8)
+        hdr_end = pos // 8 - 1
+        assert raw[hdr_end] == crc(raw[f0:hdr_end], 0x07, 8), "frame header CRC-8"
         chans = []
         for _ in range(ch):
             assert rd(1) == 0
@@ -221,7 +243,8 @@ def _flac_decode(path):
                     s.append(r + (2 * s[i - 1] - s[i - 2] if order == 2 else 0))
             chans.append(s)
         pos = (pos + 7) & ~7
-        rd(16)
+        # CRC-16 (x^16 + x^15 + x^2 + 1) over the whole frame before it
+        assert rd(16) == crc(raw[f0:pos // 8 - 2], 0x8005, 16), "frame CRC-16"
         out.extend(zip(*chans))
     return rate, ch, bps, np.array(out[:total], dtype=np.int64)
 

@@ -117,8 +117,12 @@ def fmt_i32(q):
 def main():
     filters = []   # dicts: name, type, M, N, S, q(list), method
 
+    unquantised = {}   # name -> the design's own f64 half taps (symmetrised, unity DC gain), before the 24-bit grid
+
     def add(name, ftype, M, h, method):
         S, q = quantise(h)
+        hn = np.asarray(h, dtype=np.float64) / np.sum(h)
+        unquantised[name] = [float(v).hex() for v in 0.5 * (hn[len(hn) // 2:] + hn[:len(hn) // 2][::-1])]
         full = np.concatenate([q[::-1], q]).astype(np.float64) * 2.0 ** -S
         w, mag = response_db(full, float(M))
         filters.append(dict(name=name, type=ftype, M=M, N=2 * len(q), S=S,
@@ -170,6 +174,9 @@ def main():
         print(f"B_{out_rate} L={L} P={P} N={N}", file=sys.stderr)
 
     os.makedirs(os.path.join(ROOT, "filters"), exist_ok=True)
+    # test data only (oracle/, tests/): what the 24-bit tap grid costs against the designs' f64 taps
+    with open(os.path.join(ROOT, "filters", "filter_taps_f64.json"), "w") as f:
+        json.dump(unquantised, f, indent=0)
     with open(os.path.join(ROOT, "filters", "filter_tables.json"), "w") as f:
         json.dump(dict(filters=filters,
                        resamplers=[{k: (v if k != "coef" else [x.hex() for x in v])

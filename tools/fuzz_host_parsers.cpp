@@ -16,6 +16,11 @@ int main(int argc,char**argv){
   const char* ext = strrchr(argv[1],'.');
   std::string tmp=std::string(std::string(argc > 4 ? argv[4] : "/tmp") + "/d2d_fuzz_m")+ext;
   unsigned x=seed; auto rnd=[&]{ x=x*1664525u+1013904223u; return x>>8; };
+  {  // the seed file as it is (regression files are fed this way, with 0 iterations)
+    DsdInfo info; std::string e=probe(argv[1],info);
+    if(e.empty()){ std::vector<uint8_t> tag; std::string w; read_source_tag(argv[1],info,tag,w);
+      DsdSource src; if(src.open(argv[1],info).empty()){ std::vector<uint8_t> buf(8192*std::max(1u,info.channels>64?64u:info.channels)); for(int q=0;q<4;++q){ long n=src.read(buf.data(),8192); if(n<=0) break; } } }
+  }
   for(int it=0;it<iters;++it){
     std::vector<uint8_t> b=base;
     int nm=1+rnd()%8;
