@@ -366,3 +366,24 @@ int orc_filter_info(const orc_ctx* c, int* M, int* ntaps, int* S, int* L, int* P
 }
 
 double orc_tap(const orc_ctx* c, int i) { return (i >= 0 && i < c->N) ? c->taps[i] : 0.0; }
+
+static void build_byte_tables(orc_ctx* c) {
+    int nt = c->Wb / 2;
+    for (int i = 0; i < nt; ++i)
+        for (int v = 0; v < 256; ++v) {
+            double acc = 0.0;
+            for (int m = 0; m < 8; ++m)
+                acc += (double)(((v >> (7 - m)) & 1) * 2 - 1) * c->taps[c->N / 2 + 8 * i + m];
+            c->lut[i * 256 + v] = acc;
+        }
+}
+
+int orc_set_half_taps(orc_ctx* c, const double* half, int n_half) {
+    if (!c || !half || n_half != c->N / 2) return -1;
+    for (int k = 0; k < n_half; ++k) {
+        c->taps[c->N / 2 + k] = half[k];
+        c->taps[c->N / 2 - 1 - k] = half[k];
+    }
+    build_byte_tables(c);
+    return 0;
+}

@@ -69,6 +69,11 @@ float  orc_peak_dbfs(const orc_ctx* c);                    /* 20*log10(max over 
 int    orc_filter_info(const orc_ctx* c, int* M, int* ntaps, int* S, int* resamp_L, int* resamp_P);
 /* full (both halves) tap i as f64; returns 0.0 outside */
 double orc_tap(const orc_ctx* c, int i);
+/* Replace the context's taps by `half` (ntaps/2 doubles, 2nd half centre-outward, any values) and rebuild the byte
+ * tables from them: with the designs' UNQUANTISED f64 taps (filters/filter_taps_f64.json) the context becomes the
+ * f64-tap reference that measures what this build's 24-bit tap grid costs (tests/test_tap_grid.py).  The sums are
+ * then ordinary f64 arithmetic in dsd2pcm's order (table i of the newer half + table i of the older half, i ascending). */
+int    orc_set_half_taps(orc_ctx* c, const double* half, int n_half);
 
 /* The dither generator, exposed so tests can pin it. */
 uint32_t orc_rng(uint64_t seed, uint32_t channel, uint64_t n);

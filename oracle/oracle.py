@@ -76,6 +76,7 @@ def _load(path):
     L.orc_filter_info.argtypes = [C.c_void_p] + [C.POINTER(C.c_int)] * 5
     L.orc_tap.argtypes = [C.c_void_p, C.c_int]
     L.orc_tap.restype = C.c_double
+    L.orc_set_half_taps.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
     L.orc_rng.argtypes = [C.c_uint64, C.c_uint32, C.c_uint64]
     L.orc_rng.restype = C.c_uint32
     _lib = L
@@ -120,6 +121,12 @@ class Oracle:
         v = [C.c_int() for _ in range(5)]
         lib().orc_filter_info(self._h, *[C.byref(x) for x in v])
         return dict(M=v[0].value, ntaps=v[1].value, S=v[2].value, L=v[3].value, P=v[4].value)
+
+    def set_half_taps(self, half):
+        """replace the taps (2nd half, centre outward) -- e.g. by the designs' unquantised f64 taps"""
+        a = np.ascontiguousarray(np.asarray(half, dtype=np.float64))
+        if lib().orc_set_half_taps(self._h, a.ctypes.data, a.size):
+            raise OracleError("tap count does not match the context's filter")
 
     def taps(self):
         n = self.info()["ntaps"]
