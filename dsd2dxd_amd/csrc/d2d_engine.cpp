@@ -62,7 +62,7 @@ struct d2d_engine {
     double* d_peak = nullptr;
     int32_t* d_scratch = nullptr; size_t scratch_stride = 0;  // stage-A integers per stream (multiple of 4)
     bool noise_shape = false;             // 'N' dither: the FIR writes integers, a sequential pass requantises
-    double* d_ns = nullptr;               // its state: two errors per stream
+    double* d_ns[2] = {nullptr, nullptr}; int ns_cur = 0;   // its state: two errors per stream, ping-pong between calls
     uint32_t xs_hist = 0;                 // samples carried in front of each scratch line (P of the resampler, else 0)
     StreamJob* d_jobs = nullptr;
     StreamJob* h_jobs = nullptr;          // pinned, JOB_SLOTS x nstreams
@@ -140,7 +140,7 @@ static void free_device(d2d_engine* e) {
     if (e->d_hist[1]) hipFree(e->d_hist[1]);
     if (e->d_peak) hipFree(e->d_peak);
     if (e->d_scratch) hipFree(e->d_scratch);
-    if (e->d_ns) hipFree(e->d_ns);
+    for (int i = 0; i < 2; ++i) if (e->d_ns[i]) hipFree(e->d_ns[i]);
     if (e->d_jobs) hipFree(e->d_jobs);
     if (e->h_jobs) hipHostFree(e->h_jobs);
     if (e->d_in) hipFree(e->d_in);
@@ -164,7 +164,7 @@ static int reset_state(d2d_engine* e) {
     HIPCHK(e, hipMemset(e->d_hist[1], idle, hbytes));
     HIPCHK(e, hipMemset(e->d_peak, 0, sizeof(double) * e->nstreams));
     if (e->d_scratch) HIPCHK(e, hipMemset(e->d_scratch, 0, sizeof(int32_t) * e->scratch_stride * e->nstreams));
-    if (e->d_ns) HIPCHK(e, hipMemset(e->d_ns, 0, sizeof(double) * 2 * e->nstreams));
+    for (int i = 0; i < 2; ++i) if (e->d_ns[i]) HIPCHK(e, hipMemset(e->d_ns[i], 0, sizeof(double) * 2 * e->nstreams));
     for (auto& f : e->files) f = FileState{};
     e->hist_cur = 0;
     return D2D_OK;
@@ -274,7 +274,7 @@ int d2d_create(const d2d_params* params, uint32_t n_files, d2d_engine** out) {
     if (e->noise_shape) {
         e->scratch_stride = 4096;
         CK(hipMalloc((void**)&e->d_scratch, sizeof(int32_t) * e->scratch_stride * e->nstreams));
-        CK(hipMalloc((void**)&e->d_ns, sizeof(double) * 2 * e->nstreams));
+        for (int i = 0; i < 2; ++i) CK(hipMalloc((void**)&e->d_ns[i], sizeof(double) * 2 * e->nstreams));
     }
     const size_t hbytes = (size_t)e->nstreams * e->keep;
     CK(hipMalloc((void**)&e->d_hist[0], hbytes));
@@ -460,8 +460,12 @@ int d2d_translate_batch_device(d2d_engine* e, d2d_file_io* io, uint32_t n_files,
     if (pe) HIPCHK(e, hipEventRecord(pe->second, s));
     if (e->noise_shape) {
         NoiseShapeArgs ns{};
-        ns.jobs = e->d_jobs; ns.state = e->d_ns; ns.scale_bits = e->S; ns.nstreams = e->nstreams; ns.max_nout = max_nx; ns.epi = e->epi;
+        ns.jobs = e->d_jobs; ns.state = e->d_ns[e->ns_cur]; ns.state_next = e->d_ns[e->ns_cur ^ 1];
+        ns.scale_bits = e->S; ns.nstreams = e->nstreams; ns.max_nout = max_nx; ns.epi = e->epi;
+        // a stream whose call ends exactly on a segment boundary, or feeds nothing, writes no state: start the next buffer from the current one
+        HIPCHK(e, hipMemcpyAsync(e->d_ns[e->ns_cur ^ 1], e->d_ns[e->ns_cur], sizeof(double) * 2 * e->nstreams, hipMemcpyDeviceToDevice, s));
         HIPCHK(e, launch_noise_shape(ns, s));
+        e->ns_cur ^= 1;
     }
     if (e->fc.resamp) {
         ResampArgs r{};

@@ -63,14 +63,15 @@ struct FirArgs {
     Epilogue epi;
 };
 
-// the noise-shaping pass ('N' dither): one thread per (stream, 65536-output segment) walks its integers in order
+// the noise-shaping pass ('N' dither): one lane per (8192-output segment, channel) walks its integers in order
 struct NoiseShapeArgs {
     const StreamJob* jobs;
-    double*  state;            // [nstreams][2]: the last two requantisation errors, carried from call to call
+    const double* state;       // [nstreams][2]: the last two requantisation errors carried INTO this call
+    double*  state_next;       // ... and out of it (ping-pong: reader and writer of a stream's state may be different blocks)
     int32_t  scale_bits;       // S: the scratch holds y * 2^S
     uint32_t nstreams;
     uint32_t max_nout;         // the longest stream's outputs this call (sizes the grid)
-    uint32_t reserved;
+    uint32_t cp_bits;          // log2(channels rounded up to a power of two): filled by the launcher
     Epilogue epi;
 };
 

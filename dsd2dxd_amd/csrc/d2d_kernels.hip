@@ -6,7 +6,7 @@
 //   d2d_resample_kernel<NT>  stage B of the 48k cascade: polyphase L/147 on f64, one fma per tap; lanes run along
 //                            cycles of L outputs so that coefficients are wave-uniform scalar operands
 //   d2d_deinterleave_kernel  byte-interleaved multichannel input -> the planar 4096-byte-block layout (one LDS pass)
-//   d2d_noise_shape_kernel   the 'N' dither extension: error-feedback requantiser, one thread per 65536-output segment
+//   d2d_noise_shape_kernel   the 'N' dither extension: error-feedback requantiser, one lane per (8192-output segment, channel)
 //   d2d_history_kernel       carries the last `keep` bytes per channel to the next call
 //   d2d_xhist_kernel         carries the last P stage-A outputs per channel to the next call
 //
@@ -363,60 +363,115 @@ __global__ __launch_bounds__(256) void d2d_deinterleave_kernel(const StreamJob* 
 //   w = x - (2*e1 - e2);  r = round_half_away(w + d);  e = r - w;  e2 = e1;  e1 = e
 // in exactly the oracle's operation order (emit_sample() in oracle/d2d_oracle.c).  The loop is a
 // recurrence through a rounding, so it cannot be reassociated; by definition it restarts from
-// e1 = e2 = 0 at every output index that is a multiple of NS_SEG, and one thread walks one such segment
-// (the part of it that lies in this call; a segment begun in an earlier call continues from the carried
-// state).  blockIdx.y = stream, blockIdx.x * 64 + threadIdx.x = segment of this call.
-constexpr uint32_t NS_SEG_BITS = 16;
+// e1 = e2 = 0 at every output index that is a multiple of NS_SEG = 8192 (0.093 s at 88.2 kHz), which is what
+// makes segments independent.  One LANE walks one (segment, channel); the lanes of a file's channels sit
+// side by side and share an LDS row per segment, in which eight whole frames are assembled and then
+// stored with 16-byte stores by the segment's first lane (a lane storing its own three bytes per frame
+// would touch 64 cache lines per store instruction: that, not the arithmetic, bounded the first version).
+//   blockIdx.y = file; a wave holds 64/Cp segments (Cp = channels rounded up to a power of two).
+constexpr uint32_t NS_SEG_BITS = 13;
+constexpr uint32_t NS_FRAMES = 8;          // frames assembled per flush
 
-__global__ __launch_bounds__(64) void d2d_noise_shape_kernel(NoiseShapeArgs a) {
-    const uint32_t sidx = blockIdx.y;
-    const StreamJob job = a.jobs[sidx];
-    if (job.nout == 0) return;
-    const uint64_t n_end = job.n0 + job.nout;
-    const uint64_t k0 = job.n0 >> NS_SEG_BITS, k1 = (n_end - 1) >> NS_SEG_BITS;
-    const uint64_t k = k0 + blockIdx.x * 64 + threadIdx.x;
-    if (k > k1) return;
+__global__ __launch_bounds__(256) void d2d_noise_shape_kernel(NoiseShapeArgs a) {
+    extern __shared__ __align__(16) unsigned char ns_smem[];
+    const uint32_t C = a.epi.channels, sb = a.epi.sample_bytes, fb = sb * C;
+    const uint32_t cp_bits = a.cp_bits, Cp = 1u << cp_bits;
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t ch = lane & (Cp - 1), sw = lane >> cp_bits;            // channel, segment slot inside the wave
+    const uint32_t spw = 64u >> cp_bits;                                  // segments per wave
+    const uint32_t file = blockIdx.y;
+    const StreamJob* jobs = a.jobs + (size_t)file * C;
+    const StreamJob j0 = jobs[0];                                          // n0, nout, out are common to a file's channels
+    if (j0.nout == 0) return;
+    const uint64_t n_end = j0.n0 + j0.nout;
+    const uint64_t k0 = j0.n0 >> NS_SEG_BITS, k1 = (n_end - 1) >> NS_SEG_BITS;
+    const uint64_t k = k0 + (uint64_t)(blockIdx.x * (blockDim.x >> 6) + wave) * spw + sw;
+    const bool active = k <= k1 && ch < C;
+    const uint32_t rb = NS_FRAMES * fb;                                    // row bytes (a multiple of 8)
+    const uint32_t rstride = rb + 4;                                       // + one pad dword: rows on distinct banks
+    uint8_t* row = ns_smem + (size_t)(wave * spw + sw) * rstride;
+    // (every lane of a wave runs the same number of loop trips; inactive ones do nothing inside)
     const uint64_t seg_lo = k << NS_SEG_BITS, seg_hi = (k + 1) << NS_SEG_BITS;
-    const uint32_t i0 = seg_lo > job.n0 ? (uint32_t)(seg_lo - job.n0) : 0u;
-    const uint32_t i1 = (uint32_t)((seg_hi < n_end ? seg_hi : n_end) - job.n0);
+    const uint32_t i0 = active ? (seg_lo > j0.n0 ? (uint32_t)(seg_lo - j0.n0) : 0u) : 0u;
+    const uint32_t i1 = active ? (uint32_t)((seg_hi < n_end ? seg_hi : n_end) - j0.n0) : 0u;
+    const StreamJob job = jobs[ch < C ? ch : 0];
     const D2D_GLOBAL int32_t* xs = as_global(job.xs);
-    uint8_t* out = reinterpret_cast<uint8_t*>(job.out) + job.och * a.epi.sample_bytes;
-    const uint32_t frame_bytes = a.epi.sample_bytes * a.epi.channels;
-    const bool carried = seg_lo < job.n0;                                  // begun in an earlier call
+    const uint32_t sidx = file * C + (ch < C ? ch : 0);
+    const bool carried = active && seg_lo < j0.n0;                         // begun in an earlier call
     double e1 = carried ? a.state[2 * sidx] : 0.0, e2 = carried ? a.state[2 * sidx + 1] : 0.0, pk = 0.0;
     const double lim = (double)(1u << (a.epi.bits - 1));
-    // few waves are resident (outputs/65536 threads per stream), so nothing hides a global load's
-    // latency but the thread itself: the integers are fetched NS_AHEAD at a time, then walked
-    constexpr uint32_t NS_AHEAD = 16;
-    auto step = [&](int32_t X, uint32_t i) {
-        const double y = ldexp((double)X, -a.scale_bits);                // exact
-        pk = fmax(pk, fabs(y * a.epi.gain));
-        const double x = y * a.epi.scale;
-        const uint32_t rnd = rng32(job, job.n0 + i);
-        const double d = (double)((rnd & 0xFFFFu) + (rnd >> 16) + 1u) * 0x1p-16 - 1.0;
-        const double fb = 2.0 * e1 - e2;
-        const double w = x - fb;
-        const double q = w + d;
-        const double r = trunc(q + copysign(0.5, q));
-        e2 = e1;
-        e1 = r - w;
-        int32_t iv = (int32_t)fmax(fmin(r, lim - 1.0), -lim);
-        if (a.epi.bits == 20) iv *= 16;
-        uint8_t* dst = out + (size_t)i * frame_bytes;
-        if (a.epi.bits == 16) { *reinterpret_cast<uint16_t*>(dst) = (uint16_t)iv; }
-        else { dst[0] = (uint8_t)iv; dst[1] = (uint8_t)(iv >> 8); dst[2] = (uint8_t)(iv >> 16); }
-    };
-    uint32_t i = i0;
-    for (; i + NS_AHEAD <= i1; i += NS_AHEAD) {
-        int32_t v[NS_AHEAD];
+    const double xscale = ldexp(a.epi.scale, -a.scale_bits);
+    uint32_t vmax = 0;                                                     // max |y * 2^S|: the peak, scaled back at the end
+    uint8_t* gout = reinterpret_cast<uint8_t*>(j0.out);
+    // dword stores need the segment's first byte on a dword boundary: true for a carried segment (the call's
+    // buffer is 16-byte aligned) and for every later one when (first index of the segment) * fb is a multiple of 4
+    const bool dw_ok = ((size_t)i0 * fb & 3u) == 0;
+    // longest run of steps any lane of the wave has
+    uint32_t len = i1 - i0;
 #pragma unroll
-        for (uint32_t u = 0; u < NS_AHEAD; ++u) v[u] = xs[i + u];
+    for (int o = 32; o > 0; o >>= 1) len = max(len, (uint32_t)__shfl_xor((int)len, o));
+    for (uint32_t t0 = 0; t0 < len; t0 += NS_FRAMES) {
+        // this lane's integers of the next eight steps (two 16-byte loads: 4-byte aligned is enough)
+        int32_t v[NS_FRAMES];
+        const uint32_t ib = i0 + t0;
+        if (active && ib + NS_FRAMES <= i1) {
+            typedef int32_t i32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
+            const i32x4_a4 lo4 = *reinterpret_cast<D2D_GLOBAL const i32x4_a4*>(xs + ib), hi4 = *reinterpret_cast<D2D_GLOBAL const i32x4_a4*>(xs + ib + 4);
+            v[0] = lo4.x; v[1] = lo4.y; v[2] = lo4.z; v[3] = lo4.w; v[4] = hi4.x; v[5] = hi4.y; v[6] = hi4.z; v[7] = hi4.w;
+        } else {
 #pragma unroll
-        for (uint32_t u = 0; u < NS_AHEAD; ++u) step(v[u], i + u);
+            for (uint32_t u = 0; u < NS_FRAMES; ++u) v[u] = (active && ib + u < i1) ? xs[ib + u] : 0;
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < NS_FRAMES; ++u) {
+            const uint32_t i = ib + u;
+            if (active && i < i1) {
+                // y = v * 2^-S is exact and x = y * scale rounds once: v * (scale * 2^-S) is the same product, rounded the same
+                vmax = max(vmax, (uint32_t)(v[u] < 0 ? -v[u] : v[u]));
+                const double x = (double)v[u] * xscale;
+                const uint32_t rnd = rng32(job, job.n0 + i);
+                const double d = (double)((rnd & 0xFFFFu) + (rnd >> 16) + 1u) * 0x1p-16 - 1.0;
+                const double fbk = 2.0 * e1 - e2;
+                const double w = x - fbk;
+                const double q = w + d;
+                const double r = trunc(q + copysign(0.5, q));
+                e2 = e1;
+                e1 = r - w;
+                int32_t iv = (int32_t)fmax(fmin(r, lim - 1.0), -lim);
+                if (a.epi.bits == 20) iv *= 16;
+                uint8_t* dst = row + u * fb + ch * sb;
+                if (sb == 2) { *reinterpret_cast<uint16_t*>(dst) = (uint16_t)iv; }
+                else { dst[0] = (uint8_t)iv; dst[1] = (uint8_t)(iv >> 8); dst[2] = (uint8_t)(iv >> 16); }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // the segment's first lane sends the assembled frames on their way
+        if (active && ch == 0 && ib < i1) {
+            const uint32_t nfr = min(NS_FRAMES, i1 - ib);
+            uint8_t* g = gout + (size_t)ib * fb;
+            const uint32_t nb = nfr * fb;
+            if (dw_ok && nfr == NS_FRAMES) {
+                uint32_t o = 0;
+                for (; o + 16 <= nb; o += 16)
+                    *reinterpret_cast<D2D_GLOBAL u32x4*>(as_global(g + o)) =
+                        u32x4{*reinterpret_cast<uint32_t*>(row + o), *reinterpret_cast<uint32_t*>(row + o + 4),
+                              *reinterpret_cast<uint32_t*>(row + o + 8), *reinterpret_cast<uint32_t*>(row + o + 12)};
+                for (; o < nb; o += 4) *reinterpret_cast<D2D_GLOBAL uint32_t*>(as_global(g + o)) = *reinterpret_cast<uint32_t*>(row + o);
+            } else {
+                for (uint32_t o = 0; o < nb; ++o) as_global(g)[o] = row[o];
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
-    for (; i < i1; ++i) step(xs[i], i);
-    if (k == k1) { a.state[2 * sidx] = e1; a.state[2 * sidx + 1] = e2; }   // the open segment's state travels on
-    if (pk > 0.0) atomicMax(reinterpret_cast<unsigned long long*>(job.peak), (unsigned long long)__double_as_longlong(pk));
+    // the open segment's state travels on -- into the OTHER state buffer: the lane that reads a stream's carried state and
+    // the lane that writes its new one may sit in different blocks
+    if (active && k == k1) { a.state_next[2 * sidx] = e1; a.state_next[2 * sidx + 1] = e2; }
+    pk = fabs(ldexp((double)vmax, -a.scale_bits) * a.epi.gain);            // |y * gain| is monotonic in |y|
+    if (active && pk > 0.0) atomicMax(reinterpret_cast<unsigned long long*>(job.peak), (unsigned long long)__double_as_longlong(pk));
 }
 
 // new_hist[j] = stream byte (L - keep + j), j in [0, keep)
@@ -531,10 +586,21 @@ hipError_t launch_deinterleave(const StreamJob* jobs, uint32_t nfiles, uint32_t 
     return hipGetLastError();
 }
 
-hipError_t launch_noise_shape(const NoiseShapeArgs& a, hipStream_t s) {
-    if (a.nstreams == 0) return hipSuccess;
+hipError_t launch_noise_shape(const NoiseShapeArgs& a0, hipStream_t s) {
+    if (a0.nstreams == 0) return hipSuccess;
+    NoiseShapeArgs a = a0;
+    const uint32_t C = a.epi.channels;
+    uint32_t cpb = 0;
+    while ((1u << cpb) < C) ++cpb;
+    if (cpb > 6) return hipErrorInvalidValue;                                  // at most 64 channels (d2d_create's limit)
+    a.cp_bits = cpb;
+    const uint32_t spw = 64u >> cpb;                                           // segments per wave
     const uint32_t max_seg = (a.max_nout >> NS_SEG_BITS) + 2;                 // segments one call can touch
-    hipLaunchKernelGGL(d2d_noise_shape_kernel, dim3((max_seg + 63) / 64, a.nstreams), dim3(64), 0, s, a);
+    const uint32_t waves = 4;                                                  // per block
+    const uint32_t fb = a.epi.sample_bytes * C;
+    const size_t smem = (size_t)waves * spw * (NS_FRAMES * fb + 4);
+    const uint32_t nfiles = a.nstreams / C;
+    hipLaunchKernelGGL(d2d_noise_shape_kernel, dim3((max_seg + waves * spw - 1) / (waves * spw), nfiles), dim3(64 * waves), smem, s, a);
     return hipGetLastError();
 }
 

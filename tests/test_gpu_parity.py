@@ -207,15 +207,15 @@ def test_noise_shaped_dither_matches_the_oracle(engine_lib, oracle_mod, dsd_rate
 
 @pytest.mark.parametrize("kernel", KERNELS)
 def test_noise_shaped_segments_restart_and_carry(engine_lib, oracle_mod, kernel):
-    """the shaper restarts at output indices that are multiples of 65536: calls that end inside a segment,
-    start exactly on a boundary, or span two boundaries all match the oracle"""
+    """the shaper restarts at output indices that are multiples of 8192: calls that end inside a segment,
+    start exactly on a boundary, or span several boundaries all match the oracle"""
     nbytes = 65536 * 2 + 5000                             # M = 8: one output per byte, 136072 outputs per channel
     chans = [synth("sine", nbytes, seed=3, msb_first=True, amp=0.4), synth("pink", nbytes, seed=4, amp=0.098, msb_first=True)]
-    cuts = [0, 30000, 65536, 65537, 131071, 135000, nbytes]
+    cuts = [0, 8191, 8192, 30000, 32768, 32769, 49151, 65536, 65537, 131071, 135000, nbytes]
     bufs = [pack_layout([ch[a:b] for ch in chans], "I", 1) for a, b in zip(cuts[:-1], cuts[1:])]
     kw = dict(dsd_rate=1, output_rate=352800, channels=2, fmt="I", endianness="M", block_size=1,
               filter="E", bit_depth=16, dither="N", seed=5)
     g, r, e, o = run_pair(engine_lib, oracle_mod, bufs, kw, kernel)
     assert np.array_equal(g, r)
     one, r1, _, _ = run_pair(engine_lib, oracle_mod, [pack_layout(chans, "I", 1)], kw, kernel)
-    assert np.array_equal(one, g)                          # one call (three segments side by side) == six calls
+    assert np.array_equal(one, g)                          # one call (nine segments side by side) == nine calls

@@ -259,7 +259,7 @@ def test_noise_shaped_dither_moves_the_error_out_of_band(oracle_mod):
     got = decode_pcm(r[:rf2 * 4], 16, 2)[:, 0]
     xs = pre.reshape(-1, 2)[:, 0] * 32768.0
     e1 = e2 = 0.0
-    for i in range(400):                                              # (the loop restarts at multiples of 65536)
+    for i in range(400):                                              # (the loop restarts at multiples of 8192)
         z = oracle_mod.rng(3, 0, i)
         d = ((z & 0xFFFF) + (z >> 16) + 1) * 2.0 ** -16 - 1.0
         w = xs[i] - (2.0 * e1 - e2)
