@@ -112,7 +112,9 @@ def make_files(n_files, bytes_per_channel, dsd_rate, distinct, rank, threads, ch
 
 def cpu_baseline(kw, files, threads, budget_s):
     """The CPU restatement on the host cores: one file per thread (the reference's Rayon policy,
-    src/main.rs:148-155,280-300: threads = logical cores / 2), chunked like its 4096-byte block loop."""
+    src/main.rs:148-155,280-300: threads = logical cores / 2), fed in chunks like its block loop, through the oracle
+    library's streaming organisation (orc_translate_stream: buffers kept between calls, integer byte tables, no bit
+    reversal -- the same bytes as the oracle, tests/test_oracle_kat.py)."""
     from oracle import oracle as O
     O.use_native()          # -O3 -march=native, built on this box
     chunk_blocks = 64
@@ -121,11 +123,12 @@ def cpu_baseline(kw, files, threads, budget_s):
     def work(buf):
         o = O.Oracle(**kw)
         step = 4096 * C_ * chunk_blocks          # (a multiple of every layout's block group)
+        out = None
         n = 0
         t0 = time.perf_counter()
         while time.perf_counter() - t0 < budget_s:        # the file again and again until the budget is spent
             for a in range(0, len(buf), step):
-                _, fr = o.translate(buf[a:a + step])
+                out, fr = o.translate_stream(buf[a:a + step], out)
                 n += fr * C_
                 if time.perf_counter() - t0 > budget_s:
                     break
@@ -359,7 +362,7 @@ def main():
         out["cpu_baseline"] = {"value": round(v, 3), "unit": "Msamples/s", "cores": threads, "kind": "port",
                                "per_thread": round(v / threads, 3),
                                "reference_screenshot_per_worker": REF_SCREENSHOT_MSAMPLES_PER_WORKER,
-                               "sample": f"{threads} streams of the same workload (one file per thread, threads = logical cores/2 as src/main.rs:148-155), {n} output samples in {secs:.1f} s; oracle/d2d_oracle.c byte-LUT f64, gcc -O3 -march=native"}
+                               "sample": f"{threads} streams of the same workload (one file per thread, threads = logical cores/2 as src/main.rs:148-155), {n} output samples in {secs:.1f} s; oracle/d2d_oracle.c orc_translate_stream (integer byte tables, f64 epilogue), gcc -O3 -march=native"}
     elif rank == 0:
         out["cpu_baseline"] = None
     if rank == 0:

@@ -727,7 +727,10 @@ std::vector<int8_t> build_mfma2_tables(const d2d_filter_def& f, bool msb_first) 
 #ifdef D2D_M2_DEV
 #define D2D_M2_SHAPES(X) X(4, 13)
 #else
-#define D2D_M2_SHAPES(X) X(1, 3) X(1, 4) X(2, 5) X(2, 6) X(2, 7) X(4, 10) X(4, 12) X(4, 13) X(8, 19) X(8, 24) X(8, 25)
+// M = 32 and 64 only: with 1 or 2 bytes per output a 512-output tile holds so little stream that the per-tile work
+// (staging, waits, the epilogue) outweighs the shorter chain and the one-group kernel is faster (measured: DSD64 -> 352.8 kHz
+// float 451 against 514 Gsamples/s, the M = 8 stage A of the 48k cascade 4.7 against 3.8 ms)
+#define D2D_M2_SHAPES(X) X(4, 10) X(4, 12) X(4, 13) X(8, 19) X(8, 24) X(8, 25)
 #endif
 
 bool mfma2_supported(int M, int N) {

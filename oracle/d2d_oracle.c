@@ -42,6 +42,9 @@ struct orc_ctx {
     uint64_t nres;    /* stage-B outputs so far */
     double* peak;     /* C */
     double* ns_err;   /* C x 2: the last two requantisation errors of the noise shaper ('N') */
+    /* streaming path (orc_translate_stream): integer byte tables in the stream's own bit order, buffers kept between calls */
+    int32_t* ilut;    /* Wb x 256 */
+    uint8_t* sbuf; size_t sbuf_cap;
 };
 
 static uint8_t bitrev8(uint8_t v) {
@@ -157,7 +160,7 @@ int orc_create(const orc_params* p, orc_ctx** out, const char** err) {
 
 void orc_destroy(orc_ctx* c) {
     if (!c) return;
-    free(c->taps); free(c->lut); free(c->hist_raw); free(c->xhist); free(c->peak); free(c->ns_err); free(c);
+    free(c->taps); free(c->lut); free(c->hist_raw); free(c->xhist); free(c->peak); free(c->ns_err); free(c->ilut); free(c->sbuf); free(c);
 }
 
 size_t orc_frame_bytes(const orc_ctx* c) {
@@ -350,6 +353,74 @@ int orc_translate_f64(orc_ctx* c, const uint8_t* dsd, size_t L, void* pcm_out, s
 
 int orc_translate(orc_ctx* c, const uint8_t* dsd, size_t L, void* pcm_out, size_t cap, size_t* frames_out) {
     return orc_translate_f64(c, dsd, L, pcm_out, cap, NULL, frames_out);
+}
+
+/* The same conversion organised the way a tuned CPU converter runs it (bench.py's cpu_baseline leg; checked against
+ * orc_translate by tests/test_oracle_kat.py): no per-call allocation, the channel's bytes gathered block by block into a
+ * buffer kept between calls, one 256-entry INTEGER table per window byte in the stream's own bit order (no bit reversal;
+ * the sums are the exact integers sum q*s, so any order gives the oracle's number), then the identical emit_sample().
+ * Integer decimator only (44.1k family, no 'N'); anything else is handed to orc_translate. */
+int orc_translate_stream(orc_ctx* c, const uint8_t* dsd, size_t L, void* pcm_out, size_t cap, size_t* frames_out) {
+    if (c->r || c->p.dither == 'N' || !pcm_out) return orc_translate_f64(c, dsd, L, pcm_out, cap, NULL, frames_out);
+    const uint32_t C = c->C;
+    const size_t keep = c->keep;
+    const int Wb = c->Wb;
+    if (!c->ilut) {
+        c->ilut = (int32_t*)malloc(sizeof(int32_t) * 256 * (size_t)Wb);
+        const int h = c->N / 2;
+        for (int k = 0; k < Wb; ++k)
+            for (int v = 0; v < 256; ++v) {
+                int64_t acc = 0;
+                for (int m = 0; m < 8; ++m) {
+                    const int j = 8 * k + m;                                  /* tap index = time index inside the window */
+                    const int64_t q = j >= h ? c->f->half[j - h] : c->f->half[h - 1 - j];
+                    const int bit = c->p.endianness ? (v >> (7 - m)) & 1 : (v >> m) & 1;
+                    acc += bit ? q : -q;
+                }
+                c->ilut[k * 256 + v] = (int32_t)acc;
+            }
+    }
+    uint64_t nfir1 = fir_outputs_after(c, c->pos + L);
+    size_t nx = (size_t)(nfir1 - c->nfir);
+    size_t fb = orc_frame_bytes(c), sb = fb / C;
+    if (frames_out) *frames_out = 0;
+    if (nx * fb > cap) return -20;
+    if (c->sbuf_cap < keep + L + 8) {
+        free(c->sbuf);
+        c->sbuf_cap = (keep + L + 8) * 2;
+        c->sbuf = (uint8_t*)malloc(c->sbuf_cap);
+    }
+    uint8_t* raw = c->sbuf;
+    const double ys = ldexp(1.0, -c->S);
+    for (uint32_t ch = 0; ch < C; ++ch) {
+        memcpy(raw, c->hist_raw + (size_t)ch * keep, keep);
+        if (c->B == 1) {
+            for (size_t j = 0; j < L; ++j) raw[keep + j] = dsd[j * C + ch];
+        } else {
+            for (size_t j = 0; j < L; j += c->B) {                            /* one memcpy per block of the channel */
+                size_t blen = L - j; if (blen > c->B) blen = c->B;
+                memcpy(raw + keep + j, dsd + (j / c->B) * (size_t)c->B * C + (size_t)ch * blen, blen);
+            }
+        }
+        double pk = c->peak[ch];
+        for (size_t i = 0; i < nx; ++i) {
+            const uint64_t n = c->nfir + i;
+            const uint8_t* w = raw + (size_t)((n + 1) * (uint64_t)c->Mb - c->pos) + keep - (size_t)Wb;
+            int32_t a0 = 0, a1 = 0;
+            const int32_t* t = c->ilut;
+            int k = 0;
+            for (; k + 1 < Wb; k += 2) { a0 += t[k * 256 + w[k]]; a1 += t[(k + 1) * 256 + w[k + 1]]; }
+            if (k < Wb) a0 += t[k * 256 + w[k]];
+            const double y = (double)(a0 + a1) * ys;                          /* exact: |sum q s| < 2^31 */
+            const double a = fabs(y * c->gain); if (a > pk) pk = a;
+            emit_sample(c, y, ch, n, (uint8_t*)pcm_out + i * fb + ch * sb);
+        }
+        c->peak[ch] = pk;
+        memcpy(c->hist_raw + (size_t)ch * keep, raw + L, keep);
+    }
+    c->pos += L; c->nfir = nfir1; c->nres = nfir1;
+    if (frames_out) *frames_out = nx;
+    return 0;
 }
 
 double orc_peak(const orc_ctx* c, uint32_t ch) { return ch < c->C ? c->peak[ch] : 0.0; }

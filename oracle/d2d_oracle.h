@@ -62,6 +62,11 @@ int orc_translate(orc_ctx* c, const uint8_t* dsd, size_t bytes_per_channel,
 int orc_translate_f64(orc_ctx* c, const uint8_t* dsd, size_t bytes_per_channel,
                       void* pcm_out, size_t pcm_capacity_bytes, double* f64_out, size_t* frames_out);
 
+/* The same bytes and state as orc_translate through a streaming organisation (preallocated buffers, integer byte tables
+ * in the stream's bit order): the CPU baseline that bench.py times.  Falls back to orc_translate where it does not apply. */
+int orc_translate_stream(orc_ctx* c, const uint8_t* dsd, size_t bytes_per_channel,
+                         void* pcm_out, size_t pcm_capacity_bytes, size_t* frames_out);
+
 double orc_peak(const orc_ctx* c, uint32_t channel);      /* max |sample*gain| so far */
 float  orc_peak_dbfs(const orc_ctx* c);                    /* 20*log10(max over channels) */
 

@@ -69,6 +69,8 @@ def _load(path):
     L.orc_translate_f64.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
                                 C.c_void_p, C.POINTER(C.c_size_t)]
     L.orc_translate_f64.restype = C.c_int
+    L.orc_translate_stream.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
+    L.orc_translate_stream.restype = C.c_int
     L.orc_peak.argtypes = [C.c_void_p, C.c_uint32]
     L.orc_peak.restype = C.c_double
     L.orc_peak_dbfs.argtypes = [C.c_void_p]
@@ -149,6 +151,21 @@ class Oracle:
             raise OracleError(f"translate failed: {rc}")
         assert frames.value == nmax
         return (out, frames.value, f64) if want_f64 else (out, frames.value)
+
+    def translate_stream(self, dsd, out=None):
+        """the streaming organisation of the same conversion (orc_translate_stream): identical bytes and state; `out`
+        may be a preallocated uint8 array that is reused from call to call (the timed CPU baseline does that)"""
+        buf = np.ascontiguousarray(np.frombuffer(dsd, dtype=np.uint8) if not isinstance(dsd, np.ndarray) else dsd)
+        bpc = buf.size // self.channels
+        L = lib()
+        nmax = L.orc_max_frames(self._h, bpc)
+        if out is None or out.size < nmax * self.frame_bytes:
+            out = np.zeros(nmax * self.frame_bytes, dtype=np.uint8)
+        frames = C.c_size_t()
+        rc = L.orc_translate_stream(self._h, buf.ctypes.data, bpc, out.ctypes.data, out.size, C.byref(frames))
+        if rc:
+            raise OracleError(f"translate failed: {rc}")
+        return out, frames.value
 
     def peak(self, ch):
         return lib().orc_peak(self._h, ch)

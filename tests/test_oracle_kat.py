@@ -267,3 +267,26 @@ def test_noise_shaped_dither_moves_the_error_out_of_band(oracle_mod):
         rr = np.floor(q + 0.5) if q >= 0 else np.ceil(q - 0.5)
         e2, e1 = e1, rr - w
         assert got[i] == int(rr), i
+
+
+@pytest.mark.parametrize("kw", [
+    dict(dsd_rate=1, output_rate=88200, channels=2, fmt="P", endianness="L", block_size=4096, filter="E", bit_depth=24, dither="T", seed=206),
+    dict(dsd_rate=1, output_rate=352800, channels=3, fmt="I", endianness="M", block_size=1, filter="D", bit_depth=32, dither="F", seed=1),
+    dict(dsd_rate=2, output_rate=176400, channels=1, fmt="P", endianness="M", block_size=100, filter="C", bit_depth=16, dither="R", seed=2, level_db=-3.0),
+    dict(dsd_rate=1, output_rate=96000, channels=2, fmt="P", endianness="L", block_size=4096, filter="E", bit_depth=24, dither="T", seed=3),
+])
+def test_streaming_cpu_path_equals_the_oracle(oracle_mod, kw):
+    """orc_translate_stream (what bench.py times as the CPU baseline) produces the oracle's bytes, peaks and state,
+    call after call, whatever the layout; configurations it does not cover (the 48k cascade) fall back to the oracle."""
+    C_ = kw["channels"]
+    blk = kw["block_size"] if kw["fmt"] == "P" else 1
+    n = blk * (9000 // blk + 3)
+    chans = [random_bytes(n, 700 + c) for c in range(C_)]
+    cuts = [0, blk * 2, blk * 2, blk * (n // blk - 1), n]
+    a, b = oracle_mod.Oracle(**kw), oracle_mod.Oracle(**kw)
+    for lo, hi in zip(cuts[:-1], cuts[1:]):
+        buf = pack_layout([ch[lo:hi] for ch in chans], kw["fmt"], blk) if hi > lo else np.zeros(0, np.uint8)
+        ra, fa = a.translate(buf)
+        rb, fbb = b.translate_stream(buf)
+        assert fa == fbb and np.array_equal(ra[:fa * a.frame_bytes], rb[:fbb * b.frame_bytes])
+    assert [a.peak(c) for c in range(C_)] == [b.peak(c) for c in range(C_)]
