@@ -80,6 +80,8 @@ struct M2Geom {
     static constexpr int LSH = MB == 1 ? 2 : MB == 2 ? 3 : MB == 4 ? 4 : MB == 8 ? 5 : 6;
 };
 
+// plane 0 unmasked: a byte then weighs up to 128*128 + 254*128 in a limb sum; the int32 recombination needs the sums below 2^23
+__host__ __device__ constexpr bool m2_unmask0(int NPG) { return (long long)NPG * 8 * (128 * 128 + 254 * 128) < (1 << 23); }
 __host__ __device__ constexpr int m2_span_dw(int MB, int NPG) { return 31 * 4 * MB + 2 * (NPG + MB); }
 __host__ __device__ constexpr int m2_chunks(int MB, int NPG) { return (m2_span_dw(MB, NPG) + 3 + 3) / 4; }   // + up to 3 dwords in front
 __host__ __device__ constexpr int m2_pf(int MB, int NPG) { return (m2_chunks(MB, NPG) + 63) / 64; }
@@ -324,7 +326,10 @@ __global__ __launch_bounds__(D2D_M2_THREADS) void d2d_fir_mfma2_kernel(Mfma2Args
                     constexpr int u = decltype(uc)::value;
                     const uint32_t W = *reinterpret_cast<const uint32_t*>(rb + 4 * (2 * u + ((2 * u) >> LSH)));
 #ifndef D2D_M2_NO_VMASK
-                    const v4i lo = {(int)(W & km[0]), (int)(W & km[1]), (int)(W & km[2]), (int)(W & km[3])};
+                    // plane 0 goes in UNMASKED where the limb sums allow it: as int8 a stream byte is the sum of its eight
+                    // masked planes, so the table's other planes carry (their tap - the plane-0 tap) and the products still
+                    // add up to 2^7 * q * bit exactly -- one v_and in eight less
+                    const v4i lo = {(int)(m2_unmask0(NPG) ? W : (W & km[0])), (int)(W & km[1]), (int)(W & km[2]), (int)(W & km[3])};
                     const v4i hi = {(int)(W & km[4]), (int)(W & km[5]), (int)(W & km[6]), (int)(W & km[7])};
 #else
                     const v4i lo = {(int)(W & K1), (int)(W & (K1 << 1)), (int)(W & (K1 << 2)), (int)(W & (K1 << 3))};
@@ -696,6 +701,7 @@ static inline int8_t limb_of2(int64_t v, int l) {
 // which arrives as 2^p (p = 7: -128): the table holds q * 2^(7-p), negated for p = 7.
 std::vector<int8_t> build_mfma2_tables(const d2d_filter_def& f, bool msb_first) {
     const int NPG = mfma2_pairs(f.M, f.ntaps);
+    const bool unmask0 = m2_unmask0(NPG);
     const size_t per = (size_t)(2 * NPG) * 64 * 16;
     std::vector<int8_t> t(4 * per, 0);
     for (int sh = 0; sh < 4; ++sh)                                  // window starts `sh` bytes into its first dword
@@ -711,13 +717,18 @@ std::vector<int8_t> build_mfma2_tables(const d2d_filter_def& f, bool msb_first) 
                     const int wb = 32 * (2 * pp + hh) + 8 * (j & 3) + p;                     // bit of the staged window
                     const int tau = (msb_first ? (wb & ~7) + 7 - (wb & 7) : wb) - 8 * sh;   // its time index in the window
                     const int tap = tau - ph * f.M;
-                    int8_t v = 0;
-                    if (tau >= 0 && tap >= 0 && tap < f.ntaps) {
-                        int64_t q = tap_q(f, tap);
-                        q = p == 7 ? -q : q * (int64_t)(1 << (7 - p));
-                        v = limb_of2(q, limb);
-                    }
-                    t[sh * per + ((size_t)fr * 64 + l) * 16 + j] = v;
+                    auto entry = [&](int pp_) -> int64_t {                                   // q * 2^(7-p) (p = 7: -q) of bit position pp_ of this byte
+                        const int wb_ = 32 * (2 * pp + hh) + 8 * (j & 3) + pp_;
+                        const int tau_ = (msb_first ? (wb_ & ~7) + 7 - (wb_ & 7) : wb_) - 8 * sh;
+                        const int tap_ = tau_ - ph * f.M;
+                        if (tau_ < 0 || tap_ < 0 || tap_ >= f.ntaps) return 0;
+                        const int64_t q = tap_q(f, tap_);
+                        return pp_ == 7 ? -q : q * (int64_t)(1 << (7 - pp_));
+                    };
+                    (void)tau; (void)tap;
+                    int64_t T = entry(p);
+                    if (unmask0 && p != 0) T -= entry(0);                                 // plane 0 arrives unmasked (see the kernel)
+                    t[sh * per + ((size_t)fr * 64 + l) * 16 + j] = limb_of2(T, limb);
                 }
             }
     return t;
@@ -759,7 +770,7 @@ static void mfma2_geometry(const FirArgs& a, int MB, int NPG, Mfma2Args& m, size
     m.qsh = a.epi.bits == 20 ? 4u : 0u;
     m.qmin_i = a.epi.bits == 32 ? 0 : -(1 << (a.epi.bits - 1)); m.qmax_i = a.epi.bits == 32 ? 0 : (1 << (a.epi.bits - 1)) - 1;
     // |limb sum| <= (bytes of a group's window) * 255 * 128; below 2^23 the pairs recombine in int32
-    m.wide = (uint64_t)NPG * 8u * 255u * 128u >= (1u << 23) ? 1u : 0u;
+    m.wide = m2_unmask0(NPG) ? 0u : ((uint64_t)NPG * 8u * 255u * 128u >= (1u << 23) ? 1u : 0u);
     m.fbits = a.scale_bits - ((int)a.epi.bits - 1);
     static const char* noint = getenv("D2D_NO_INTQ");
     // (the fast form carries v0 = v + 2^S in an int32: 2^S + sum|q| has to stay below 2^31)
