@@ -88,6 +88,25 @@ def spawn_ranks(n):
     return max(abs(rc) for rc in rcs)
 
 
+def usable_cpus():
+    """logical CPUs this process may really use: the affinity mask capped by the cgroup CPU quota (a GPU box hands each
+    lease a share of the host, e.g. 16 of 256)"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period) + 0.5)))
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read()); p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, int(q / p + 0.5)))
+        except Exception:
+            pass
+    return max(1, n)
+
+
 def make_files(n_files, bytes_per_channel, dsd_rate, distinct, rank, threads, channels=2, fmt="P", endian="L", block=4096):
     """Synthetic planar-4096 LSB-first stereo files: half 1 kHz-family sines at 0.352 FS, half pink
     noise at ~0.098 RMS.  `distinct` different files are generated and tiled."""
@@ -197,7 +216,7 @@ def main():
     kw = dict(dsd_rate=dsd_rate, output_rate=out_rate, channels=channels, fmt=fmt, endianness=endian,
               block_size=block, filter="E", bit_depth=bits, dither=dither, seed=206)
     kernel = {"auto": d.KERNEL_AUTO, "lut": d.KERNEL_LUT, "mfma": d.KERNEL_MFMA}[args.kernel]
-    ncpu = os.cpu_count() or 1
+    ncpu = usable_cpus()
     gen_threads = max(1, min(32, ncpu // max(1, min(world, 8))))
 
     if args.distinct <= 0:
@@ -362,7 +381,8 @@ def main():
         out["cpu_baseline"] = {"value": round(v, 3), "unit": "Msamples/s", "cores": threads, "kind": "port",
                                "per_thread": round(v / threads, 3),
                                "reference_screenshot_per_worker": REF_SCREENSHOT_MSAMPLES_PER_WORKER,
-                               "sample": f"{threads} streams of the same workload (one file per thread, threads = logical cores/2 as src/main.rs:148-155), {n} output samples in {secs:.1f} s; oracle/d2d_oracle.c orc_translate_stream (integer byte tables, f64 epilogue), gcc -O3 -march=native"}
+                               "host_cpus_usable": ncpu,
+                               "sample": f"{threads} streams of the same workload (one file per thread, threads = usable logical cores/2 as src/main.rs:148-155), {n} output samples in {secs:.1f} s; oracle/d2d_oracle.c orc_translate_stream (integer byte tables, f64 epilogue), gcc -O3 -march=native"}
     elif rank == 0:
         out["cpu_baseline"] = None
     if rank == 0:
