@@ -358,6 +358,46 @@ __global__ __launch_bounds__(MFMA_MAX_THREADS, 3) void d2d_fir_mfma_kernel(MfmaA
                 constexpr bool WIDE = decltype(wide_tag)::value;
                 constexpr bool SCRATCH = decltype(scratch_tag)::value;
                 constexpr int KIND = decltype(kind_tag)::value;          // 0 no noise word needed, 1 triangular, 2 rectangular, 3 float FPD
+                if constexpr (!WIDE) {
+                    // Two all-integer forms (no f64 instruction).  128*sum q b = lo + 65536*hi with lo a multiple of 128, so
+                    // v = sum q s = (lo >> 6) + (hi << 10) - 2^S in int32 (wraps are harmless, |v| < 2^31).
+                    //  * the stage-A scratch wants exactly v;
+                    //  * float output at 0 dB: x = v * 2^-S, and rounding v to f32 then scaling by the power of two is the same
+                    //    rounding as (float)x; |x| is monotonic in |v|, so the peak is tracked on v.
+                    const bool f32_int = KIND == 0 && a.epi.bits == 32 && m.c0 == 1.0 && !SCRATCH;
+                    if (SCRATCH || f32_int) {
+                        int32_t v[4];
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            const int32_t lo = acc[4 * k] + (acc[4 * k + 1] << 8);
+                            const uint32_t hi = (uint32_t)acc[4 * k + 2] + ((uint32_t)acc[4 * k + 3] << 8);
+                            v[k] = (int32_t)((uint32_t)(lo >> 6) + (hi << 10) - (1u << a.scale_bits));
+                        }
+                        const uint32_t nl0 = wt * 256u + (8 * r + 4 * h);
+                        if constexpr (SCRATCH) {
+                            typedef int32_t i32x4 __attribute__((ext_vector_type(4)));
+                            if (FULL || nl0 + 3 < j0.nout) {
+                                *reinterpret_cast<D2D_GLOBAL i32x4*>(as_global(jobs[c].xs + nl0)) = i32x4{v[0], v[1], v[2], v[3]};
+                            } else {
+#pragma unroll
+                                for (int k = 0; k < 4; ++k)
+                                    if (nl0 + k < j0.nout) as_global(jobs[c].xs)[nl0 + k] = v[k];
+                            }
+                        } else {
+                            const float sc = __builtin_ldexpf(1.0f, -a.scale_bits);
+                            uint32_t vm = 0;
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) {
+                                const bool ok = FULL || (nl0 + k < j0.nout);
+                                const uint32_t av = (uint32_t)(v[k] < 0 ? -v[k] : v[k]);
+                                vm = max(vm, ok ? av : 0u);
+                                *reinterpret_cast<float*>(outw + (size_t)((8 * r + 4 * h + k) * C + c) * 4) = (float)v[k] * sc;
+                            }
+                            pkw[c * 64 + lane] = fmax(pkw[c * 64 + lane], ldexp((double)vm, -a.scale_bits));
+                        }
+                        return;
+                    }
+                }
                 double xv[4];
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {

@@ -569,11 +569,33 @@ __global__ __launch_bounds__(D2D_M2_THREADS) void d2d_fir_mfma2_kernel(Mfma2Args
                     constexpr int KIND = decltype(kind_tag)::value;       // 0 none, 1 triangular, 2 rectangular, 3 float FPD
 #pragma unroll
                     for (int g = 0; g < 2; ++g) {
+                        const uint32_t fl0 = 16u * r + 8u * g + 4u * h;                  // frame inside the tile
+                        const uint32_t nl0 = wt * (uint32_t)M2_TILE + fl0;
+                        if constexpr (EPI == 2 && !decltype(wide_tag)::value) {
+                            // the scratch wants the exact integer y * 2^S = sum q s itself: (A0 >> 6) + 4*A1 + 2^10*A2 + 2^18*A3 - 2^S in
+                            // int32 (A0 is a multiple of 128; wraps are harmless, |sum q s| < 2^31) -- no f64 instruction
+                            int32_t iv[4];
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) {
+                                const v16i& A = acc[g];
+                                uint32_t u0 = (uint32_t)(A[4 * k] >> 6);
+                                u0 = ((uint32_t)A[4 * k + 1] << 2) + u0;
+                                u0 = ((uint32_t)A[4 * k + 2] << 10) + u0;
+                                u0 = ((uint32_t)A[4 * k + 3] << 18) + u0;
+                                iv[k] = (int32_t)(u0 - (1u << a.scale_bits));
+                            }
+                            if (FULL || nl0 + 3 < j0.nout) {
+                                *reinterpret_cast<D2D_GLOBAL i32x4*>(as_global(jobs[c].xs + nl0)) = i32x4{iv[0], iv[1], iv[2], iv[3]};
+                            } else {
+#pragma unroll
+                                for (int k = 0; k < 4; ++k)
+                                    if (nl0 + k < j0.nout) as_global(jobs[c].xs)[nl0 + k] = iv[k];
+                            }
+                            continue;
+                        }
                         double xv[4];
 #pragma unroll
                         for (int k = 0; k < 4; ++k) xv[k] = recombine(acc[g], k, wide_tag);
-                        const uint32_t fl0 = 16u * r + 8u * g + 4u * h;                  // frame inside the tile
-                        const uint32_t nl0 = wt * (uint32_t)M2_TILE + fl0;
                         if constexpr (EPI == 2) {
                             // stage A of the 48k cascade / input of the noise-shaping pass: the exact integers y*2^S
                             if (FULL || nl0 + 3 < j0.nout) {
