@@ -499,6 +499,7 @@ __global__ __launch_bounds__(MFMA_MAX_THREADS, 3) void d2d_fir_mfma_kernel(MfmaA
                 if (m.wide) kinds(std::true_type{}); else kinds(std::false_type{});
             };
             const bool reg_store = full && two && Cs == 2 && sb == 3 && m.qsh == 0 && !m.wide && !a.to_scratch;
+            bool stored_from_regs_now = false;
             if (dbg & 2) { if (acc0[0] == 0x12345 && acc1[5] == 77 && acc0[9] + acc1[13] + acc0[15] + acc1[2] == 99) outw[lane] = 1; }
             else if (reg_store) {
                 // Stereo 24-bit, whole tile: no LDS round trip.  Lane (r, h) owns frames 4h .. 4h+3 of
@@ -567,9 +568,33 @@ __global__ __launch_bounds__(MFMA_MAX_THREADS, 3) void d2d_fir_mfma_kernel(MfmaA
                 else if (m.dkind == 2) body(std::integral_constant<int, 2>{});
                 else body(std::integral_constant<int, 0>{});
             }
+            else if (full && two && Cs == 2 && a.epi.bits == 32 && !m.wide && !a.to_scratch && a.epi.dither != 'F' && m.c0 == 1.0) {
+                // Stereo float at 0 dB, whole tile: no LDS round trip either.  Lane (r, h) owns frames 4h .. 4h+3 of row r for
+                // both channels = 32 contiguous output bytes, two 16-byte stores; x = v * 2^-S with v = sum q s an int32, and
+                // rounding v to f32 then scaling by the power of two is the rounding of (float)x.
+                const float sc = __builtin_ldexpf(1.0f, -a.scale_bits);
+                uint32_t vm0 = 0, vm1 = 0;
+                float L[4], R[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int32_t lo0 = acc0[4 * k] + (acc0[4 * k + 1] << 8), lo1 = acc1[4 * k] + (acc1[4 * k + 1] << 8);
+                    const uint32_t hi0 = (uint32_t)acc0[4 * k + 2] + ((uint32_t)acc0[4 * k + 3] << 8), hi1 = (uint32_t)acc1[4 * k + 2] + ((uint32_t)acc1[4 * k + 3] << 8);
+                    const int32_t v0 = (int32_t)((uint32_t)(lo0 >> 6) + (hi0 << 10) - (1u << a.scale_bits));
+                    const int32_t v1 = (int32_t)((uint32_t)(lo1 >> 6) + (hi1 << 10) - (1u << a.scale_bits));
+                    vm0 = max(vm0, (uint32_t)(v0 < 0 ? -v0 : v0)); vm1 = max(vm1, (uint32_t)(v1 < 0 ? -v1 : v1));
+                    L[k] = (float)v0 * sc; R[k] = (float)v1 * sc;
+                }
+                pkw[c0 * 64 + lane] = fmax(pkw[c0 * 64 + lane], ldexp((double)vm0, -a.scale_bits));
+                pkw[c1 * 64 + lane] = fmax(pkw[c1 * 64 + lane], ldexp((double)vm1, -a.scale_bits));
+                typedef float f32x4 __attribute__((ext_vector_type(4)));
+                uint8_t* g = reinterpret_cast<uint8_t*>(j0.out) + (size_t)wt * 2048 + 64u * r + 32u * h;
+                *reinterpret_cast<D2D_GLOBAL f32x4*>(as_global(g)) = f32x4{L[0], R[0], L[1], R[1]};
+                *reinterpret_cast<D2D_GLOBAL f32x4*>(as_global(g + 16)) = f32x4{L[2], R[2], L[3], R[3]};
+                stored_from_regs_now = true;
+            }
             else if (full) finish_tile(std::true_type{});
             else finish_tile(std::false_type{});
-            stored_from_regs = reg_store;
+            stored_from_regs = reg_store || stored_from_regs_now;
         }
         stamp(3);
         if (!a.to_scratch && !(dbg & 4) && !stored_from_regs) {
