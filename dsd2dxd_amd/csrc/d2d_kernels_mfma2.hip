@@ -222,11 +222,6 @@ __global__ __launch_bounds__(D2D_M2_THREADS) void d2d_fir_mfma2_kernel(Mfma2Args
     // this lane's row window: staged dwords RS*r + 2u + h, u = 0 .. TP-1, padded by one dword per RS
     const uint8_t* rb = wbase + 4u * ((RS + 1) * r + h);
     const v4i* tp = reinterpret_cast<const v4i*>(smem) + lane;      // fragment f: tp[64 * f]
-#ifdef D2D_M2_TAPREG
-    v4i tapreg[2 * NPG];                                            // the whole tap table of this lane, resident
-#pragma unroll
-    for (int f = 0; f < 2 * NPG; ++f) tapreg[f] = tp[64 * f];
-#endif
     const uint32_t K1 = 0x01010101u;
 #ifndef D2D_M2_NO_VMASK
     // the eight plane masks parked in VGPRs: a VOP2 with only VGPR operands is the cheapest encoding to issue
@@ -339,11 +334,7 @@ __global__ __launch_bounds__(D2D_M2_THREADS) void d2d_fir_mfma2_kernel(Mfma2Args
                         constexpr int g = decltype(gc)::value;
                         constexpr int pp = u - MB * g;
                         if constexpr (pp >= 0 && pp < NPG) {
-#ifdef D2D_M2_TAPREG
-                            const v4i F0 = tapreg[2 * pp], F1 = tapreg[2 * pp + 1];
-#else
                             const v4i F0 = tp[64 * (2 * pp)], F1 = tp[64 * (2 * pp + 1)];
-#endif
                             if constexpr (pp == 0) acc[g] = __builtin_amdgcn_mfma_i32_32x32x32_i8(F0, lo, zero, 0, 0, 0);
                             else acc[g] = __builtin_amdgcn_mfma_i32_32x32x32_i8(F0, lo, acc[g], 0, 0, 0);
                             acc[g] = __builtin_amdgcn_mfma_i32_32x32x32_i8(F1, hi, acc[g], 0, 0, 0);
