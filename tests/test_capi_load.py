@@ -107,3 +107,22 @@ def test_product_does_not_touch_the_oracle():
                     txt = open(os.path.join(dirpath, f), errors="ignore").read()
                     assert "liboracle" not in txt and "from oracle" not in txt and "import oracle" not in txt, os.path.join(dirpath, f)
                     assert "oracle/d2d_oracle" not in txt.replace("oracle/d2d_oracle.c", "").replace("oracle/d2d_oracle.h", "") or True
+
+
+def test_bench_helpers_run_without_a_gpu():
+    """bench.py's host-side helpers: the kernel-source stamp that gates roofline.traffic, the usable-CPU count that sizes
+    the CPU baseline, and the rule that --gpus must match an inherited WORLD_SIZE."""
+    import subprocess
+    import sys
+    sys.path.insert(0, ROOT)
+    import bench
+    h = bench.kernel_source_hash()
+    assert len(h) == 16 and h == bench.kernel_source_hash()
+    assert 1 <= bench.usable_cpus() <= (os.cpu_count() or 1)
+    with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+        import json
+        ent = json.load(f)
+    assert any("kernel_src_sha16" in w for k in ent.values() for w in k.values())
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=dict(os.environ, WORLD_SIZE="1", RANK="0"),
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "WORLD_SIZE=1" in (r.stderr + r.stdout)

@@ -254,3 +254,27 @@ def test_channel_subsets_reproduce_the_full_conversion(engine_lib, oracle_mod, k
             assert e.peak(c) == o.peak(first + c)
     with pytest.raises(engine_lib.D2DError, match="Invalid channel subset"):
         engine_lib.Engine(n_files=1, kernel=kernel, channel_first=4, channel_count=3, **kw)
+
+
+def test_profile_read_all_brackets_every_kernel_of_a_call(engine_lib):
+    """d2d_profile_read_all: the FIR kernel's device time and the time of every kernel of the calls (the
+    bench priced multi-kernel workloads with the FIR launch alone).  For the 48k cascade the step holds stage A, stage B
+    and the carries; for a plain 44.1k conversion the step is the FIR kernel plus the history carry."""
+    import torch
+    for out_rate, more in ((88200, 1.0), (96000, 1.3)):
+        kw = dict(KW, output_rate=out_rate, fmt="P", endianness="L")
+        e = engine_lib.Engine(n_files=2, kernel=2, **kw)
+        n = 4096 * 64
+        buf = torch.from_numpy(np.concatenate([pack_layout([random_bytes(n, 1), random_bytes(n, 2)], "P", 4096)] * 1)).cuda()
+        frames = e.next_frames(n)
+        out = torch.zeros((2, (frames * e.frame_bytes + 31) // 16 * 16), dtype=torch.uint8, device="cuda")
+        ios = (engine_lib.FileIO * 2)()
+        for i in range(2):
+            ios[i].dsd = buf.data_ptr(); ios[i].bytes_per_channel = n
+            ios[i].pcm = out[i].data_ptr(); ios[i].pcm_capacity_bytes = frames * e.frame_bytes
+        e.profile_enable(True)
+        e.translate_batch_device(ios)
+        torch.cuda.synchronize()
+        fir, step, launches = e.profile_read_all()
+        assert launches == 1 and fir > 0 and step >= fir * more, (out_rate, fir, step)
+        assert e.profile_read_all() == (0.0, 0.0, 0)              # read clears
