@@ -9,7 +9,8 @@ KERNEL_AUTO, KERNEL_LUT, KERNEL_MFMA = 0, 1, 2
 
 
 def library_path():
-    return os.path.join(HERE, "libdsd2dxd_amd.so")
+    # D2D_AMD_LIB: development A/B builds of the same library (tools/ab_build.sh); never a different implementation
+    return os.environ.get("D2D_AMD_LIB") or os.path.join(HERE, "libdsd2dxd_amd.so")
 
 
 def build_library(force=False):
