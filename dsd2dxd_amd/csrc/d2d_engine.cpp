@@ -50,6 +50,7 @@ struct d2d_engine {
     LutLayout lut{};
     MfmaLayout mfma{};
     bool mfma_v2 = false;      // the two-group matrix-core kernel (d2d_kernels_mfma2.hip) serves this shape
+    bool mfma_pipe = false;    // ... through its software-pipelined variant (d2d_kernels_mfma3.hip): stereo 24-bit at 0 dB; its tap table masks every plane
     std::string kname;
     Epilogue epi{};
     std::string err;
@@ -170,6 +171,23 @@ static int reset_state(d2d_engine* e) {
     return D2D_OK;
 }
 
+// the part of a FIR launch's arguments that is fixed when the engine is created
+static void fir_args_static(const d2d_engine* e, FirArgs& a) {
+    a.tables = e->d_fir_tables;
+    a.Wb = (uint32_t)e->Wb;
+    a.ntab = (uint32_t)e->lut.ntab; a.pad = (uint32_t)e->lut.pad; a.nq = (uint32_t)e->lut.nq;
+    a.B = e->B; a.keep = e->keep;
+    a.to_scratch = (e->fc.resamp || e->noise_shape) ? 1u : 0u;
+    a.ksteps = (uint32_t)e->mfma.ksteps;
+    a.scale_bits = e->S;
+    a.in_channels = e->Cin;
+    uint64_t sa = 0;
+    for (int j = 0; j < e->N; ++j) { const int64_t q = tap_q(*e->fc.fir, j); sa += (uint64_t)(q < 0 ? -q : q); }
+    a.sum_abs_q = sa;
+    a.epi = e->epi;
+    a.pipelined = e->mfma_pipe ? 1u : 0u;
+}
+
 extern "C" {
 
 const char* d2d_create_error(void) { return g_create_error.c_str(); }
@@ -257,7 +275,8 @@ int d2d_create(const d2d_params* params, uint32_t n_files, d2d_engine** out) {
         CK(hipMalloc(&e->d_fir_tables, e->fir_table_bytes));
         CK(hipMemcpy(e->d_fir_tables, t.data(), e->fir_table_bytes, hipMemcpyHostToDevice));
     } else {
-        std::vector<int8_t> t = e->mfma_v2 ? build_mfma2_tables(f, msb) : build_mfma_tables(f, e->mfma, msb);
+        if (e->mfma_v2) { FirArgs a{}; fir_args_static(e, a); e->mfma_pipe = mfma2_pipelined(a, e->M, e->N); }
+        std::vector<int8_t> t = e->mfma_v2 ? build_mfma2_tables(f, msb, !e->mfma_pipe) : build_mfma_tables(f, e->mfma, msb);
         e->fir_table_bytes = t.size();
         CK(hipMalloc(&e->d_fir_tables, e->fir_table_bytes));
         CK(hipMemcpy(e->d_fir_tables, t.data(), e->fir_table_bytes, hipMemcpyHostToDevice));
@@ -423,20 +442,7 @@ int d2d_translate_batch_device(d2d_engine* e, d2d_file_io* io, uint32_t n_files,
 
     FirArgs a{};
     a.jobs = e->d_jobs;
-    a.tables = e->d_fir_tables;
-    a.Wb = (uint32_t)e->Wb;
-    a.ntab = (uint32_t)e->lut.ntab; a.pad = (uint32_t)e->lut.pad; a.nq = (uint32_t)e->lut.nq;
-    a.B = e->B; a.keep = e->keep;
-    a.to_scratch = (e->fc.resamp || e->noise_shape) ? 1u : 0u;
-    a.ksteps = (uint32_t)e->mfma.ksteps;
-    a.scale_bits = e->S;
-    a.in_channels = e->Cin;
-    {
-        uint64_t sa = 0;
-        for (int j = 0; j < e->N; ++j) { const int64_t q = tap_q(*e->fc.fir, j); sa += (uint64_t)(q < 0 ? -q : q); }
-        a.sum_abs_q = sa;
-    }
-    a.epi = e->epi;
+    fir_args_static(e, a);
     std::pair<hipEvent_t, hipEvent_t>* pe = nullptr;
     if (e->profiling && max_nx) {
         if (e->prof_used == e->prof_pool.size()) {
@@ -801,11 +807,17 @@ int d2d_get_info(const d2d_engine* e, d2d_info* out) {
 // diagnostic, not part of the public header: per-phase wave-cycle sums of the MFMA kernel (D2D_DBG=16)
 void d2d_debug_stamps(unsigned long long* out8) { hipDeviceSynchronize(); mfma_debug_stamps(out8); }
 void d2d_debug_stamps2(unsigned long long* out8) { hipDeviceSynchronize(); mfma2_debug_stamps(out8); }
+void d2d_debug_stamps3(unsigned long long* out8) { hipDeviceSynchronize(); mfma3_debug_stamps(out8); }
 
 const char* d2d_kernel_name(const d2d_engine* e) {
     if (!e) return "";
     if (e->kernel == D2D_KERNEL_MFMA && e->mfma_v2) {
         d2d_engine* m = const_cast<d2d_engine*>(e);
+        if (e->mfma_pipe) {
+            const int kind = e->epi.dither == 'T' ? 1 : e->epi.dither == 'R' ? 2 : 0;
+            m->kname = "d2d_fir_mfma3_kernel<" + std::to_string(e->Mb) + ", " + std::to_string(mfma2_pairs(e->M, e->N)) + ", " + std::to_string(kind) + ">";
+            return m->kname.c_str();
+        }
         m->kname = "d2d_fir_mfma2_kernel<" + std::to_string(e->Mb) + ", " + std::to_string(mfma2_pairs(e->M, e->N)) + ", " +
                    std::to_string(e->C == 1 ? 1 : 2) + ">";
         return m->kname.c_str();

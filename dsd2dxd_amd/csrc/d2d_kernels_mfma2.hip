@@ -25,90 +25,13 @@
 #include <stdio.h>
 #include <stdlib.h>
 
-#include <type_traits>
-
-#include "d2d_device.h"
-#include "d2d_launch.h"
-#include "d2d_mfma.h"
+#include "d2d_mfma2_dev.h"
 
 namespace d2d {
-
-typedef int v4i __attribute__((ext_vector_type(4)));
-typedef int v16i __attribute__((ext_vector_type(16)));
-typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-typedef int32_t i32x4 __attribute__((ext_vector_type(4)));
-
-template <int I, int N, class F>
-__device__ __forceinline__ void static_for(F&& f) {
-    if constexpr (I < N) {
-        f(std::integral_constant<int, I>{});
-        static_for<I + 1, N>(f);
-    }
-}
-
-struct Mfma2Args {
-    FirArgs f;
-    double c1, c0;        // x = fma(acc128, c1, -c0) == round(y*c0): c1 = 2^(1-S-7)*c0, c0 = scale | gain | 2^S
-    double dmul, dadd;    // integer depths: d = fma(term, dmul, dadd)
-    uint32_t dkind;       // 0: no dither, 1: triangular, 2: rectangular
-    uint32_t qsh;         // 4 for 20-bit samples in a 24-bit container, else 0
-    int32_t qmin_i, qmax_i;
-    uint32_t wide;        // 1: limb sums may exceed 2^23, recombine in f64
-    uint32_t off_waves;   // LDS: start of the per-wave regions (after the shared tap table)
-    uint32_t wave_lds;    // LDS bytes per wave
-    uint32_t off_out;     // the wave's output slice inside its region
-    uint32_t nwaves;      // waves per block
-    uint32_t ngroups;     // channel groups per file: 1 for mono/stereo, else one block row per channel PAIR
-    uint32_t intq;        // 1: unit gain at an integer depth -- the all-integer requantiser applies
-    int32_t  fbits;       // intq: x = v * 2^-fbits LSB (v = sum q s), fbits = S - (bits - 1)
-    uint32_t dbg;         // diagnostic ablation mask (make DIAG=1, env D2D_DBG): 1 no chain, 2 no epilogue, 4 no staging
-};
-
-#ifndef D2D_DIAG
-#define D2D_DIAG 0
-#endif
 
 #if D2D_DIAG
 __device__ unsigned long long d2d_m2_stamps[8];
 #endif
-
-constexpr int M2_TILE = 512;          // outputs per wave-tile and channel
-
-template <int MB>
-struct M2Geom {
-    static constexpr int RS = 4 * MB;                               // row stride in dwords (16 outputs)
-    static constexpr int LSH = MB == 1 ? 2 : MB == 2 ? 3 : MB == 4 ? 4 : MB == 8 ? 5 : 6;
-};
-
-// plane 0 unmasked: a byte then weighs up to 128*128 + 254*128 in a limb sum; the int32 recombination needs the sums below 2^23
-__host__ __device__ constexpr bool m2_unmask0(int NPG) { return (long long)NPG * 8 * (128 * 128 + 254 * 128) < (1 << 23); }
-__host__ __device__ constexpr int m2_span_dw(int MB, int NPG) { return 31 * 4 * MB + 2 * (NPG + MB); }
-__host__ __device__ constexpr int m2_chunks(int MB, int NPG) { return (m2_span_dw(MB, NPG) + 3 + 3) / 4; }   // + up to 3 dwords in front
-__host__ __device__ constexpr int m2_pf(int MB, int NPG) { return (m2_chunks(MB, NPG) + 63) / 64; }
-__host__ __device__ constexpr int m2_stream_bytes(int MB, int NPG) {
-    const int dw = 4 * 64 * m2_pf(MB, NPG);
-    const int lsh = MB == 1 ? 2 : MB == 2 ? 3 : MB == 4 ? 4 : MB == 8 ? 5 : 6;
-    return (((dw + (dw >> lsh) + 4) * 4 + 15) & ~15) + 16;   // + a dummy slot for the dwords in front of the window
-}
-
-__device__ __forceinline__ void wave_sync2() {
-    // LDS operations of one wave execute in order; this only stops the compiler from moving them.
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
-// 16 bytes of the channel's stream starting at call-relative byte j (any alignment): the slow,
-// always-right path (history, ragged blocks, interleaved layouts, call edges)
-__device__ __noinline__ u32x4 gather_chunk(const StreamJob* job, uint32_t C, uint32_t B, uint32_t keep, int32_t j) {
-    uint32_t w[4] = {0, 0, 0, 0};
-#pragma unroll 1
-    for (int b = 0; b < 16; ++b) {
-        const uint32_t x = stream_byte(*job, C, B, keep, j + b) << (8 * (b & 3));
-        if ((b >> 2) == 0) w[0] |= x; else if ((b >> 2) == 1) w[1] |= x; else if ((b >> 2) == 2) w[2] |= x; else w[3] |= x;
-    }
-    return u32x4{w[0], w[1], w[2], w[3]};
-}
 
 #ifndef D2D_M2_THREADS
 #define D2D_M2_THREADS 768
@@ -712,9 +635,9 @@ static inline int8_t limb_of2(int64_t v, int l) {
 // 4*slot + limb for the K slots of lane half hh = l >> 5, i.e. the staged dword 2*pp + hh of the window;
 // slot j of the lane = byte (j & 3), plane (j >> 2) -> bit position p = 4n + (j >> 2) of that byte,
 // which arrives as 2^p (p = 7: -128): the table holds q * 2^(7-p), negated for p = 7.
-std::vector<int8_t> build_mfma2_tables(const d2d_filter_def& f, bool msb_first) {
+std::vector<int8_t> build_mfma2_tables(const d2d_filter_def& f, bool msb_first, bool unmask0_wanted) {
     const int NPG = mfma2_pairs(f.M, f.ntaps);
-    const bool unmask0 = m2_unmask0(NPG);
+    const bool unmask0 = unmask0_wanted && m2_unmask0(NPG);
     const size_t per = (size_t)(2 * NPG) * 64 * 16;
     std::vector<int8_t> t(4 * per, 0);
     for (int sh = 0; sh < 4; ++sh)                                  // window starts `sh` bytes into its first dword
@@ -769,6 +692,24 @@ bool mfma2_supported(int M, int N) {
 static int mfma2_epilogue(const FirArgs& a, const Mfma2Args& m) {
     if (a.to_scratch) return 2;
     return a.epi.channels == 2 && a.epi.sample_bytes == 3 && m.qsh == 0 && !m.wide ? 1 : 0;
+}
+
+// the pipelined kernel serves the register-packed stereo flavour with the all-integer requantiser; its accumulators start
+// from -2^(S-18) in the limb-3 rows
+static bool mfma3_eligible(const FirArgs& a, const Mfma2Args& m, int MB, int NPG) {
+    return mfma2_epilogue(a, m) == 1 && m.intq && a.scale_bits >= 18 && a.scale_bits <= 30 && mfma3_supported(MB, NPG);
+}
+
+static void mfma2_geometry(const FirArgs& a, int MB, int NPG, Mfma2Args& m, size_t& smem);
+
+bool mfma2_pipelined(const FirArgs& a, int M, int N) {
+    static const char* nopipe = getenv("D2D_NO_PIPE");
+    if (nopipe && atoi(nopipe)) return false;
+    const int MB = M / 8, NPG = mfma2_pairs(M, N);
+    if (!mfma2_supported(M, N)) return false;
+    Mfma2Args m{}; size_t smem = 0;
+    mfma2_geometry(a, MB, NPG, m, smem);
+    return mfma3_eligible(a, m, MB, NPG);
 }
 
 static void mfma2_geometry(const FirArgs& a, int MB, int NPG, Mfma2Args& m, size_t& smem) {
@@ -864,6 +805,9 @@ hipError_t launch_fir_mfma2(const FirArgs& a, int M, int N, uint32_t max_nout, u
     const uint32_t nwt = (max_nout + (M2_TILE - 1)) / M2_TILE;
     // the epilogue flavour: the integers for the stage-A scratch, stereo 24-bit packed in registers, or anything via LDS
     const int epi = mfma2_epilogue(a, m);
+    // stereo 24-bit at 0 dB: the software-pipelined kernel (d2d_kernels_mfma3.hip), same results; the engine chose it (and its
+    // table variant) when it was created
+    if (a.pipelined) return launch_fir_mfma3(m, MB, NPG, nwt, nrows, s);
 #define X(mb, npg)                                                                                  \
     if (MB == mb && NPG == npg) {                                                                   \
         if (C == 1) return epi == 2 ? launch_mfma2_t<mb, npg, 1, 2>(m, smem, nwt, nrows, s) : launch_mfma2_t<mb, npg, 1, 0>(m, smem, nwt, nrows, s); \

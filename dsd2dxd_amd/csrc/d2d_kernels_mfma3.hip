@@ -1,0 +1,561 @@
+// d2d_kernels_mfma3.hip -- the two-group int8 matrix-core FIR decimator, software-pipelined (gfx950), exact.
+//
+// Same arithmetic, tap tables, staging and output as d2d_kernels_mfma2.hip's stereo 24-bit flavour at 0 dB (EPI = 1 with
+// the all-integer requantiser); what changes is WHEN a wave does the requantisation.  The two-group kernel alternates
+// between a matrix-core chain and a vector-only epilogue, and with three waves per SIMD the two kinds of phase overlap
+// only by chance (the parts of the kernel add up, profiles/r02_ablations.txt).  Here every chain carries the epilogue of
+// the chain before it inside its own instruction stream:
+//
+//   region A (tile t):  chain of channel 0  ||  requantise channel 1 of tile t-1, then pack + store tile t-1
+//   region B (tile t):  chain of channel 1  ||  requantise channel 0 of tile t
+//
+// so each wave keeps the matrix pipe and the vector issue port busy at the same time, whatever its neighbours do; two
+// accumulator sets are live, the kernel runs two waves per SIMD (up to 256 VGPRs).  The epilogue interleaved with a chain
+// is the branch-free fast form (whole tile, no clip possible, no exact rounding tie, dither counter not wrapping); a tile
+// that fails one of those tests is redone after the region from its stream bytes, which are still in the wave's LDS buffer
+// of that channel (one buffer per channel), by a plain chain and the general per-sample code -- identical results.
+//
+// The accumulators start from -2^S spread over the limb-3 rows (the MFMA's C operand) instead of zero, so a sample's limbs
+// recombine to v = sum q s directly (no bias to carry through the epilogue), and the requantiser is
+//   r = (v + (T >> (16 - F))) >> F,  T = lo16 + hi16 - 32767  (triangular; F = S - 23 fraction bits of x = v * 2^-F LSB)
+// which is floor(x + d + 1/2) exactly: floor((a + y) / n) = floor((a + floor(y)) / n) for integers a, n.
+//
+// Replaces: the per-block translate loop inside Rdsd2Pcm::do_conversion
+// (/root/reference/src/main.rs:345,429); the crate that holds it is absent from the reference.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+
+#include "d2d_mfma2_dev.h"
+
+namespace d2d {
+
+#define D2D_M3_THREADS 512
+
+#ifndef D2D_M3_ABL
+#define D2D_M3_ABL 0
+#endif
+#ifndef D2D_M3_STAMPS
+#define D2D_M3_STAMPS 0
+#endif
+#if D2D_M3_STAMPS
+// per-wave s_memtime ticks (-DD2D_M3_STAMPS=1): [0] min, [1] max, [2] sum, [3] count of the waves' lifetimes; sums over all waves of
+// [4] staging (waiting for the prefetch, LDS writes, next prefetch, stores), [5] the two regions (chain + epilogue), [6] what follows a region
+__device__ unsigned long long d2d_m3_stamps[8] = {~0ull, 0, 0, 0, 0, 0, 0, 0};
+#endif
+
+__device__ __forceinline__ int32_t m3_lshl_add(int32_t x, uint32_t sh, int32_t y) {
+    int32_t d;
+    asm("v_lshl_add_u32 %0, %1, %2, %3" : "=v"(d) : "v"(x), "v"(sh), "v"(y));
+    return d;
+}
+__device__ __forceinline__ uint32_t m3_min3_u16(uint32_t x, uint32_t y, uint32_t z) {
+    uint32_t d;
+    asm("v_min3_u16 %0, %1, %2, %3" : "=v"(d) : "v"(x), "v"(y), "v"(z));
+    return d;
+}
+__device__ __forceinline__ int32_t m3_min3(int32_t x, int32_t y, int32_t z) {
+    int32_t d;
+    asm("v_min3_i32 %0, %1, %2, %3" : "=v"(d) : "v"(x), "v"(y), "v"(z));
+    return d;
+}
+__device__ __forceinline__ int32_t m3_max3(int32_t x, int32_t y, int32_t z) {
+    int32_t d;
+    asm("v_max3_i32 %0, %1, %2, %3" : "=v"(d) : "v"(x), "v"(y), "v"(z));
+    return d;
+}
+
+// KIND: 0 no dither, 1 triangular, 2 rectangular.  Stereo, 24-bit packed frames, unit gain.
+template <int MB, int NPG, int KIND>
+__global__ __launch_bounds__(D2D_M3_THREADS) void d2d_fir_mfma3_kernel(Mfma2Args m) {
+    using G = M2Geom<MB>;
+    constexpr int RS = G::RS, LSH = G::LSH;
+    constexpr int TP = NPG + MB;                                    // pair steps of one chain
+    constexpr int NCHK = m2_chunks(MB, NPG);
+    constexpr int PF = m2_pf(MB, NPG);
+    constexpr uint32_t SB = (uint32_t)m2_stream_bytes(MB, NPG);
+    const FirArgs& a = m.f;
+    constexpr uint32_t dbg = D2D_M3_ABL;                  // compile-time ablation mask (tools/ab_build.sh <name> -DD2D_M3_ABL=<mask>): 1 no chain, 2 no epilogue, 4 no staging, 8 never slow, 16 zero taps, 64 no stores
+    extern __shared__ __align__(16) unsigned char smem[];
+    const uint32_t Ct = a.in_channels;                     // channels of the file (input layout); both channels of the frame are converted
+    const uint32_t fidx = blockIdx.y;
+    const uint32_t tid = threadIdx.x, lane = tid & 63;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    uint8_t* wbase = smem + m.off_waves + wave * m.wave_lds;       // [channel 0 stream buffer | channel 1 stream buffer]
+    const StreamJob* jobs = a.jobs + (size_t)fidx * 2;
+    const StreamJob j0 = jobs[0];          // in, L, e0, n0, nout are common to a file's channels
+
+    const int64_t first0 = j0.e0 - (int64_t)a.Wb;          // first byte of output 0's window
+    const uint32_t sh = (uint32_t)(first0 & 3);            // its misalignment inside the staged dword
+    {   // tap fragments: L2 -> LDS once per block; the variant for this byte misalignment
+        const uint4* s = reinterpret_cast<const uint4*>(a.tables) + (size_t)sh * (2 * NPG * 64);
+        uint4* dl = reinterpret_cast<uint4*>(smem);
+        for (uint32_t i = tid; i < 2 * NPG * 64; i += blockDim.x) dl[i] = (dbg & 16) ? uint4{0, 0, 0, 0} : s[i];      // (16: all-zero taps, a power experiment)
+    }
+    __syncthreads();
+
+    const uint32_t nwt = (j0.nout + (M2_TILE - 1)) / M2_TILE;      // wave-tiles in this file
+    const uint32_t wstride = gridDim.x * m.nwaves;
+    const uint32_t r = lane & 31, h = lane >> 5;
+
+    // ---- staging geometry: as in d2d_kernels_mfma2.hip ----
+    const uint32_t X0 = (uint32_t)(first0 >> 2) & 3u;
+    constexpr uint32_t DUMMY = SB - 16u;
+    uint32_t wlo[PF], whi[PF];
+#pragma unroll
+    for (int i = 0; i < PF; ++i) {
+        const uint32_t q = lane + 64u * i;
+        const uint32_t Lh = 4u * q;
+        whi[i] = 4u * (Lh + (Lh >> LSH)) - 4u * X0;
+        const uint32_t Ll = 4u * q - X0;
+        wlo[i] = q == 0 ? DUMMY : 4u * (Ll + (Ll >> LSH));
+    }
+    const uint32_t Bsz = a.B, Lcall = (uint32_t)j0.L;
+    const bool pow2B = Bsz >= 16 && (Bsz & (Bsz - 1)) == 0;
+    const uint32_t bshift = pow2B ? 31 - __builtin_clz(Bsz) : 0;
+    const uint32_t full_bytes = pow2B ? (Lcall >> bshift) << bshift : 0;
+    const uint32_t jump = (Ct - 1u) * Bsz;
+    const bool fast_layout = pow2B && (uint64_t)full_bytes * Ct < (1ull << 32) && jump < (1u << 24);
+    auto tile_ab16 = [&](uint32_t w) -> int32_t { return (int32_t)((first0 + (int64_t)w * (M2_TILE * MB)) & ~(int64_t)15); };
+
+    // per-lane chunk offsets: lanes past the last chunk of a tile re-read it (their LDS writes are masked off), so the loads
+    // need no predicate and their results no merge with older register contents
+    uint32_t lofs[PF];
+#pragma unroll
+    for (int i = 0; i < PF; ++i) { const uint32_t q = lane + 64u * i; lofs[i] = 16u * (q < (uint32_t)NCHK ? q : (uint32_t)NCHK - 1u); }
+    const uint32_t chf[2] = {(uint32_t)__builtin_amdgcn_readfirstlane((int)jobs[0].ch), (uint32_t)__builtin_amdgcn_readfirstlane((int)jobs[1].ch)};
+    u32x4 pf[PF];                                           // a chain's bytes are requested one chain ahead
+    auto issue_loads = [&](uint32_t w, auto cc) {
+        constexpr int c = decltype(cc)::value;
+        const int32_t ab = tile_ab16(w);
+        if (fast_layout && ab >= 0 && (uint32_t)ab + 16u * NCHK <= full_bytes) {
+            const uint32_t blk0 = (uint32_t)ab >> bshift, r0 = (uint32_t)ab & (Bsz - 1);
+            const uint8_t* base = j0.in + ((uint64_t)(blk0 * Ct + chf[c]) << bshift);
+#pragma unroll
+            for (int i = 0; i < PF; ++i) {
+                const uint32_t off = r0 + lofs[i];
+                const uint32_t o = __umul24(off >> bshift, jump) + off;
+                pf[i] = *reinterpret_cast<D2D_GLOBAL const u32x4*>(as_global(base) + o);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < PF; ++i) pf[i] = gather_chunk(jobs + c, Ct, a.B, a.keep, ab + (int32_t)lofs[i]);
+        }
+    };
+    auto write_lds_x = [&](auto cc, auto xc) {
+        constexpr int X = decltype(xc)::value;
+        constexpr int c = decltype(cc)::value;
+        uint8_t* buf = wbase + c * SB;
+#pragma unroll
+        for (int i = 0; i < PF; ++i)
+            if (lane + 64u * i < (uint32_t)NCHK) {
+                const uint32_t v[4] = {pf[i].x, pf[i].y, pf[i].z, pf[i].w};
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    *reinterpret_cast<uint32_t*>(buf + (k < X ? wlo[i] : whi[i]) + 4 * k) = v[k];
+            }
+    };
+    auto write_lds = [&](auto cc) {
+        if (X0 == 0) write_lds_x(cc, std::integral_constant<int, 0>{});
+        else if (X0 == 1) write_lds_x(cc, std::integral_constant<int, 1>{});
+        else if (X0 == 2) write_lds_x(cc, std::integral_constant<int, 2>{});
+        else write_lds_x(cc, std::integral_constant<int, 3>{});
+    };
+
+    // this lane's row window: staged dwords RS*r + 2u + h, u = 0 .. TP-1, padded by one dword per RS
+    const uint8_t* rb0 = wbase + 4u * ((RS + 1) * r + h);
+    const uint8_t* rb1 = rb0 + SB;
+    const v4i* tp = reinterpret_cast<const v4i*>(smem) + lane;      // fragment f: tp[64 * f]
+    uint32_t km[8];
+#pragma unroll
+    for (int p_ = 0; p_ < 8; ++p_) { km[p_] = 0x01010101u << p_; asm volatile("" : "+v"(km[p_])); }
+    // accumulators start from -2^S: 128 * (-2^(S-1)) = -2^(S+6) = limb 3 (weight 2^24) times -2^(S-18)
+    v16i cinit;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) cinit[i] = (i & 3) == 3 ? -(1 << (a.scale_bits - 18)) : 0;
+    asm volatile("" : "+v"(cinit));
+
+    // One chain: TP pair steps, two groups of eight phases; the LDS reads of a step are issued one step ahead; `hook(u)` is
+    // whatever else the wave does during step u.
+    auto chain = [&](const uint8_t* rbc, v16i& acc0, v16i& acc1, auto&& hook) {
+        uint32_t W[TP];
+        v4i F[2 * NPG];
+        auto rdW = [&](auto uc) { constexpr int u = decltype(uc)::value; W[u] = *reinterpret_cast<const uint32_t*>(rbc + 4 * (2 * u + ((2 * u) >> LSH))); };
+        auto rdF = [&](auto uc) { constexpr int u = decltype(uc)::value; F[2 * u] = tp[64 * (2 * u)]; F[2 * u + 1] = tp[64 * (2 * u + 1)]; };
+        constexpr int AHEAD = 2;                                    // LDS reads run this many steps ahead of their use
+        static_for<0, AHEAD>([&](auto uc) { rdW(uc); rdF(uc); });
+        static_for<0, TP>([&](auto uc) {
+            constexpr int u = decltype(uc)::value;
+            if constexpr (u + AHEAD < TP) rdW(std::integral_constant<int, u + AHEAD>{});
+            if constexpr (u + AHEAD < NPG) rdF(std::integral_constant<int, u + AHEAD>{});
+            const uint32_t w = W[u];
+            const v4i lo = {(int)(w & km[0]), (int)(w & km[1]), (int)(w & km[2]), (int)(w & km[3])};   // every plane masked: a raw byte operand costs more power than its v_and saves
+            const v4i hi = {(int)(w & km[4]), (int)(w & km[5]), (int)(w & km[6]), (int)(w & km[7])};
+            if constexpr (u < NPG) {
+                if constexpr (u == 0) acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(F[0], lo, cinit, 0, 0, 0);
+                else acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(F[2 * u], lo, acc0, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(F[2 * u + 1], hi, acc0, 0, 0, 0);
+            }
+            if constexpr (u >= MB && u - MB < NPG) {
+                constexpr int pp = u - MB;
+                if constexpr (pp == 0) acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(F[0], lo, cinit, 0, 0, 0);
+                else acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(F[2 * pp], lo, acc1, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(F[2 * pp + 1], hi, acc1, 0, 0, 0);
+            }
+            hook(uc);
+            __builtin_amdgcn_sched_barrier(0);
+        });
+    };
+    auto no_hook = [](auto) {};
+
+    // dither keys of the two channels (uniform)
+    uint32_t rkey[2], rstep[2], rlo0[2];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) { rkey[c] = jobs[c].rng_key; rstep[c] = jobs[c].rng_kstep; rlo0[c] = jobs[c].rng_lo0; }
+    double pk[2] = {0.0, 0.0};                              // peaks met on the slow path, in LSB
+    int32_t vmn[2] = {0, 0}, vmx[2] = {0, 0};               // running extremes of v on the fast path
+
+    // constants of the fast epilogue, parked in VGPRs
+    const int F_ = m.fbits;                                 // 0 < F <= 16
+    uint32_t kF = (uint32_t)F_, kSh = 16u - (uint32_t)F_, kShR = 32u - (uint32_t)F_;
+    uint32_t kC1 = 0x7feb352dU, kC2 = 0x846ca68bU, kTm = (uint32_t)-32767;
+    uint32_t k2 = 2u, k10 = 10u, k18 = 18u;
+    int32_t kHalf = 1 << (F_ - 1);
+    asm volatile("" : "+v"(kF), "+v"(kSh), "+v"(kShR), "+v"(kC1), "+v"(kC2), "+v"(kTm), "+v"(k2), "+v"(k10), "+v"(k18), "+v"(kHalf));
+    // |x| <= qmax - 2 LSB keeps x + d inside the range whatever the dither
+    const int32_t kSafe = (int32_t)(((uint32_t)m.qmax_i - 2u) << F_);
+    const uint32_t lane_fr = 16u * r + 4u * h;              // the lane's first frame inside a tile
+
+    // v = sum q s of sample k of a group's accumulators: (A0 >> 6) + 4*A1 + 2^10*A2 + 2^18*A3 (A0 is a multiple of 128; mod 2^32)
+    auto recombine = [&](const v16i& A, int k) -> int32_t {
+        return m3_lshl_add(A[4 * k + 3], k18, m3_lshl_add(A[4 * k + 2], k10, m3_lshl_add(A[4 * k + 1], k2, A[4 * k] >> 6)));
+    };
+    auto noise = [&](uint32_t c, uint32_t nl) -> uint32_t {
+        const uint32_t nlo = (uint32_t)j0.n0 + nl;
+        uint32_t z = nlo + rkey[c] + (nlo < rlo0[c] ? rstep[c] : 0u);
+        z ^= z >> 16; z *= 0x7feb352dU;
+        z ^= z >> 15; z *= 0x846ca68bU;
+        z ^= z >> 16;
+        return z;
+    };
+    // the general per-sample requantiser (any tile): x = v * 2^-F LSB, dither in 2^-16 (2^-17) LSB, round half away, clip
+    auto quant_slow = [&](int32_t v, uint32_t c, uint32_t nl) -> int32_t {
+        const int F = m.fbits;
+        const int32_t vh = v >> F;
+        const uint32_t vl = (uint32_t)v & ((1u << F) - 1u);
+        int32_t rr;
+        if constexpr (KIND == 2) {
+            const uint32_t z = noise(c, nl);
+            const int32_t w = (int32_t)(vl << (17 - F)) + (int32_t)(2u * (z >> 16) + 1u) - 65536;
+            const int32_t neg = (vh + (w >> 17)) >> 31;
+            rr = vh + ((w + 65536 + neg) >> 17);
+        } else {
+            int32_t w = (int32_t)(vl << (16 - F));
+            if constexpr (KIND == 1) {
+                const uint32_t z = noise(c, nl);
+                w += (int32_t)((z & 0xFFFFu) + (z >> 16)) - 65535;
+            }
+            const int32_t neg = (vh + (w >> 16)) >> 31;
+            rr = vh + ((w + 32768 + neg) >> 16);
+        }
+        return min(max(rr, m.qmin_i), m.qmax_i);
+    };
+
+    // ---- the fast epilogue of one (tile, channel), cut into jobs that ride on the steps of a chain ----
+    struct Fast {
+        uint32_t zb;            // hash input of the lane's first sample
+        uint32_t T[8];          // per sample: the dither term
+        int32_t res[8];
+        int32_t vprev; uint32_t wprev;
+        int32_t tmn, tmx; uint32_t tie;
+    };
+    auto fast_begin = [&](Fast& f, uint32_t tile, uint32_t c) {
+        const uint32_t first = (uint32_t)j0.n0 + tile * (uint32_t)M2_TILE;
+        const uint32_t key_eff = rkey[c] + (first < rlo0[c] ? rstep[c] : 0u);
+        f.zb = first + key_eff + lane_fr;
+        f.tmn = 0; f.tmx = 0; f.tie = 0xFFFFu;
+    };
+    constexpr int NJ = (KIND == 0 ? 8 : 16);                // jobs per epilogue
+    auto fast_job = [&](Fast& f, const v16i& o0, const v16i& o1, auto jc) {
+        constexpr int j = decltype(jc)::value;
+        constexpr int i = KIND == 0 ? j : j >> 1;           // sample 0..7: group i >> 2, k = i & 3
+        constexpr bool HASH = KIND != 0 && (j & 1) == 0;
+        if constexpr (HASH) {
+            uint32_t z = f.zb + (uint32_t)(8 * (i >> 2) + (i & 3));
+            z ^= z >> 16; z *= kC1;
+            z ^= z >> 15; z *= kC2;
+            z ^= z >> 16;
+            if constexpr (KIND == 1) f.T[i] = __builtin_amdgcn_sad_u16(z, 0u, kTm);      // lo16 + hi16 - 32767, units of 2^-16 LSB
+            else f.T[i] = z >> kShR;                                                       // (2*hi16 + 1) >> (17 - F)
+        } else {
+            const v16i& A = (i >> 2) ? o1 : o0;
+            const int32_t v = recombine(A, i & 3);
+            int32_t s;
+            if constexpr (KIND == 1) {
+                s = v + ((int32_t)f.T[i] >> kSh);
+                const uint32_t w = (uint32_t)m3_lshl_add(v, kSh, (int32_t)f.T[i]);         // low 16 bits zero: an exact tie
+                if constexpr (i & 1) f.tie = m3_min3_u16(f.tie, f.wprev, w); else f.wprev = w;
+            } else if constexpr (KIND == 2) {
+                s = v + (int32_t)f.T[i];
+            } else {
+                s = v + kHalf + (v >> 31);                                                 // round half away from zero
+            }
+            f.res[i] = s >> kF;
+            asm volatile("" : "+v"(f.res[i]));         // keep the whole job on this step (the value is only used after the region)
+            if constexpr (i & 1) { f.tmn = m3_min3(f.tmn, f.vprev, v); f.tmx = m3_max3(f.tmx, f.vprev, v); } else f.vprev = v;
+        }
+    };
+    // the jobs of step u: job j rides on step (j * TP) / NJ
+    auto fast_hook = [&](Fast& f, const v16i& o0, const v16i& o1, auto uc) {
+        constexpr int u = decltype(uc)::value;
+        static_for<0, NJ>([&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+            if constexpr ((j * TP) / NJ == u) fast_job(f, o0, o1, jc);
+        });
+    };
+    // after the region: did the fast form hold for this (tile, channel)?  (uniform)
+    auto fast_failed = [&](const Fast& f, uint32_t tile) -> bool {
+        const uint32_t first = (uint32_t)j0.n0 + tile * (uint32_t)M2_TILE;
+        const bool full = tile * (uint32_t)M2_TILE + (uint32_t)M2_TILE <= j0.nout;
+        if (dbg & 8) return false;                          // (8: never take the slow path, for timing experiments)
+        if (!full || first > 0xFFFFFFFFu - (uint32_t)M2_TILE) return true;
+        const bool bad = (KIND == 1 && (f.tie & 0xFFFFu) == 0) || f.tmx > kSafe || f.tmn < -kSafe;
+        return __builtin_amdgcn_ballot_w64(bad) != 0;
+    };
+    // the careful way: the channel's chain again (its stream bytes are still in `rbc`'s buffer), then sample by sample
+    auto redo = [&](const uint8_t* rbc, uint32_t tile, uint32_t c, int32_t (&out)[8]) {
+        v16i t0, t1;
+        chain(rbc, t0, t1, no_hook);
+        const bool full = tile * (uint32_t)M2_TILE + (uint32_t)M2_TILE <= j0.nout;
+        const uint32_t nl_base = tile * (uint32_t)M2_TILE + lane_fr;
+        uint32_t vmax = 0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const uint32_t nl = nl_base + 8u * (i >> 2) + (i & 3);
+            const int32_t v = recombine((i >> 2) ? t1 : t0, i & 3);
+            out[i] = quant_slow(v, c, nl);
+            const uint32_t va = (uint32_t)(v < 0 ? -v : v);
+            vmax = max(vmax, full || nl < j0.nout ? va : 0u);
+        }
+        pk[c] = fmax(pk[c], ldexp((double)vmax, -m.fbits));   // |x| = |v| * 2^-F exactly
+    };
+    // a tile's frames: channel 0's samples in L[], channel 1's in R[].  A full tile is packed into registers here (per group
+    // the lane owns 4 consecutive frames of both channels = 24 contiguous bytes) and stored by store_packed() AFTER the next
+    // prefetch has been issued, so that nothing waits behind the stores; a partial tile (the file's last) goes out frame by
+    // frame at once.
+    auto tile_full = [&](uint32_t tile) -> bool { return tile * (uint32_t)M2_TILE + (uint32_t)M2_TILE <= j0.nout; };
+    auto pack_tile = [&](uint32_t tile, const int32_t (&L)[8], const int32_t (&R)[8], u32x4 (&p4)[2], u32x2 (&p2)[2]) {
+        if (tile_full(tile)) {
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                // frames k, k+1 -> 12 bytes: [L0 L1 L2 R0 | R1 R2 L0' L1' | L2' R0' R1' R2']
+                const uint32_t La = L[4 * g], Ra = R[4 * g], Lb = L[4 * g + 1], Rb = R[4 * g + 1];
+                const uint32_t Lc = L[4 * g + 2], Rc = R[4 * g + 2], Ld = L[4 * g + 3], Rd = R[4 * g + 3];
+                p4[g] = u32x4{__builtin_amdgcn_perm(Ra, La, 0x04020100u), __builtin_amdgcn_perm(Lb, Ra, 0x05040201u),
+                              __builtin_amdgcn_perm(Rb, Lb, 0x06050402u), __builtin_amdgcn_perm(Rc, Lc, 0x04020100u)};
+                p2[g] = u32x2{__builtin_amdgcn_perm(Ld, Rc, 0x05040201u), __builtin_amdgcn_perm(Rd, Ld, 0x06050402u)};
+            }
+        } else {
+            uint8_t* gout = reinterpret_cast<uint8_t*>(j0.out) + (size_t)tile * (M2_TILE * 6) + 96u * r + 24u * h;
+            const uint32_t nl_base = tile * (uint32_t)M2_TILE + lane_fr;
+#pragma unroll 1
+            for (int i = 0; i < 8; ++i) {
+                const uint32_t g = (uint32_t)i >> 2, k = (uint32_t)i & 3u;
+                if (nl_base + 8u * g + k < j0.nout) {
+                    uint32_t Lv = 0, Rv = 0;
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) { Lv = i == q ? (uint32_t)L[q] : Lv; Rv = i == q ? (uint32_t)R[q] : Rv; }
+                    D2D_GLOBAL uint16_t* p16 = reinterpret_cast<D2D_GLOBAL uint16_t*>(as_global(gout + 48u * g + 6u * k));
+                    p16[0] = (uint16_t)Lv; p16[1] = (uint16_t)(((Lv >> 16) & 0xFFu) | (Rv << 8)); p16[2] = (uint16_t)(Rv >> 8);
+                }
+            }
+        }
+    };
+    auto store_packed = [&](uint32_t tile, const u32x4 (&p4)[2], const u32x2 (&p2)[2]) {
+        if (!tile_full(tile)) return;
+        uint8_t* gout = reinterpret_cast<uint8_t*>(j0.out) + (size_t)tile * (M2_TILE * 6) + 96u * r + 24u * h;
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            if (dbg & 64) { asm volatile("" :: "v"(p4[g]), "v"(p2[g])); continue; }
+            *reinterpret_cast<D2D_GLOBAL u32x4*>(as_global(gout + 48 * g)) = p4[g];
+            *reinterpret_cast<D2D_GLOBAL u32x2*>(as_global(gout + 48 * g + 16)) = p2[g];
+        }
+    };
+    auto merge_extremes = [&](const Fast& f, uint32_t c) { vmn[c] = min(vmn[c], f.tmn); vmx[c] = max(vmx[c], f.tmx); };
+
+    uint32_t wt = blockIdx.x * m.nwaves + wave;
+#if D2D_M3_STAMPS
+    const unsigned long long t_start = __builtin_amdgcn_s_memtime(), rt_start = __builtin_amdgcn_s_memrealtime();
+    unsigned long long st_sum[3] = {0, 0, 0}, st_last = t_start;
+    auto stamp = [&](int slot) { const unsigned long long t = __builtin_amdgcn_s_memtime(); st_sum[slot] += t - st_last; st_last = t; };
+#else
+    auto stamp = [](int) {};
+#endif
+    using C0 = std::integral_constant<int, 0>;
+    using C1 = std::integral_constant<int, 1>;
+    if (wt < nwt) issue_loads(wt, C0{});
+    v16i accA[2], accB[2];                                  // channel 0's / channel 1's accumulators
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { accB[0][i] = 0; accB[1][i] = 0; }
+    int32_t held[8];                                        // channel 0's samples of the tile in flight
+    bool have_prev = false;
+    uint32_t pw = 0;                                        // the tile whose channel 1 still waits for its epilogue
+    for (; wt < nwt; wt += wstride) {
+        // ---- region A: channel 0's chain of tile wt, channel 1's epilogue of tile pw ----
+        stamp(2);
+        wave_sync2();
+        if (!(dbg & 4)) {
+            write_lds(C0{});
+            issue_loads(wt, C1{});
+        }
+        wave_sync2();
+        stamp(0);
+        u32x4 p4[2]; u32x2 p2[2];
+        {
+            Fast f;
+            fast_begin(f, pw, 1);
+            if (dbg & 2) chain(rb0, accA[0], accA[1], no_hook);
+            else if (dbg & 1) { static_for<0, NJ>([&](auto jc) { fast_job(f, accB[0], accB[1], jc); }); accA[0] = cinit + (int)lane; accA[1] = cinit - (int)lane; }
+            else chain(rb0, accA[0], accA[1], [&](auto uc) { fast_hook(f, accB[0], accB[1], uc); });
+            if (D2D_M3_STAMPS) asm volatile("" :: "v"(accA[0]), "v"(accA[1]));
+            stamp(1);
+            if (have_prev) {
+                if (!(dbg & 3) && fast_failed(f, pw)) redo(rb1, pw, 1, f.res); else merge_extremes(f, 1);
+                pack_tile(pw, held, f.res, p4, p2);
+            }
+        }
+        // ---- region B: channel 1's chain of tile wt, channel 0's epilogue of tile wt ----
+        stamp(2);
+        wave_sync2();
+        if (!(dbg & 4)) {
+            write_lds(C1{});
+            if (wt + wstride < nwt) issue_loads(wt + wstride, C0{});
+        }
+        if (have_prev) store_packed(pw, p4, p2);
+        wave_sync2();
+        stamp(0);
+        {
+            Fast f;
+            fast_begin(f, wt, 0);
+            if (dbg & 2) chain(rb1, accB[0], accB[1], no_hook);
+            else if (dbg & 1) { static_for<0, NJ>([&](auto jc) { fast_job(f, accA[0], accA[1], jc); }); accB[0] = cinit - (int)lane; accB[1] = cinit + (int)lane; }
+            else chain(rb1, accB[0], accB[1], [&](auto uc) { fast_hook(f, accA[0], accA[1], uc); });
+            if (D2D_M3_STAMPS) asm volatile("" :: "v"(accB[0]), "v"(accB[1]));
+            stamp(1);
+            if (!(dbg & 3) && fast_failed(f, wt)) redo(rb0, wt, 0, f.res); else merge_extremes(f, 0);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) held[i] = f.res[i];
+        }
+        have_prev = true; pw = wt;
+    }
+    if (have_prev) {
+        // drain: channel 1 of the wave's last tile
+        Fast f;
+        fast_begin(f, pw, 1);
+        static_for<0, NJ>([&](auto jc) { fast_job(f, accB[0], accB[1], jc); });
+        if (fast_failed(f, pw)) redo(rb1, pw, 1, f.res); else merge_extremes(f, 1);
+        u32x4 p4[2]; u32x2 p2[2];
+        pack_tile(pw, held, f.res, p4, p2);
+        store_packed(pw, p4, p2);
+    }
+
+#if D2D_M3_STAMPS
+    if (lane == 0) {
+        const unsigned long long dt = __builtin_amdgcn_s_memtime() - t_start;
+        atomicMin(&d2d_m3_stamps[0], dt); atomicMax(&d2d_m3_stamps[1], dt); atomicAdd(&d2d_m3_stamps[2], dt); atomicAdd(&d2d_m3_stamps[3], 1ull);
+        for (int i = 0; i < 3; ++i) atomicAdd(&d2d_m3_stamps[4 + i], st_sum[i]);
+        atomicAdd(&d2d_m3_stamps[7], __builtin_amdgcn_s_memrealtime() - rt_start);      // constant 100 MHz: sum[2] / sum[7] = core clock / 100 MHz
+    }
+#endif
+    // peak meter: |x| in LSB; undo the power-of-two part exactly
+    const double unscale = 1.0 / (double)(1u << (a.epi.bits - 1));
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        const int32_t dev = max(vmx[c], -vmn[c]);
+        double p = fmax(pk[c], ldexp((double)dev, -m.fbits)) * unscale;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) p = fmax(p, __shfl_xor(p, o));
+        if (lane == 0 && p > 0.0)
+            atomicMax(reinterpret_cast<unsigned long long*>(jobs[c].peak), (unsigned long long)__double_as_longlong(p));
+    }
+}
+
+// ---- host side -------------------------------------------------------------------------------
+
+#ifdef D2D_M2_DEV
+#define D2D_M3_SHAPES(X) X(4, 13)
+#else
+#define D2D_M3_SHAPES(X) X(4, 10) X(4, 12) X(4, 13) X(8, 19) X(8, 24) X(8, 25)
+#endif
+
+bool mfma3_supported(int MB, int NPG) {
+#define X(mb, npg) if (MB == mb && NPG == npg) return true;
+    D2D_M3_SHAPES(X)
+#undef X
+    return false;
+}
+
+template <int MB, int NPG, int KIND>
+static hipError_t launch_mfma3_t(Mfma2Args& m, uint32_t nwt_max, uint32_t nrows, hipStream_t s) {
+    static KernelPrep prep;
+    int dev = 0;
+    const void* fn = reinterpret_cast<const void*>(&d2d_fir_mfma3_kernel<MB, NPG, KIND>);
+    hipError_t e = prep.max_dynamic_lds(fn, 160 * 1024, &dev);
+    if (e != hipSuccess) return e;
+    // LDS: the shared tap table, then two stream buffers per wave; eight waves per block = two per SIMD
+    m.off_waves = (uint32_t)(2 * NPG) * 1024u;
+    m.wave_lds = 2u * (uint32_t)m2_stream_bytes(MB, NPG);
+    m.off_out = m.wave_lds;
+    static const char* wenv = getenv("D2D_MFMA_WAVES");   // diagnostic override
+    m.nwaves = wenv ? (uint32_t)atoi(wenv) : 8u;
+    if (m.nwaves < 1 || m.nwaves > 8) m.nwaves = 8;
+    while (m.nwaves > 1 && (size_t)m.off_waves + (size_t)m.nwaves * m.wave_lds > 160 * 1024) m.nwaves >>= 1;
+    const size_t smem = (size_t)m.off_waves + (size_t)m.nwaves * m.wave_lds;
+    if (smem > 160 * 1024) return hipErrorInvalidValue;
+    int blocks_per_cu, ncu;
+    {
+        std::lock_guard<std::mutex> g(prep.mu);
+        if (prep.blocks_per_cu[dev] == 0 || smem != prep.smem_seen[dev] || m.nwaves != prep.nwaves_seen[dev]) {
+            hipDeviceProp_t prop;
+            if ((e = hipGetDeviceProperties(&prop, dev)) != hipSuccess) return e;
+            int nb = 0;
+            e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, d2d_fir_mfma3_kernel<MB, NPG, KIND>, (int)(64 * m.nwaves), smem);
+            if (e != hipSuccess) return e;
+            prep.ncu[dev] = prop.multiProcessorCount;
+            prep.blocks_per_cu[dev] = nb < 1 ? 1 : nb;
+            prep.smem_seen[dev] = smem; prep.nwaves_seen[dev] = m.nwaves;
+        }
+        blocks_per_cu = prep.blocks_per_cu[dev]; ncu = prep.ncu[dev];
+    }
+    // every wave loops over its share of the wave-tiles: launch what is resident at once
+    uint32_t gx = (uint32_t)(ncu * blocks_per_cu) / nrows;
+    if (gx < 1) gx = 1;
+    const uint32_t need = (nwt_max + m.nwaves - 1) / m.nwaves;
+    if (gx > need) gx = need;
+    hipLaunchKernelGGL((d2d_fir_mfma3_kernel<MB, NPG, KIND>), dim3(gx, nrows), dim3(64 * m.nwaves), smem, s, m);
+    return hipGetLastError();
+}
+
+hipError_t launch_fir_mfma3(Mfma2Args& m, int MB, int NPG, uint32_t nwt_max, uint32_t nrows, hipStream_t s) {
+#define X(mb, npg)                                                                        \
+    if (MB == mb && NPG == npg) {                                                         \
+        if (m.dkind == 1) return launch_mfma3_t<mb, npg, 1>(m, nwt_max, nrows, s);         \
+        if (m.dkind == 2) return launch_mfma3_t<mb, npg, 2>(m, nwt_max, nrows, s);         \
+        return launch_mfma3_t<mb, npg, 0>(m, nwt_max, nrows, s);                           \
+    }
+    D2D_M3_SHAPES(X)
+#undef X
+    return hipErrorInvalidValue;
+}
+
+#if D2D_M3_STAMPS
+void mfma3_debug_stamps(unsigned long long out[8]) {
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(d2d_m3_stamps), sizeof(unsigned long long) * 8);
+    unsigned long long z[8] = {~0ull, 0, 0, 0, 0, 0, 0, 0};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(d2d_m3_stamps), z, sizeof(z));
+}
+#else
+void mfma3_debug_stamps(unsigned long long out[8]) { for (int i = 0; i < 8; ++i) out[i] = 0; }
+#endif
+
+}  // namespace d2d

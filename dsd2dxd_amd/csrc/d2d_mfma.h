@@ -30,8 +30,13 @@ void mfma_debug_stamps(unsigned long long out[8]);   // diagnostic (D2D_DBG=16)
 int mfma2_pairs(int M, int N);
 bool mfma2_supported(int M, int N);
 size_t mfma2_smem_bytes(int M, int N, uint32_t channels, uint32_t sample_bytes, uint32_t* waves_per_block);
-std::vector<int8_t> build_mfma2_tables(const d2d_filter_def& f, bool msb_first);
+// `unmask0`: plane 0 of a stream dword reaches the matrix cores unmasked where the limb sums allow it (the two-group kernel);
+// false: every plane masked (the pipelined kernel)
+std::vector<int8_t> build_mfma2_tables(const d2d_filter_def& f, bool msb_first, bool unmask0);
+// does this launch shape go to the software-pipelined kernel (d2d_kernels_mfma3.hip)?  Fixed per engine: decides the table variant.
+bool mfma2_pipelined(const FirArgs& a, int M, int N);
 void mfma2_debug_stamps(unsigned long long out[8]);   // diagnostic (make DIAG=1, D2D_DBG & 256)
 hipError_t launch_fir_mfma2(const FirArgs& a, int M, int N, uint32_t max_nout, uint32_t nstreams, hipStream_t s);
+void mfma3_debug_stamps(unsigned long long out[8]);  // diagnostic (make DIAG=1, D2D_DBG & 256): per-wave lifetimes of the pipelined kernel
 
 }  // namespace d2d
