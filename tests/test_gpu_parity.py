@@ -219,3 +219,36 @@ def test_noise_shaped_segments_restart_and_carry(engine_lib, oracle_mod, kernel)
     assert np.array_equal(g, r)
     one, r1, _, _ = run_pair(engine_lib, oracle_mod, [pack_layout(chans, "I", 1)], kw, kernel)
     assert np.array_equal(one, g)                          # one call (nine segments side by side) == nine calls
+
+
+@pytest.mark.parametrize("dither", ["T", "R", "X"])
+@pytest.mark.parametrize("dsd_rate,out_rate,filt", [(1, 88200, "E"), (1, 88200, "X"), (2, 88200, "E"), (2, 176400, "C"), (4, 176400, "E")])
+def test_pipelined_stereo_kernel_fast_and_careful_tiles(engine_lib, oracle_mod, dsd_rate, out_rate, filt, dither):
+    """Stereo 24-bit at 0 dB runs d2d_fir_mfma3_kernel: the requantiser rides on the next chain in its branch-free form and a
+    tile that could clip, holds an exact rounding tie or is cut short by the end of the call is redone sample by sample.
+    Full-scale stretches (all-ones / all-zeros bytes clip at both rails), quiet stretches, ragged call sizes and a short last
+    call exercise those paths (an exact tie under triangular dither is a 2^-16 event per sample: likely here, certain in
+    tests/test_gpu_fullsize.py)."""
+    rng = np.random.default_rng(5)
+    nbytes = 4096 * 40 * dsd_rate
+    chans = []
+    for c in range(2):
+        x = synth("sine", nbytes, seed=20 + c, dsd_rate=dsd_rate).copy()
+        for _ in range(6):                                   # full-scale stretches: +1.0 and -1.0 for a few thousand bits
+            a = int(rng.integers(0, nbytes - 3000))
+            x[a:a + int(rng.integers(200, 3000))] = 0xFF if rng.integers(0, 2) else 0x00
+        a = int(rng.integers(0, nbytes - 9000))
+        x[a:a + 8192] = 0x69                                 # an idle-like pattern: output near zero
+        chans.append(x)
+    kw = dict(dsd_rate=dsd_rate, output_rate=out_rate, channels=2, fmt="P", endianness="L", block_size=4096,
+              filter=filt, bit_depth=24, dither=dither, seed=99)
+    cuts = [0, 4096 * 7, 4096 * 7 + 4096 * 20, nbytes - 4096, nbytes]
+    bufs = [pack_layout([ch[a:b] for ch in chans], "P", 4096) for a, b in zip(cuts[:-1], cuts[1:])]
+    g, r, e, o = run_pair(engine_lib, oracle_mod, bufs, kw, 2)
+    assert e.kernel_name().startswith("d2d_fir_mfma3_kernel")
+    assert g.size == r.size and g.size > 0
+    assert np.array_equal(g, r)
+    pcm = decode_pcm(g, 24, 2)
+    assert pcm.max() == (1 << 23) - 1 and pcm.min() == -(1 << 23)          # both rails were reached
+    for c in range(2):
+        assert e.peak(c) == o.peak(c)
