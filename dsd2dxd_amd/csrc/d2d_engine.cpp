@@ -50,7 +50,7 @@ struct d2d_engine {
     LutLayout lut{};
     MfmaLayout mfma{};
     bool mfma_v2 = false;      // the two-group matrix-core kernel (d2d_kernels_mfma2.hip) serves this shape
-    bool mfma_pipe = false;    // ... through its software-pipelined variant (d2d_kernels_mfma3.hip): stereo 24-bit at 0 dB; its tap table masks every plane
+    int mfma_pipe = 0;         // ... through its software-pipelined variant (d2d_kernels_mfma3.hip; stereo 24-bit at 0 dB): 3 dense chain, 4 sparse chain
     std::string kname;
     Epilogue epi{};
     std::string err;
@@ -185,7 +185,7 @@ static void fir_args_static(const d2d_engine* e, FirArgs& a) {
     for (int j = 0; j < e->N; ++j) { const int64_t q = tap_q(*e->fc.fir, j); sa += (uint64_t)(q < 0 ? -q : q); }
     a.sum_abs_q = sa;
     a.epi = e->epi;
-    a.pipelined = e->mfma_pipe ? 1u : 0u;
+    a.pipelined = (uint32_t)e->mfma_pipe;
 }
 
 extern "C" {
@@ -276,7 +276,8 @@ int d2d_create(const d2d_params* params, uint32_t n_files, d2d_engine** out) {
         CK(hipMemcpy(e->d_fir_tables, t.data(), e->fir_table_bytes, hipMemcpyHostToDevice));
     } else {
         if (e->mfma_v2) { FirArgs a{}; fir_args_static(e, a); e->mfma_pipe = mfma2_pipelined(a, e->M, e->N); }
-        std::vector<int8_t> t = e->mfma_v2 ? build_mfma2_tables(f, msb, !e->mfma_pipe) : build_mfma_tables(f, e->mfma, msb);
+        std::vector<int8_t> t = e->mfma_pipe == 4 ? build_mfma4_tables(f, msb)
+                              : e->mfma_v2 ? build_mfma2_tables(f, msb, !e->mfma_pipe) : build_mfma_tables(f, e->mfma, msb);
         e->fir_table_bytes = t.size();
         CK(hipMalloc(&e->d_fir_tables, e->fir_table_bytes));
         CK(hipMemcpy(e->d_fir_tables, t.data(), e->fir_table_bytes, hipMemcpyHostToDevice));
@@ -815,7 +816,8 @@ const char* d2d_kernel_name(const d2d_engine* e) {
         d2d_engine* m = const_cast<d2d_engine*>(e);
         if (e->mfma_pipe) {
             const int kind = e->epi.dither == 'T' ? 1 : e->epi.dither == 'R' ? 2 : 0;
-            m->kname = "d2d_fir_mfma3_kernel<" + std::to_string(e->Mb) + ", " + std::to_string(mfma2_pairs(e->M, e->N)) + ", " + std::to_string(kind) + ">";
+            m->kname = "d2d_fir_mfma3_kernel<" + std::to_string(e->Mb) + ", " + std::to_string(mfma2_pairs(e->M, e->N)) + ", " +
+                       std::to_string(e->mfma_pipe == 4 ? e->N : 0) + ", " + std::to_string(kind) + ">";
             return m->kname.c_str();
         }
         m->kname = "d2d_fir_mfma2_kernel<" + std::to_string(e->Mb) + ", " + std::to_string(mfma2_pairs(e->M, e->N)) + ", " +

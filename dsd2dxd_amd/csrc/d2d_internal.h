@@ -60,7 +60,7 @@ struct FirArgs {
     int32_t  scale_bits;       // S of the tap table (h = q * 2^-S)
     uint32_t in_channels;      // channels of the input layout (epi.channels = channels of the output frame; fewer for a channel subset)
     uint64_t sum_abs_q;        // sum |q_j| of the tap table (bounds |y*2^S|)
-    uint32_t pipelined;        // two-group MFMA kernels: 1 = the engine built the all-planes-masked table of the pipelined kernel and expects it to run
+    uint32_t pipelined;        // two-group MFMA kernels: 0, or the variant of the pipelined kernel whose tap table the engine built (3 dense, 4 sparse)
     Epilogue epi;
 };
 

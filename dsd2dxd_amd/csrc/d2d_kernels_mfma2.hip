@@ -696,20 +696,25 @@ static int mfma2_epilogue(const FirArgs& a, const Mfma2Args& m) {
 
 // the pipelined kernel serves the register-packed stereo flavour with the all-integer requantiser; its accumulators start
 // from -2^(S-18) in the limb-3 rows
-static bool mfma3_eligible(const FirArgs& a, const Mfma2Args& m, int MB, int NPG) {
-    return mfma2_epilogue(a, m) == 1 && m.intq && a.scale_bits >= 18 && a.scale_bits <= 30 && mfma3_supported(MB, NPG);
+static bool mfma3_eligible(const FirArgs& a, const Mfma2Args& m, int MB, int NPG, int NT) {
+    return mfma2_epilogue(a, m) == 1 && m.intq && a.scale_bits >= 18 && a.scale_bits <= 30 && mfma3_supported(MB, NPG, NT);
 }
 
 static void mfma2_geometry(const FirArgs& a, int MB, int NPG, Mfma2Args& m, size_t& smem);
 
-bool mfma2_pipelined(const FirArgs& a, int M, int N) {
-    static const char* nopipe = getenv("D2D_NO_PIPE");
-    if (nopipe && atoi(nopipe)) return false;
+int mfma2_pipelined(const FirArgs& a, int M, int N) {
+    // (read at every engine creation, not cached: the tests switch variants inside one process)
+    const char* nopipe = getenv("D2D_NO_PIPE");
+    const char* sparse = getenv("D2D_SPARSE");
+    if (nopipe && atoi(nopipe)) return 0;
     const int MB = M / 8, NPG = mfma2_pairs(M, N);
-    if (!mfma2_supported(M, N)) return false;
+    if (!mfma2_supported(M, N)) return 0;
     Mfma2Args m{}; size_t smem = 0;
     mfma2_geometry(a, MB, NPG, m, smem);
-    return mfma3_eligible(a, m, MB, NPG);
+    if (!mfma3_eligible(a, m, MB, NPG, N)) return 0;
+    // the structured-sparse chain issues 27 % fewer MFMAs but 8 % more vector instructions, and the kernel is bound by vector issue:
+    // measured 4-7 % slower than the dense chain; kept selectable (D2D_SPARSE=1), exact and tested
+    return sparse && atoi(sparse) ? 4 : 3;
 }
 
 static void mfma2_geometry(const FirArgs& a, int MB, int NPG, Mfma2Args& m, size_t& smem) {
@@ -807,7 +812,7 @@ hipError_t launch_fir_mfma2(const FirArgs& a, int M, int N, uint32_t max_nout, u
     const int epi = mfma2_epilogue(a, m);
     // stereo 24-bit at 0 dB: the software-pipelined kernel (d2d_kernels_mfma3.hip), same results; the engine chose it (and its
     // table variant) when it was created
-    if (a.pipelined) return launch_fir_mfma3(m, MB, NPG, nwt, nrows, s);
+    if (a.pipelined) return launch_fir_mfma3(m, (int)a.pipelined, MB, NPG, N, nwt, nrows, s);
 #define X(mb, npg)                                                                                  \
     if (MB == mb && NPG == npg) {                                                                   \
         if (C == 1) return epi == 2 ? launch_mfma2_t<mb, npg, 1, 2>(m, smem, nwt, nrows, s) : launch_mfma2_t<mb, npg, 1, 0>(m, smem, nwt, nrows, s); \

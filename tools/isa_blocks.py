@@ -6,7 +6,7 @@ lines = open(path).read().split("\n")
 start = next(i for i, l in enumerate(lines) if l.startswith("_Z") and key in l and l.rstrip().endswith(":") or (l.startswith("_Z") and key in l and ": " in l and "; @" in l))
 blocks, cur = [], ["entry", {}]
 def cls(op):
-    if op.startswith("v_mfma"): return "mfma"
+    if op.startswith("v_mfma") or op.startswith("v_smfmac"): return "mfma"
     if op.startswith("v_readlane") or op.startswith("v_writelane") or op.startswith("v_readfirstlane"): return "lane"
     if op.startswith("v_"): return "valu"
     if op.startswith("ds_"): return "lds"

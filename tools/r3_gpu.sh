@@ -1,5 +1,5 @@
 #!/bin/bash
-# pipelined kernel: parity tests, then A/B bench against the two-group kernel (D2D_NO_PIPE=1)
+# pipelined kernel: parity tests, then A/B bench: sparse chain (default), dense chain (D2D_NO_SPARSE=1), two-group kernel (D2D_NO_PIPE=1)
 TAG=${1:-r3a}; TESTS=${2:-"tests/test_gpu_parity.py tests/test_gpu_api.py"}
 mkdir -p gpurun_out/$TAG
 timeout -k 10 900 python -m pytest $TESTS -m gpu -x -q > gpurun_out/$TAG/pytest.log 2>&1
@@ -10,4 +10,4 @@ import json; j=json.load(open("gpurun_out/$TAG/$name.json")); r=j["roofline"]
 print("%-14s" % "$name", r.get("kernel"), "kernel_ms", r.get("kernel_ms", r.get("fir_kernel_ms")), "frac", r["frac"], "ms_per_step", j["ms_per_step"], "value", j["value"])
 PY
 }
-run pipe A=1; run nopipe D2D_NO_PIPE=1; run pipe2 A=1
+run sparse A=1; run dense D2D_NO_SPARSE=1; run nopipe D2D_NO_PIPE=1; run sparse2 A=1
