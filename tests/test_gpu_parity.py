@@ -164,6 +164,42 @@ def test_batch_of_files_matches_per_file(engine_lib, oracle_mod, kernel):
         assert e.peak(0, file=f) == o.peak(0) and e.peak(1, file=f) == o.peak(1)
 
 
+@pytest.mark.parametrize("out_rate,dither,bits", [(88200, "T", 24), (96000, "R", 16), (88200, "N", 24)])
+def test_batch_of_interleaved_files(engine_lib, oracle_mod, out_rate, dither, bits):
+    """A batch of byte-interleaved files (the DFF layout) of different lengths through the planar-copy pre-pass, two calls in a row
+    (the second reuses the planar copy), 44.1k and 48k family, noise-shaped included."""
+    import torch
+    n_files, chans = 7, 3
+    lens = [4096 * 6 + 64 * f for f in range(n_files)]
+    kw = dict(dsd_rate=1, output_rate=out_rate, channels=chans, fmt="I", endianness="M", block_size=4096,
+              filter="E", bit_depth=bits, dither=dither, seed=31)
+    e = engine_lib.Engine(n_files=n_files, kernel=2, **kw)
+    streams = [[synth("sine" if c != 1 else "pink", lens[f], seed=40 + 7 * f + c, amp=0.3 if c != 1 else 0.098, msb_first=True) for c in range(chans)]
+               for f in range(n_files)]
+    oracles = [oracle_mod.Oracle(**kw) for _ in range(n_files)]
+    for part in range(2):
+        cut = [(0, 4096 * 3 + 128), (4096 * 3 + 128, None)][part]
+        bufs = [pack_layout([ch[cut[0]:cut[1]] for ch in streams[f]], "I", 1) for f in range(n_files)]
+        d_in = [torch.from_numpy(b).cuda() for b in bufs]
+        ios = (engine_lib.FileIO * n_files)()
+        d_out = []
+        for f in range(n_files):
+            bpc = len(bufs[f]) // chans
+            nfr = e.next_frames(bpc, file=f)
+            d_out.append(torch.zeros(max(nfr * e.frame_bytes, 16), dtype=torch.uint8, device="cuda"))
+            ios[f].dsd = d_in[f].data_ptr(); ios[f].bytes_per_channel = bpc
+            ios[f].pcm = d_out[f].data_ptr(); ios[f].pcm_capacity_bytes = d_out[f].numel()
+        e.translate_batch_device(ios, torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        for f in range(n_files):
+            r, rf = oracles[f].translate(bufs[f])
+            assert ios[f].frames_out == rf
+            assert np.array_equal(d_out[f].cpu().numpy()[:rf * e.frame_bytes], r[:rf * e.frame_bytes])
+    for f in range(n_files):
+        for c in range(chans):
+            assert e.peak(c, file=f) == oracles[f].peak(c)
+
+
 @pytest.mark.parametrize("kernel", KERNELS)
 def test_known_answers_on_device(engine_lib, kernel):
     """All-ones DSD -> +full scale (taps sum to exactly 1), all-zeros -> -full scale; first frames carry
