@@ -7,7 +7,7 @@ NAME=$1; shift
 ROOT=$(cd "$(dirname "$0")/.." && pwd); CS=$ROOT/dsd2dxd_amd/csrc
 mkdir -p $ROOT/ab/$NAME
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wall -Wno-unused-function -Wno-unused-value -Wno-unused-result \
-    -I$CS -I$ROOT/filters -DD2D_M2_DEV "$@" -c $CS/d2d_kernels_mfma3.hip -o $ROOT/ab/$NAME/d2d_kernels_mfma3.o
+    -I$CS -I$ROOT/filters "$@" -c $CS/d2d_kernels_mfma3.hip -o $ROOT/ab/$NAME/d2d_kernels_mfma3.o
 M2O=$CS/d2d_kernels_mfma2.o
 if [ -n "$AB_M2" ]; then    # AB_M2=1: the two-group kernel's file too (it builds the tap tables both kernels read)
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wall -Wno-unused-function -Wno-unused-value -Wno-unused-result \
