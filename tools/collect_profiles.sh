@@ -3,7 +3,7 @@
 set -e
 R=r02
 cp gpurun_out/prof_r02_console.txt profiles/${R}_summary.txt
-cp $(ls gpurun_out/prof_r02/trace/*/*_kernel_stats.csv | head -1) profiles/${R}_kernel_stats.csv
+cp $(ls -t gpurun_out/prof_r02/trace/*/*_kernel_stats.csv | head -1) profiles/${R}_kernel_stats.csv
 cp gpurun_out/prof_r02/bench_trace.json profiles/${R}_bench_under_rocprof_trace.json
 cp gpurun_out/r02_bench_default.json profiles/${R}_bench_default.json
 cat gpurun_out/r02_workloads/*.json > profiles/${R}_bench_other_workloads.json
