@@ -697,7 +697,9 @@ static int mfma2_epilogue(const FirArgs& a, const Mfma2Args& m) {
 // the pipelined kernel serves the register-packed stereo flavour with the all-integer requantiser; its accumulators start
 // from -2^(S-18) in the limb-3 rows
 static bool mfma3_eligible(const FirArgs& a, const Mfma2Args& m, int MB, int NPG, int NT) {
-    return mfma2_epilogue(a, m) == 1 && m.intq && a.scale_bits >= 18 && a.scale_bits <= 30 && mfma3_supported(MB, NPG, NT);
+    // stereo, 24-bit packed or 16-bit frames, the all-integer requantiser (unit gain)
+    const bool frames_ok = !a.to_scratch && a.epi.channels == 2 && (a.epi.sample_bytes == 3 || a.epi.sample_bytes == 2) && m.qsh == 0 && !m.wide;
+    return frames_ok && m.intq && a.scale_bits >= 18 && a.scale_bits <= 30 && mfma3_supported(MB, NPG, NT);
 }
 
 static void mfma2_geometry(const FirArgs& a, int MB, int NPG, Mfma2Args& m, size_t& smem);
@@ -714,7 +716,7 @@ int mfma2_pipelined(const FirArgs& a, int M, int N) {
     if (!mfma3_eligible(a, m, MB, NPG, N)) return 0;
     // the structured-sparse chain issues 27 % fewer MFMAs but 8 % more vector instructions, and the kernel is bound by vector issue:
     // measured 4-7 % slower than the dense chain; kept selectable (D2D_SPARSE=1), exact and tested
-    return sparse && atoi(sparse) ? 4 : 3;
+    return sparse && atoi(sparse) && a.epi.sample_bytes == 3 && mfma3_sparse_compiled(MB, N) ? 4 : 3;
 }
 
 static void mfma2_geometry(const FirArgs& a, int MB, int NPG, Mfma2Args& m, size_t& smem) {

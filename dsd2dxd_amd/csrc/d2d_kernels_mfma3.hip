@@ -87,13 +87,14 @@ __host__ __device__ constexpr int m4_stream_bytes(int MB, int NT) {
 }
 constexpr int M4_FRAG_BYTES = 1280;          // a tap fragment: 64 lanes x 16 compressed int8, then 64 index words
 
-// KIND: 0 no dither, 1 triangular, 2 rectangular.  Stereo, 24-bit packed frames, unit gain.
+// KIND: 0 no dither, 1 triangular, 2 rectangular.  Stereo, unit gain; SBY = bytes per sample: 3 (24-bit packed frames) or 2 (16-bit).
 // NT = 0: the dense chain (tables of build_mfma2_tables); NT = taps: the structured-sparse chain (build_mfma4_tables).
-template <int MB, int NPG, int NT, int KIND>
+template <int MB, int NPG, int NT, int KIND, int SBY>
 __global__ __launch_bounds__(D2D_M3_THREADS) void d2d_fir_mfma3_kernel(Mfma2Args m) {
     using G = M2Geom<MB>;
     constexpr int RS = G::RS, LSH = G::LSH;
     constexpr bool SP = NT > 0;
+    constexpr uint32_t FB = 2u * SBY;                               // bytes per stereo frame
     constexpr int TP = SP ? m4_nst(MB, NT) : NPG + MB;              // steps of one chain
     constexpr int NCHK = SP ? m4_chunks(MB, NT) : m2_chunks(MB, NPG);
     constexpr int PF = SP ? m4_pf(MB, NT) : m2_pf(MB, NPG);
@@ -429,15 +430,22 @@ __global__ __launch_bounds__(D2D_M3_THREADS) void d2d_fir_mfma3_kernel(Mfma2Args
         if (tile_full(tile)) {
 #pragma unroll
             for (int g = 0; g < 2; ++g) {
-                // frames k, k+1 -> 12 bytes: [L0 L1 L2 R0 | R1 R2 L0' L1' | L2' R0' R1' R2']
                 const uint32_t La = L[4 * g], Ra = R[4 * g], Lb = L[4 * g + 1], Rb = R[4 * g + 1];
                 const uint32_t Lc = L[4 * g + 2], Rc = R[4 * g + 2], Ld = L[4 * g + 3], Rd = R[4 * g + 3];
-                p4[g] = u32x4{__builtin_amdgcn_perm(Ra, La, 0x04020100u), __builtin_amdgcn_perm(Lb, Ra, 0x05040201u),
-                              __builtin_amdgcn_perm(Rb, Lb, 0x06050402u), __builtin_amdgcn_perm(Rc, Lc, 0x04020100u)};
-                p2[g] = u32x2{__builtin_amdgcn_perm(Ld, Rc, 0x05040201u), __builtin_amdgcn_perm(Rd, Ld, 0x06050402u)};
+                if constexpr (SBY == 3) {
+                    // frames k, k+1 -> 12 bytes: [L0 L1 L2 R0 | R1 R2 L0' L1' | L2' R0' R1' R2']
+                    p4[g] = u32x4{__builtin_amdgcn_perm(Ra, La, 0x04020100u), __builtin_amdgcn_perm(Lb, Ra, 0x05040201u),
+                                  __builtin_amdgcn_perm(Rb, Lb, 0x06050402u), __builtin_amdgcn_perm(Rc, Lc, 0x04020100u)};
+                    p2[g] = u32x2{__builtin_amdgcn_perm(Ld, Rc, 0x05040201u), __builtin_amdgcn_perm(Rd, Ld, 0x06050402u)};
+                } else {
+                    // 16-bit: one dword per frame [L0 L1 R0 R1]
+                    p4[g] = u32x4{__builtin_amdgcn_perm(Ra, La, 0x05040100u), __builtin_amdgcn_perm(Rb, Lb, 0x05040100u),
+                                  __builtin_amdgcn_perm(Rc, Lc, 0x05040100u), __builtin_amdgcn_perm(Rd, Ld, 0x05040100u)};
+                }
             }
         } else {
-            uint8_t* gout = reinterpret_cast<uint8_t*>(j0.out) + (size_t)tile * (M2_TILE * 6) + 96u * r + 24u * h;
+            // the file's last, partial tile: frame by frame (24-bit: three 2-byte stores each)
+            uint8_t* gout = reinterpret_cast<uint8_t*>(j0.out) + (size_t)tile * (M2_TILE * FB) + FB * lane_fr;
             const uint32_t nl_base = tile * (uint32_t)M2_TILE + lane_fr;
 #pragma unroll 1
             for (int i = 0; i < 8; ++i) {
@@ -446,20 +454,21 @@ __global__ __launch_bounds__(D2D_M3_THREADS) void d2d_fir_mfma3_kernel(Mfma2Args
                     uint32_t Lv = 0, Rv = 0;
 #pragma unroll
                     for (int q = 0; q < 8; ++q) { Lv = i == q ? (uint32_t)L[q] : Lv; Rv = i == q ? (uint32_t)R[q] : Rv; }
-                    D2D_GLOBAL uint16_t* p16 = reinterpret_cast<D2D_GLOBAL uint16_t*>(as_global(gout + 48u * g + 6u * k));
-                    p16[0] = (uint16_t)Lv; p16[1] = (uint16_t)(((Lv >> 16) & 0xFFu) | (Rv << 8)); p16[2] = (uint16_t)(Rv >> 8);
+                    D2D_GLOBAL uint16_t* p16 = reinterpret_cast<D2D_GLOBAL uint16_t*>(as_global(gout + 8u * FB * g + FB * k));
+                    if constexpr (SBY == 3) { p16[0] = (uint16_t)Lv; p16[1] = (uint16_t)(((Lv >> 16) & 0xFFu) | (Rv << 8)); p16[2] = (uint16_t)(Rv >> 8); }
+                    else { p16[0] = (uint16_t)Lv; p16[1] = (uint16_t)Rv; }
                 }
             }
         }
     };
     auto store_packed = [&](uint32_t tile, const u32x4 (&p4)[2], const u32x2 (&p2)[2]) {
         if (!tile_full(tile)) return;
-        uint8_t* gout = reinterpret_cast<uint8_t*>(j0.out) + (size_t)tile * (M2_TILE * 6) + 96u * r + 24u * h;
+        uint8_t* gout = reinterpret_cast<uint8_t*>(j0.out) + (size_t)tile * (M2_TILE * FB) + FB * lane_fr;
 #pragma unroll
         for (int g = 0; g < 2; ++g) {
             if (dbg & 64) { asm volatile("" :: "v"(p4[g]), "v"(p2[g])); continue; }
-            *reinterpret_cast<D2D_GLOBAL u32x4*>(as_global(gout + 48 * g)) = p4[g];
-            *reinterpret_cast<D2D_GLOBAL u32x2*>(as_global(gout + 48 * g + 16)) = p2[g];
+            *reinterpret_cast<D2D_GLOBAL u32x4*>(as_global(gout + 8 * FB * g)) = p4[g];
+            if constexpr (SBY == 3) *reinterpret_cast<D2D_GLOBAL u32x2*>(as_global(gout + 8 * FB * g + 16)) = p2[g];
         }
     };
     auto merge_extremes = [&](const Fast& f, uint32_t c) { vmn[c] = min(vmn[c], f.tmn); vmx[c] = max(vmx[c], f.tmx); };
@@ -562,6 +571,11 @@ __global__ __launch_bounds__(D2D_M3_THREADS) void d2d_fir_mfma3_kernel(Mfma2Args
 }
 
 // ---- host side -------------------------------------------------------------------------------
+// The file is compiled twice (Makefile): D2D_M3_PART 0 = the 24-bit kernels, the table builder and the dispatcher; 1 = the 16-bit
+// kernels (halves the compile time of the longest translation unit).
+#ifndef D2D_M3_PART
+#define D2D_M3_PART 0
+#endif
 
 // (MB, NPG, taps) of the filters this kernel serves: X_M32, C_M32, E_M32, C_M64, E_M64 (the stage-A filters only ever write the scratch)
 #ifdef D2D_M2_DEV
@@ -570,6 +584,7 @@ __global__ __launch_bounds__(D2D_M3_THREADS) void d2d_fir_mfma3_kernel(Mfma2Args
 #define D2D_M3_SHAPES(X) X(4, 10, 384) X(4, 12, 512) X(4, 13, 560) X(8, 24, 1024) X(8, 25, 1104)
 #endif
 
+#if D2D_M3_PART == 0
 bool mfma3_supported(int MB, int NPG, int NT) {
 #define X(mb, npg, nt) if (MB == mb && NPG == npg && NT == nt) return true;
     D2D_M3_SHAPES(X)
@@ -623,11 +638,13 @@ std::vector<int8_t> build_mfma4_tables(const d2d_filter_def& f, bool msb_first) 
     return t;
 }
 
-template <int MB, int NPG, int NT, int KIND>
+#endif
+
+template <int MB, int NPG, int NT, int KIND, int SBY>
 static hipError_t launch_mfma3_t(Mfma2Args& m, uint32_t nwt_max, uint32_t nrows, hipStream_t s) {
     static KernelPrep prep;
     int dev = 0;
-    const void* fn = reinterpret_cast<const void*>(&d2d_fir_mfma3_kernel<MB, NPG, NT, KIND>);
+    const void* fn = reinterpret_cast<const void*>(&d2d_fir_mfma3_kernel<MB, NPG, NT, KIND, SBY>);
     hipError_t e = prep.max_dynamic_lds(fn, 160 * 1024, &dev);
     if (e != hipSuccess) return e;
     // LDS: the shared tap table, then two stream buffers per wave; eight waves per block = two per SIMD
@@ -647,7 +664,7 @@ static hipError_t launch_mfma3_t(Mfma2Args& m, uint32_t nwt_max, uint32_t nrows,
             hipDeviceProp_t prop;
             if ((e = hipGetDeviceProperties(&prop, dev)) != hipSuccess) return e;
             int nb = 0;
-            e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, d2d_fir_mfma3_kernel<MB, NPG, NT, KIND>, (int)(64 * m.nwaves), smem);
+            e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, d2d_fir_mfma3_kernel<MB, NPG, NT, KIND, SBY>, (int)(64 * m.nwaves), smem);
             if (e != hipSuccess) return e;
             prep.ncu[dev] = prop.multiProcessorCount;
             prep.blocks_per_cu[dev] = nb < 1 ? 1 : nb;
@@ -660,28 +677,42 @@ static hipError_t launch_mfma3_t(Mfma2Args& m, uint32_t nwt_max, uint32_t nrows,
     if (gx < 1) gx = 1;
     const uint32_t need = (nwt_max + m.nwaves - 1) / m.nwaves;
     if (gx > need) gx = need;
-    hipLaunchKernelGGL((d2d_fir_mfma3_kernel<MB, NPG, NT, KIND>), dim3(gx, nrows), dim3(64 * m.nwaves), smem, s, m);
+    hipLaunchKernelGGL((d2d_fir_mfma3_kernel<MB, NPG, NT, KIND, SBY>), dim3(gx, nrows), dim3(64 * m.nwaves), smem, s, m);
     return hipGetLastError();
 }
 
-// variant 3: the dense chain, 4: the structured-sparse chain
-hipError_t launch_fir_mfma3(Mfma2Args& m, int variant, int MB, int NPG, int NT, uint32_t nwt_max, uint32_t nrows, hipStream_t s) {
-#define X(mb, npg, nt)                                                                              \
-    if (MB == mb && NPG == npg && NT == nt) {                                                        \
-        if (variant == 4) {                                                                          \
-            if (m.dkind == 1) return launch_mfma3_t<mb, npg, nt, 1>(m, nwt_max, nrows, s);            \
-            if (m.dkind == 2) return launch_mfma3_t<mb, npg, nt, 2>(m, nwt_max, nrows, s);            \
-            return launch_mfma3_t<mb, npg, nt, 0>(m, nwt_max, nrows, s);                              \
-        }                                                                                            \
-        if (m.dkind == 1) return launch_mfma3_t<mb, npg, 0, 1>(m, nwt_max, nrows, s);                 \
-        if (m.dkind == 2) return launch_mfma3_t<mb, npg, 0, 2>(m, nwt_max, nrows, s);                 \
-        return launch_mfma3_t<mb, npg, 0, 0>(m, nwt_max, nrows, s);                                   \
-    }
+#define K3(mb, npg, nt, sby)                                                                          \
+    { if (m.dkind == 1) return launch_mfma3_t<mb, npg, nt, 1, sby>(m, nwt_max, nrows, s);              \
+      if (m.dkind == 2) return launch_mfma3_t<mb, npg, nt, 2, sby>(m, nwt_max, nrows, s);              \
+      return launch_mfma3_t<mb, npg, nt, 0, sby>(m, nwt_max, nrows, s); }
+#if D2D_M3_PART == 1
+hipError_t launch_fir_mfma3_s16(Mfma2Args& m, int MB, int NPG, int NT, uint32_t nwt_max, uint32_t nrows, hipStream_t s) {
+#define X(mb, npg, nt) if (MB == mb && NPG == npg && NT == nt) K3(mb, npg, 0, 2)
     D2D_M3_SHAPES(X)
 #undef X
     return hipErrorInvalidValue;
 }
+#else
+hipError_t launch_fir_mfma3_s16(Mfma2Args& m, int MB, int NPG, int NT, uint32_t nwt_max, uint32_t nrows, hipStream_t s);
+// variant 3: the dense chain, 4: the structured-sparse chain (24-bit frames only)
+hipError_t launch_fir_mfma3(Mfma2Args& m, int variant, int MB, int NPG, int NT, uint32_t nwt_max, uint32_t nrows, hipStream_t s) {
+    if (m.f.epi.sample_bytes == 2) return launch_fir_mfma3_s16(m, MB, NPG, NT, nwt_max, nrows, s);
+    if (variant == 4) {          // the sparse chain is an experiment: compiled for the E filters only
+        if (MB == 4 && NT == 560) K3(4, 13, 560, 3)
+#ifndef D2D_M2_DEV
+        if (MB == 8 && NT == 1104) K3(8, 25, 1104, 3)
+#endif
+    }
+#define X(mb, npg, nt) if (MB == mb && NPG == npg && NT == nt) K3(mb, npg, 0, 3)
+    D2D_M3_SHAPES(X)
+#undef X
+    return hipErrorInvalidValue;
+}
+bool mfma3_sparse_compiled(int MB, int NT) { return (MB == 4 && NT == 560) || (MB == 8 && NT == 1104); }
+#endif
+#undef K3
 
+#if D2D_M3_PART == 0
 #if D2D_M3_STAMPS
 void mfma3_debug_stamps(unsigned long long out[8]) {
     (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(d2d_m3_stamps), sizeof(unsigned long long) * 8);
@@ -690,6 +721,7 @@ void mfma3_debug_stamps(unsigned long long out[8]) {
 }
 #else
 void mfma3_debug_stamps(unsigned long long out[8]) { for (int i = 0; i < 8; ++i) out[i] = 0; }
+#endif
 #endif
 
 }  // namespace d2d

@@ -257,16 +257,18 @@ def test_noise_shaped_segments_restart_and_carry(engine_lib, oracle_mod, kernel)
     assert np.array_equal(one, g)                          # one call (nine segments side by side) == nine calls
 
 
-@pytest.mark.parametrize("sparse", [0, 1], ids=["dense_chain", "sparse_chain"])
+@pytest.mark.parametrize("sparse,bits", [(0, 24), (1, 24), (0, 16)], ids=["dense_chain", "sparse_chain", "dense_chain_16bit"])
 @pytest.mark.parametrize("dither", ["T", "R", "X"])
 @pytest.mark.parametrize("dsd_rate,out_rate,filt", [(1, 88200, "E"), (1, 88200, "X"), (2, 88200, "E"), (2, 176400, "C"), (4, 176400, "E")])
-def test_pipelined_stereo_kernel_fast_and_careful_tiles(engine_lib, oracle_mod, monkeypatch, dsd_rate, out_rate, filt, dither, sparse):
-    """Stereo 24-bit at 0 dB runs d2d_fir_mfma3_kernel: the requantiser rides on the next chain in its branch-free form and a
+def test_pipelined_stereo_kernel_fast_and_careful_tiles(engine_lib, oracle_mod, monkeypatch, dsd_rate, out_rate, filt, dither, sparse, bits):
+    """Stereo 24-bit (and 16-bit) at 0 dB runs d2d_fir_mfma3_kernel: the requantiser rides on the next chain in its branch-free form and a
     tile that could clip, holds an exact rounding tie or is cut short by the end of the call is redone sample by sample.
     Full-scale stretches (all-ones / all-zeros bytes clip at both rails), quiet stretches, ragged call sizes and a short last
     call exercise those paths (an exact tie under triangular dither is a 2^-16 event per sample: likely here, certain in
     tests/test_gpu_fullsize.py).  D2D_SPARSE=1 swaps the kernel's dense MFMA chain for the structured-sparse one
     (v_smfmac_i32_32x32x64_i8, its own tap tables): same results."""
+    if sparse and filt != "E":
+        pytest.skip("the sparse chain is compiled for the E filters only")
     monkeypatch.setenv("D2D_SPARSE", str(sparse))
     rng = np.random.default_rng(5)
     nbytes = 4096 * 40 * dsd_rate
@@ -280,15 +282,16 @@ def test_pipelined_stereo_kernel_fast_and_careful_tiles(engine_lib, oracle_mod, 
         x[a:a + 8192] = 0x69                                 # an idle-like pattern: output near zero
         chans.append(x)
     kw = dict(dsd_rate=dsd_rate, output_rate=out_rate, channels=2, fmt="P", endianness="L", block_size=4096,
-              filter=filt, bit_depth=24, dither=dither, seed=99)
+              filter=filt, bit_depth=bits, dither=dither, seed=99)
     cuts = [0, 4096 * 7, 4096 * 7 + 4096 * 20, nbytes - 4096, nbytes]
     bufs = [pack_layout([ch[a:b] for ch in chans], "P", 4096) for a, b in zip(cuts[:-1], cuts[1:])]
     g, r, e, o = run_pair(engine_lib, oracle_mod, bufs, kw, 2)
     assert e.kernel_name().startswith("d2d_fir_mfma3_kernel")
-    assert (", 0, " in e.kernel_name()) == (sparse == 0)               # <MB, NPG, taps (0 = dense chain), dither kind>
+    targs = [t.strip() for t in e.kernel_name().split("<")[1].rstrip(">").split(",")]      # <MB, NPG, taps (0 = dense chain), dither kind, bytes per sample>
+    assert (targs[2] == "0") == (sparse == 0) and targs[4] == str(bits // 8)
     assert g.size == r.size and g.size > 0
     assert np.array_equal(g, r)
-    pcm = decode_pcm(g, 24, 2)
-    assert pcm.max() == (1 << 23) - 1 and pcm.min() == -(1 << 23)          # both rails were reached
+    pcm = decode_pcm(g, bits, 2)
+    assert pcm.max() == (1 << (bits - 1)) - 1 and pcm.min() == -(1 << (bits - 1))          # both rails were reached
     for c in range(2):
         assert e.peak(c) == o.peak(c)

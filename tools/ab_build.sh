@@ -14,6 +14,6 @@ if [ -n "$AB_M2" ]; then    # AB_M2=1: the two-group kernel's file too (it build
     -I$CS -I$ROOT/filters -DD2D_M2_DEV "$@" -c $CS/d2d_kernels_mfma2.hip -o $ROOT/ab/$NAME/d2d_kernels_mfma2.o
   M2O=$ROOT/ab/$NAME/d2d_kernels_mfma2.o
 fi
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $ROOT/ab/$NAME/libdsd2dxd_amd.so $CS/d2d_kernels.o $CS/d2d_kernels_mfma.o $M2O $ROOT/ab/$NAME/d2d_kernels_mfma3.o \
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $ROOT/ab/$NAME/libdsd2dxd_amd.so $CS/d2d_kernels.o $CS/d2d_kernels_mfma.o $M2O $ROOT/ab/$NAME/d2d_kernels_mfma3.o $CS/d2d_kernels_mfma3b.o \
   $CS/d2d_engine.o $CS/host/dsd_reader.o $CS/host/pcm_sink.o $CS/host/id3_tag.o $CS/host/rdsd2pcm.o $CS/host/rdsd2pcm_c.o -lpthread
 echo built ab/$NAME
