@@ -43,6 +43,7 @@ WORKLOADS = {
     # name: (dsd_rate, out_rate, bit_depth, dither, channels, algorithmic bytes per output sample)
     "dsd64_to_88k2_s24_stereo": (1, 88200, 24, "T", 2, 32 / 8 + 3),
     "dsd64_to_88k2_s16_stereo": (1, 88200, 16, "T", 2, 32 / 8 + 2),
+    "dsd64_to_88k2_f32_stereo": (1, 88200, 32, "X", 2, 32 / 8 + 4),
     "dsd64_to_352k8_f32_stereo": (1, 352800, 32, "X", 2, 8 / 8 + 4),
     "dsd128_to_88k2_s24_stereo": (2, 88200, 24, "T", 2, 64 / 8 + 3),
     "dsd128_to_88k2_s24_stereo_ns": (2, 88200, 24, "N", 2, 64 / 8 + 3),   # BASELINE config 3's noise-shaped variant (an extension)

@@ -699,7 +699,13 @@ static int mfma2_epilogue(const FirArgs& a, const Mfma2Args& m) {
 static bool mfma3_eligible(const FirArgs& a, const Mfma2Args& m, int MB, int NPG, int NT) {
     // stereo, 24-bit packed or 16-bit frames, the all-integer requantiser (unit gain)
     const bool frames_ok = !a.to_scratch && a.epi.channels == 2 && (a.epi.sample_bytes == 3 || a.epi.sample_bytes == 2) && m.qsh == 0 && !m.wide;
-    return frames_ok && m.intq && a.scale_bits >= 18 && a.scale_bits <= 30 && mfma3_supported(MB, NPG, NT);
+    const bool shape_ok = a.scale_bits >= 18 && a.scale_bits <= 30 && mfma3_supported(MB, NPG, NT);
+    // ... or 32-bit float at 0 dB without the float dither: the sample is (float)v * 2^-S
+    static const char* noint = getenv("D2D_NO_INTQ");
+    const bool float_ok = !noint && !a.to_scratch && a.epi.channels == 2 && a.epi.bits == 32 && a.epi.dither != 'F' && a.epi.gain == 1.0 && !m.wide &&
+                          a.sum_abs_q != 0 && a.sum_abs_q < (1ull << 31);
+    if (float_ok && shape_ok) return true;
+    return frames_ok && m.intq && shape_ok;
 }
 
 static void mfma2_geometry(const FirArgs& a, int MB, int NPG, Mfma2Args& m, size_t& smem);

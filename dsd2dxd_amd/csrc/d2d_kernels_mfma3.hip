@@ -87,7 +87,8 @@ __host__ __device__ constexpr int m4_stream_bytes(int MB, int NT) {
 }
 constexpr int M4_FRAG_BYTES = 1280;          // a tap fragment: 64 lanes x 16 compressed int8, then 64 index words
 
-// KIND: 0 no dither, 1 triangular, 2 rectangular.  Stereo, unit gain; SBY = bytes per sample: 3 (24-bit packed frames) or 2 (16-bit).
+// KIND: 0 no dither, 1 triangular, 2 rectangular.  Stereo, unit gain; SBY = bytes per sample: 3 (24-bit packed frames), 2 (16-bit) or
+// 4 (32-bit float, KIND 0 only: the sample is (float)v * 2^-S, one rounding like the oracle's (float)(double)).
 // NT = 0: the dense chain (tables of build_mfma2_tables); NT = taps: the structured-sparse chain (build_mfma4_tables).
 template <int MB, int NPG, int NT, int KIND, int SBY>
 __global__ __launch_bounds__(D2D_M3_THREADS) void d2d_fir_mfma3_kernel(Mfma2Args m) {
@@ -298,7 +299,9 @@ __global__ __launch_bounds__(D2D_M3_THREADS) void d2d_fir_mfma3_kernel(Mfma2Args
     int32_t vmn[2] = {0, 0}, vmx[2] = {0, 0};               // running extremes of v on the fast path
 
     // constants of the fast epilogue, parked in VGPRs
-    const int F_ = m.fbits;                                 // 0 < F <= 16
+    const int F_ = SBY == 4 ? 1 : m.fbits;                  // 0 < F <= 16 (integer depths)
+    float kFs = ldexpf(1.0f, -a.scale_bits);                // float output: y = v * 2^-S
+    asm volatile("" : "+v"(kFs));
     uint32_t kF = (uint32_t)F_, kSh = 16u - (uint32_t)F_, kShR = 32u - (uint32_t)F_;
     uint32_t kC1 = 0x7feb352dU, kC2 = 0x846ca68bU, kTm = (uint32_t)-32767;
     uint32_t k2 = 2u, k10 = 10u, k18 = 18u;
@@ -379,10 +382,13 @@ __global__ __launch_bounds__(D2D_M3_THREADS) void d2d_fir_mfma3_kernel(Mfma2Args
                 if constexpr (i & 1) f.tie = m3_min3_u16(f.tie, f.wprev, w); else f.wprev = w;
             } else if constexpr (KIND == 2) {
                 s = v + (int32_t)f.T[i];
+            } else if constexpr (SBY == 4) {
+                s = 0;
             } else {
                 s = v + kHalf + (v >> 31);                                                 // round half away from zero
             }
-            f.res[i] = s >> kF;
+            if constexpr (SBY == 4) f.res[i] = __float_as_int((float)v * kFs);
+            else f.res[i] = s >> kF;
             asm volatile("" : "+v"(f.res[i]));         // keep the whole job on this step (the value is only used after the region)
             if constexpr (i & 1) { f.tmn = m3_min3(f.tmn, f.vprev, v); f.tmx = m3_max3(f.tmx, f.vprev, v); } else f.vprev = v;
         }
@@ -401,6 +407,7 @@ __global__ __launch_bounds__(D2D_M3_THREADS) void d2d_fir_mfma3_kernel(Mfma2Args
         const bool full = tile * (uint32_t)M2_TILE + (uint32_t)M2_TILE <= j0.nout;
         if (dbg & 8) return false;                          // (8: never take the slow path, for timing experiments)
         if (!full || first > 0xFFFFFFFFu - (uint32_t)M2_TILE) return true;
+        if constexpr (SBY == 4) return false;                // float: nothing clips, nothing ties
         const bool bad = (KIND == 1 && (f.tie & 0xFFFFu) == 0) || f.tmx > kSafe || f.tmn < -kSafe;
         return __builtin_amdgcn_ballot_w64(bad) != 0;
     };
@@ -415,7 +422,7 @@ __global__ __launch_bounds__(D2D_M3_THREADS) void d2d_fir_mfma3_kernel(Mfma2Args
         for (int i = 0; i < 8; ++i) {
             const uint32_t nl = nl_base + 8u * (i >> 2) + (i & 3);
             const int32_t v = recombine((i >> 2) ? t1 : t0, i & 3);
-            out[i] = quant_slow(v, c, nl);
+            if constexpr (SBY == 4) out[i] = __float_as_int((float)v * kFs); else out[i] = quant_slow(v, c, nl);
             const uint32_t va = (uint32_t)(v < 0 ? -v : v);
             vmax = max(vmax, full || nl < j0.nout ? va : 0u);
         }
@@ -426,7 +433,7 @@ __global__ __launch_bounds__(D2D_M3_THREADS) void d2d_fir_mfma3_kernel(Mfma2Args
     // prefetch has been issued, so that nothing waits behind the stores; a partial tile (the file's last) goes out frame by
     // frame at once.
     auto tile_full = [&](uint32_t tile) -> bool { return tile * (uint32_t)M2_TILE + (uint32_t)M2_TILE <= j0.nout; };
-    auto pack_tile = [&](uint32_t tile, const int32_t (&L)[8], const int32_t (&R)[8], u32x4 (&p4)[2], u32x2 (&p2)[2]) {
+    auto pack_tile = [&](uint32_t tile, const int32_t (&L)[8], const int32_t (&R)[8], u32x4 (&p4)[2], u32x4 (&p2)[2]) {
         if (tile_full(tile)) {
 #pragma unroll
             for (int g = 0; g < 2; ++g) {
@@ -436,7 +443,10 @@ __global__ __launch_bounds__(D2D_M3_THREADS) void d2d_fir_mfma3_kernel(Mfma2Args
                     // frames k, k+1 -> 12 bytes: [L0 L1 L2 R0 | R1 R2 L0' L1' | L2' R0' R1' R2']
                     p4[g] = u32x4{__builtin_amdgcn_perm(Ra, La, 0x04020100u), __builtin_amdgcn_perm(Lb, Ra, 0x05040201u),
                                   __builtin_amdgcn_perm(Rb, Lb, 0x06050402u), __builtin_amdgcn_perm(Rc, Lc, 0x04020100u)};
-                    p2[g] = u32x2{__builtin_amdgcn_perm(Ld, Rc, 0x05040201u), __builtin_amdgcn_perm(Rd, Ld, 0x06050402u)};
+                    p2[g] = u32x4{__builtin_amdgcn_perm(Ld, Rc, 0x05040201u), __builtin_amdgcn_perm(Rd, Ld, 0x06050402u), 0u, 0u};
+                } else if constexpr (SBY == 4) {
+                    p4[g] = u32x4{La, Ra, Lb, Rb};
+                    p2[g] = u32x4{Lc, Rc, Ld, Rd};
                 } else {
                     // 16-bit: one dword per frame [L0 L1 R0 R1]
                     p4[g] = u32x4{__builtin_amdgcn_perm(Ra, La, 0x05040100u), __builtin_amdgcn_perm(Rb, Lb, 0x05040100u),
@@ -456,19 +466,21 @@ __global__ __launch_bounds__(D2D_M3_THREADS) void d2d_fir_mfma3_kernel(Mfma2Args
                     for (int q = 0; q < 8; ++q) { Lv = i == q ? (uint32_t)L[q] : Lv; Rv = i == q ? (uint32_t)R[q] : Rv; }
                     D2D_GLOBAL uint16_t* p16 = reinterpret_cast<D2D_GLOBAL uint16_t*>(as_global(gout + 8u * FB * g + FB * k));
                     if constexpr (SBY == 3) { p16[0] = (uint16_t)Lv; p16[1] = (uint16_t)(((Lv >> 16) & 0xFFu) | (Rv << 8)); p16[2] = (uint16_t)(Rv >> 8); }
+                    else if constexpr (SBY == 4) { p16[0] = (uint16_t)Lv; p16[1] = (uint16_t)(Lv >> 16); p16[2] = (uint16_t)Rv; p16[3] = (uint16_t)(Rv >> 16); }
                     else { p16[0] = (uint16_t)Lv; p16[1] = (uint16_t)Rv; }
                 }
             }
         }
     };
-    auto store_packed = [&](uint32_t tile, const u32x4 (&p4)[2], const u32x2 (&p2)[2]) {
+    auto store_packed = [&](uint32_t tile, const u32x4 (&p4)[2], const u32x4 (&p2)[2]) {
         if (!tile_full(tile)) return;
         uint8_t* gout = reinterpret_cast<uint8_t*>(j0.out) + (size_t)tile * (M2_TILE * FB) + FB * lane_fr;
 #pragma unroll
         for (int g = 0; g < 2; ++g) {
             if (dbg & 64) { asm volatile("" :: "v"(p4[g]), "v"(p2[g])); continue; }
             *reinterpret_cast<D2D_GLOBAL u32x4*>(as_global(gout + 8 * FB * g)) = p4[g];
-            if constexpr (SBY == 3) *reinterpret_cast<D2D_GLOBAL u32x2*>(as_global(gout + 8 * FB * g + 16)) = p2[g];
+            if constexpr (SBY == 3) *reinterpret_cast<D2D_GLOBAL u32x2*>(as_global(gout + 8 * FB * g + 16)) = u32x2{p2[g].x, p2[g].y};
+            if constexpr (SBY == 4) *reinterpret_cast<D2D_GLOBAL u32x4*>(as_global(gout + 8 * FB * g + 16)) = p2[g];
         }
     };
     auto merge_extremes = [&](const Fast& f, uint32_t c) { vmn[c] = min(vmn[c], f.tmn); vmx[c] = max(vmx[c], f.tmx); };
@@ -500,7 +512,7 @@ __global__ __launch_bounds__(D2D_M3_THREADS) void d2d_fir_mfma3_kernel(Mfma2Args
         }
         wave_sync2();
         stamp(0);
-        u32x4 p4[2]; u32x2 p2[2];
+        u32x4 p4[2]; u32x4 p2[2];
         {
             Fast f;
             fast_begin(f, pw, 1);
@@ -544,7 +556,7 @@ __global__ __launch_bounds__(D2D_M3_THREADS) void d2d_fir_mfma3_kernel(Mfma2Args
         fast_begin(f, pw, 1);
         static_for<0, NJ>([&](auto jc) { fast_job(f, accB[0], accB[1], jc); });
         if (fast_failed(f, pw)) redo(1u, pw, 1, f.res); else merge_extremes(f, 1);
-        u32x4 p4[2]; u32x2 p2[2];
+        u32x4 p4[2]; u32x4 p2[2];
         pack_tile(pw, held, f.res, p4, p2);
         store_packed(pw, p4, p2);
     }
@@ -558,7 +570,7 @@ __global__ __launch_bounds__(D2D_M3_THREADS) void d2d_fir_mfma3_kernel(Mfma2Args
     }
 #endif
     // peak meter: |x| in LSB; undo the power-of-two part exactly
-    const double unscale = 1.0 / (double)(1u << (a.epi.bits - 1));
+    const double unscale = 1.0 / (double)(1u << (a.epi.bits - 1));   // (float: fbits = S - 31, so dev * 2^-fbits * 2^-31 = dev * 2^-S)
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
         const int32_t dev = max(vmx[c], -vmn[c]);
@@ -687,6 +699,12 @@ static hipError_t launch_mfma3_t(Mfma2Args& m, uint32_t nwt_max, uint32_t nrows,
       return launch_mfma3_t<mb, npg, nt, 0, sby>(m, nwt_max, nrows, s); }
 #if D2D_M3_PART == 1
 hipError_t launch_fir_mfma3_s16(Mfma2Args& m, int MB, int NPG, int NT, uint32_t nwt_max, uint32_t nrows, hipStream_t s) {
+    if (m.f.epi.sample_bytes == 4) {       // float: no dither (the float dither 'F' stays with the two-group kernel)
+#define X(mb, npg, nt) if (MB == mb && NPG == npg && NT == nt) return launch_mfma3_t<mb, npg, 0, 0, 4>(m, nwt_max, nrows, s);
+        D2D_M3_SHAPES(X)
+#undef X
+        return hipErrorInvalidValue;
+    }
 #define X(mb, npg, nt) if (MB == mb && NPG == npg && NT == nt) K3(mb, npg, 0, 2)
     D2D_M3_SHAPES(X)
 #undef X
@@ -696,7 +714,7 @@ hipError_t launch_fir_mfma3_s16(Mfma2Args& m, int MB, int NPG, int NT, uint32_t 
 hipError_t launch_fir_mfma3_s16(Mfma2Args& m, int MB, int NPG, int NT, uint32_t nwt_max, uint32_t nrows, hipStream_t s);
 // variant 3: the dense chain, 4: the structured-sparse chain (24-bit frames only)
 hipError_t launch_fir_mfma3(Mfma2Args& m, int variant, int MB, int NPG, int NT, uint32_t nwt_max, uint32_t nrows, hipStream_t s) {
-    if (m.f.epi.sample_bytes == 2) return launch_fir_mfma3_s16(m, MB, NPG, NT, nwt_max, nrows, s);
+    if (m.f.epi.sample_bytes != 3) return launch_fir_mfma3_s16(m, MB, NPG, NT, nwt_max, nrows, s);     // 16-bit and float frames: part 1
     if (variant == 4) {          // the sparse chain is an experiment: compiled for the E filters only
         if (MB == 4 && NT == 560) K3(4, 13, 560, 3)
 #ifndef D2D_M2_DEV

@@ -257,11 +257,11 @@ def test_noise_shaped_segments_restart_and_carry(engine_lib, oracle_mod, kernel)
     assert np.array_equal(one, g)                          # one call (nine segments side by side) == nine calls
 
 
-@pytest.mark.parametrize("sparse,bits", [(0, 24), (1, 24), (0, 16)], ids=["dense_chain", "sparse_chain", "dense_chain_16bit"])
+@pytest.mark.parametrize("sparse,bits", [(0, 24), (1, 24), (0, 16), (0, 32)], ids=["dense_chain", "sparse_chain", "dense_chain_16bit", "dense_chain_float"])
 @pytest.mark.parametrize("dither", ["T", "R", "X"])
 @pytest.mark.parametrize("dsd_rate,out_rate,filt", [(1, 88200, "E"), (1, 88200, "X"), (2, 88200, "E"), (2, 176400, "C"), (4, 176400, "E")])
 def test_pipelined_stereo_kernel_fast_and_careful_tiles(engine_lib, oracle_mod, monkeypatch, dsd_rate, out_rate, filt, dither, sparse, bits):
-    """Stereo 24-bit (and 16-bit) at 0 dB runs d2d_fir_mfma3_kernel: the requantiser rides on the next chain in its branch-free form and a
+    """Stereo 24-bit (and 16-bit, and float without the float dither) at 0 dB runs d2d_fir_mfma3_kernel: the requantiser rides on the next chain in its branch-free form and a
     tile that could clip, holds an exact rounding tie or is cut short by the end of the call is redone sample by sample.
     Full-scale stretches (all-ones / all-zeros bytes clip at both rails), quiet stretches, ragged call sizes and a short last
     call exercise those paths (an exact tie under triangular dither is a 2^-16 event per sample: likely here, certain in
@@ -292,6 +292,9 @@ def test_pipelined_stereo_kernel_fast_and_careful_tiles(engine_lib, oracle_mod, 
     assert g.size == r.size and g.size > 0
     assert np.array_equal(g, r)
     pcm = decode_pcm(g, bits, 2)
-    assert pcm.max() == (1 << (bits - 1)) - 1 and pcm.min() == -(1 << (bits - 1))          # both rails were reached
+    if bits == 32:
+        assert pcm.max() >= 1.0 and pcm.min() <= -1.0                                      # full scale both ways (float does not clip)
+    else:
+        assert pcm.max() == (1 << (bits - 1)) - 1 and pcm.min() == -(1 << (bits - 1))      # both rails were reached
     for c in range(2):
         assert e.peak(c) == o.peak(c)
