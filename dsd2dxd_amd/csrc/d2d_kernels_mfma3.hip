@@ -151,22 +151,27 @@ __global__ __launch_bounds__(D2D_M3_THREADS) void d2d_fir_mfma3_kernel(Mfma2Args
 #pragma unroll
     for (int i = 0; i < PF; ++i) { const uint32_t q = lane + 64u * i; lofs[i] = 16u * (q < (uint32_t)NCHK ? q : (uint32_t)NCHK - 1u); }
     const uint32_t chf[2] = {(uint32_t)__builtin_amdgcn_readfirstlane((int)jobs[0].ch), (uint32_t)__builtin_amdgcn_readfirstlane((int)jobs[1].ch)};
-    u32x4 pf[PF];                                           // a chain's bytes are requested one chain ahead
-    auto issue_loads = [&](uint32_t w, auto cc) {
+    u32x4 pf[2][PF];                                        // one prefetch register set per channel: a tile's bytes are requested a whole tile ahead
+    // AF ("all fast"): the caller knows that the tile lies inside the call's full power-of-two blocks -- no test, and no byte-gather
+    // call in the loop (a call makes the compiler wait for every outstanding load before the next LDS write)
+    auto issue_loads = [&](uint32_t w, auto cc, auto af) {
         constexpr int c = decltype(cc)::value;
+        constexpr bool AF = decltype(af)::value;
         const int32_t ab = tile_ab16(w);
-        if (fast_layout && ab >= 0 && (uint32_t)ab + 16u * NCHK <= full_bytes) {
+        if (AF || (fast_layout && ab >= 0 && (uint32_t)ab + 16u * NCHK <= full_bytes)) {
             const uint32_t blk0 = (uint32_t)ab >> bshift, r0 = (uint32_t)ab & (Bsz - 1);
             const uint8_t* base = j0.in + ((uint64_t)(blk0 * Ct + chf[c]) << bshift);
 #pragma unroll
             for (int i = 0; i < PF; ++i) {
                 const uint32_t off = r0 + lofs[i];
                 const uint32_t o = __umul24(off >> bshift, jump) + off;
-                pf[i] = *reinterpret_cast<D2D_GLOBAL const u32x4*>(as_global(base) + o);
+                pf[c][i] = *reinterpret_cast<D2D_GLOBAL const u32x4*>(as_global(base) + o);
             }
         } else {
+            if constexpr (!AF) {
 #pragma unroll
-            for (int i = 0; i < PF; ++i) pf[i] = gather_chunk(jobs + c, Ct, a.B, a.keep, ab + (int32_t)lofs[i]);
+                for (int i = 0; i < PF; ++i) pf[c][i] = gather_chunk(jobs + c, Ct, a.B, a.keep, ab + (int32_t)lofs[i]);
+            }
         }
     };
     auto write_lds_x = [&](auto cc, auto xc) {
@@ -176,7 +181,7 @@ __global__ __launch_bounds__(D2D_M3_THREADS) void d2d_fir_mfma3_kernel(Mfma2Args
 #pragma unroll
         for (int i = 0; i < PF; ++i)
             if (lane + 64u * i < (uint32_t)NCHK) {
-                const uint32_t v[4] = {pf[i].x, pf[i].y, pf[i].z, pf[i].w};
+                const uint32_t v[4] = {pf[c][i].x, pf[c][i].y, pf[c][i].z, pf[c][i].w};
 #pragma unroll
                 for (int k = 0; k < 4; ++k)
                     *reinterpret_cast<uint32_t*>(buf + (k < X ? wlo[i] : whi[i]) + 4 * k) = v[k];
@@ -472,8 +477,8 @@ __global__ __launch_bounds__(D2D_M3_THREADS) void d2d_fir_mfma3_kernel(Mfma2Args
             }
         }
     };
-    auto store_packed = [&](uint32_t tile, const u32x4 (&p4)[2], const u32x4 (&p2)[2]) {
-        if (!tile_full(tile)) return;
+    auto store_packed = [&](uint32_t tile, const u32x4 (&p4)[2], const u32x4 (&p2)[2], bool known_full = false) {
+        if (!known_full && !tile_full(tile)) return;
         uint8_t* gout = reinterpret_cast<uint8_t*>(j0.out) + (size_t)tile * (M2_TILE * FB) + FB * lane_fr;
 #pragma unroll
         for (int g = 0; g < 2; ++g) {
@@ -485,7 +490,7 @@ __global__ __launch_bounds__(D2D_M3_THREADS) void d2d_fir_mfma3_kernel(Mfma2Args
     };
     auto merge_extremes = [&](const Fast& f, uint32_t c) { vmn[c] = min(vmn[c], f.tmn); vmx[c] = max(vmx[c], f.tmx); };
 
-    uint32_t wt = blockIdx.x * m.nwaves + wave;
+    const uint32_t wv = blockIdx.x * m.nwaves + wave;       // this wave's index among the file's waves
 #if D2D_M3_STAMPS
     const unsigned long long t_start = __builtin_amdgcn_s_memtime(), rt_start = __builtin_amdgcn_s_memrealtime();
     unsigned long long st_sum[3] = {0, 0, 0}, st_last = t_start;
@@ -495,70 +500,119 @@ __global__ __launch_bounds__(D2D_M3_THREADS) void d2d_fir_mfma3_kernel(Mfma2Args
 #endif
     using C0 = std::integral_constant<int, 0>;
     using C1 = std::integral_constant<int, 1>;
-    if (wt < nwt) issue_loads(wt, C0{});
-    v16i accA[2], accB[2];                                  // channel 0's / channel 1's accumulators
-#pragma unroll
-    for (int i = 0; i < 16; ++i) { accB[0][i] = 0; accB[1][i] = 0; }
-    int32_t held[8];                                        // channel 0's samples of the tile in flight
-    bool have_prev = false;
-    uint32_t pw = 0;                                        // the tile whose channel 1 still waits for its epilogue
-    for (; wt < nwt; wt += wstride) {
-        // ---- region A: channel 0's chain of tile wt, channel 1's epilogue of tile pw ----
-        stamp(2);
-        wave_sync2();
-        if (!(dbg & 4)) {
-            write_lds(C0{});
-            issue_loads(wt, C1{});
+    // The pipelined loop over the tiles t_begin + wv + k * wstride < t_end.
+    auto run_loop = [&](uint32_t t_begin, uint32_t t_end, auto af) {
+        constexpr bool AF = decltype(af)::value;
+        uint32_t wt = t_begin + wv;
+        u32x4 p4[2] = {u32x4{0, 0, 0, 0}, u32x4{0, 0, 0, 0}}, p2[2] = {u32x4{0, 0, 0, 0}, u32x4{0, 0, 0, 0}};
+        if (wt < t_end) {
+            issue_loads(wt, C0{}, af); issue_loads(wt, C1{}, af);
+            // AF: every trip issues the same loads and stores in the same order (the first trip stores zeros to its own tile, rewritten one
+            // trip later; the last trip re-requests its own tile), so that the compiler can count exactly how many younger requests
+            // may stay in flight at each LDS write -- with a conditional load or store in the loop it waits for all of them
+            if (AF && !(dbg & 64)) store_packed(wt, p4, p2, true);
         }
-        wave_sync2();
-        stamp(0);
-        u32x4 p4[2]; u32x4 p2[2];
-        {
+        v16i accA[2], accB[2];                                  // channel 0's / channel 1's accumulators
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { accB[0][i] = 0; accB[1][i] = 0; }
+        int32_t held[8];                                        // channel 0's samples of the tile in flight
+        bool have_prev = false;
+        uint32_t pw = wt;                                       // the tile whose channel 1 still waits for its epilogue
+        for (; wt < t_end; wt += wstride) {
+            const bool more = wt + wstride < t_end;
+            const uint32_t nxt = more ? wt + wstride : wt;
+            // ---- region A: channel 0's chain of tile wt, channel 1's epilogue of tile pw ----
+            stamp(2);
+            wave_sync2();
+            if (!(dbg & 4)) {
+                write_lds(C0{});
+                if (AF || more) issue_loads(nxt, C0{}, af);
+            }
+            wave_sync2();
+            stamp(0);
+            {
+                Fast f;
+                fast_begin(f, pw, 1);
+                if (dbg & 2) chain(0u, accA[0], accA[1], no_hook);
+                else if (dbg & 1) { static_for<0, NJ>([&](auto jc) { fast_job(f, accB[0], accB[1], jc); }); accA[0] = cinit + (int)lane; accA[1] = cinit - (int)lane; }
+                else chain(0u, accA[0], accA[1], [&](auto uc) { fast_hook(f, accB[0], accB[1], uc); });
+                if (D2D_M3_STAMPS) asm volatile("" :: "v"(accA[0]), "v"(accA[1]));
+                stamp(1);
+                if (have_prev) {
+                    if (!(dbg & 3) && fast_failed(f, pw)) redo(1u, pw, 1, f.res); else merge_extremes(f, 1);
+                    pack_tile(pw, held, f.res, p4, p2);
+                }
+            }
+            // ---- region B: channel 1's chain of tile wt, channel 0's epilogue of tile wt ----
+            stamp(2);
+            wave_sync2();
+            if (!(dbg & 4)) {
+                write_lds(C1{});
+                if (AF || more) issue_loads(nxt, C1{}, af);
+            }
+            if constexpr (AF) store_packed(pw, p4, p2, true);
+            else if (have_prev) store_packed(pw, p4, p2);
+            wave_sync2();
+            stamp(0);
+            {
+                Fast f;
+                fast_begin(f, wt, 0);
+                if (dbg & 2) chain(1u, accB[0], accB[1], no_hook);
+                else if (dbg & 1) { static_for<0, NJ>([&](auto jc) { fast_job(f, accA[0], accA[1], jc); }); accB[0] = cinit - (int)lane; accB[1] = cinit + (int)lane; }
+                else chain(1u, accB[0], accB[1], [&](auto uc) { fast_hook(f, accA[0], accA[1], uc); });
+                if (D2D_M3_STAMPS) asm volatile("" :: "v"(accB[0]), "v"(accB[1]));
+                stamp(1);
+                if (!(dbg & 3) && fast_failed(f, wt)) redo(0u, wt, 0, f.res); else merge_extremes(f, 0);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) held[i] = f.res[i];
+            }
+            have_prev = true; pw = wt;
+        }
+        if (have_prev) {
+            // drain: channel 1 of the wave's last tile
             Fast f;
             fast_begin(f, pw, 1);
-            if (dbg & 2) chain(0u, accA[0], accA[1], no_hook);
-            else if (dbg & 1) { static_for<0, NJ>([&](auto jc) { fast_job(f, accB[0], accB[1], jc); }); accA[0] = cinit + (int)lane; accA[1] = cinit - (int)lane; }
-            else chain(0u, accA[0], accA[1], [&](auto uc) { fast_hook(f, accB[0], accB[1], uc); });
-            if (D2D_M3_STAMPS) asm volatile("" :: "v"(accA[0]), "v"(accA[1]));
-            stamp(1);
-            if (have_prev) {
-                if (!(dbg & 3) && fast_failed(f, pw)) redo(1u, pw, 1, f.res); else merge_extremes(f, 1);
-                pack_tile(pw, held, f.res, p4, p2);
-            }
+            static_for<0, NJ>([&](auto jc) { fast_job(f, accB[0], accB[1], jc); });
+            if (fast_failed(f, pw)) redo(1u, pw, 1, f.res); else merge_extremes(f, 1);
+            pack_tile(pw, held, f.res, p4, p2);
+            store_packed(pw, p4, p2);
         }
-        // ---- region B: channel 1's chain of tile wt, channel 0's epilogue of tile wt ----
-        stamp(2);
+    };
+    // One tile the careful way, start to finish (call edges: the window reaches into the carried history or past the call's full
+    // blocks, so its bytes are gathered one by one).
+    auto slow_tile = [&](uint32_t t) {
         wave_sync2();
-        if (!(dbg & 4)) {
-            write_lds(C1{});
-            if (wt + wstride < nwt) issue_loads(wt + wstride, C0{});
-        }
-        if (have_prev) store_packed(pw, p4, p2);
+        issue_loads(t, C0{}, std::false_type{});
+        issue_loads(t, C1{}, std::false_type{});
+        write_lds(C0{});
+        write_lds(C1{});
         wave_sync2();
-        stamp(0);
-        {
-            Fast f;
-            fast_begin(f, wt, 0);
-            if (dbg & 2) chain(1u, accB[0], accB[1], no_hook);
-            else if (dbg & 1) { static_for<0, NJ>([&](auto jc) { fast_job(f, accA[0], accA[1], jc); }); accB[0] = cinit - (int)lane; accB[1] = cinit + (int)lane; }
-            else chain(1u, accB[0], accB[1], [&](auto uc) { fast_hook(f, accA[0], accA[1], uc); });
-            if (D2D_M3_STAMPS) asm volatile("" :: "v"(accB[0]), "v"(accB[1]));
-            stamp(1);
-            if (!(dbg & 3) && fast_failed(f, wt)) redo(0u, wt, 0, f.res); else merge_extremes(f, 0);
-#pragma unroll
-            for (int i = 0; i < 8; ++i) held[i] = f.res[i];
-        }
-        have_prev = true; pw = wt;
-    }
-    if (have_prev) {
-        // drain: channel 1 of the wave's last tile
-        Fast f;
-        fast_begin(f, pw, 1);
-        static_for<0, NJ>([&](auto jc) { fast_job(f, accB[0], accB[1], jc); });
-        if (fast_failed(f, pw)) redo(1u, pw, 1, f.res); else merge_extremes(f, 1);
+        int32_t o0[8], o1[8];
+        redo(0u, t, 0, o0);
+        redo(1u, t, 1, o1);
         u32x4 p4[2]; u32x4 p2[2];
-        pack_tile(pw, held, f.res, p4, p2);
-        store_packed(pw, p4, p2);
+        pack_tile(t, o0, o1, p4, p2);
+        store_packed(t, p4, p2);
+    };
+    if (fast_layout) {
+        // the tiles [t_lo, t_hi) lie inside the call's full blocks: the loop without the gather path; the few around them one by one
+        const int64_t T = (int64_t)M2_TILE * MB;
+        auto is_fast = [&](uint32_t w) { const int32_t ab = tile_ab16(w); return ab >= 0 && (uint32_t)ab + 16u * NCHK <= full_bytes; };
+        uint32_t t_lo = first0 >= 0 ? 0u : (uint32_t)((-first0 + T - 1) / T);
+        if (t_lo > nwt) t_lo = nwt;
+        uint32_t t_hi = t_lo;
+        {
+            const int64_t room = (int64_t)full_bytes - 16 * NCHK - first0;
+            if (room >= 0) { const int64_t e = room / T + 1; t_hi = e > (int64_t)nwt ? nwt : (uint32_t)e; if (t_hi < t_lo) t_hi = t_lo; }
+            while (t_hi > t_lo && !is_fast(t_hi - 1)) --t_hi;
+            while (t_hi < nwt && t_hi >= t_lo && is_fast(t_hi) && (t_hi > t_lo || is_fast(t_lo))) ++t_hi;
+        }
+        { const uint32_t nfull = j0.nout / (uint32_t)M2_TILE; if (t_hi > nfull) t_hi = nfull > t_lo ? nfull : t_lo; }     // whole tiles only
+        run_loop(t_lo, t_hi, std::true_type{});
+        const uint32_t n_edge = t_lo + (nwt - t_hi);
+        for (uint32_t i = wv; i < n_edge; i += wstride) slow_tile(i < t_lo ? i : t_hi + (i - t_lo));
+    } else {
+        run_loop(0u, nwt, std::false_type{});
     }
 
 #if D2D_M3_STAMPS
