@@ -151,7 +151,10 @@ __global__ __launch_bounds__(D2D_M3_THREADS) void d2d_fir_mfma3_kernel(Mfma2Args
 #pragma unroll
     for (int i = 0; i < PF; ++i) { const uint32_t q = lane + 64u * i; lofs[i] = 16u * (q < (uint32_t)NCHK ? q : (uint32_t)NCHK - 1u); }
     const uint32_t chf[2] = {(uint32_t)__builtin_amdgcn_readfirstlane((int)jobs[0].ch), (uint32_t)__builtin_amdgcn_readfirstlane((int)jobs[1].ch)};
-    u32x4 pf[2][PF];                                        // one prefetch register set per channel: a tile's bytes are requested a whole tile ahead
+    // M = 32: one prefetch register set per channel, a tile's bytes are requested a whole tile ahead; M = 64 (five chunks per lane and
+    // channel, no registers to spare): one set, a chain's bytes are requested one chain ahead
+    constexpr int NPFSET = MB >= 8 ? 1 : 2;
+    u32x4 pf[NPFSET][PF];
     // AF ("all fast"): the caller knows that the tile lies inside the call's full power-of-two blocks -- no test, and no byte-gather
     // call in the loop (a call makes the compiler wait for every outstanding load before the next LDS write)
     auto issue_loads = [&](uint32_t w, auto cc, auto af) {
@@ -165,12 +168,12 @@ __global__ __launch_bounds__(D2D_M3_THREADS) void d2d_fir_mfma3_kernel(Mfma2Args
             for (int i = 0; i < PF; ++i) {
                 const uint32_t off = r0 + lofs[i];
                 const uint32_t o = __umul24(off >> bshift, jump) + off;
-                pf[c][i] = *reinterpret_cast<D2D_GLOBAL const u32x4*>(as_global(base) + o);
+                pf[c % NPFSET][i] = *reinterpret_cast<D2D_GLOBAL const u32x4*>(as_global(base) + o);
             }
         } else {
             if constexpr (!AF) {
 #pragma unroll
-                for (int i = 0; i < PF; ++i) pf[c][i] = gather_chunk(jobs + c, Ct, a.B, a.keep, ab + (int32_t)lofs[i]);
+                for (int i = 0; i < PF; ++i) pf[c % NPFSET][i] = gather_chunk(jobs + c, Ct, a.B, a.keep, ab + (int32_t)lofs[i]);
             }
         }
     };
@@ -181,7 +184,7 @@ __global__ __launch_bounds__(D2D_M3_THREADS) void d2d_fir_mfma3_kernel(Mfma2Args
 #pragma unroll
         for (int i = 0; i < PF; ++i)
             if (lane + 64u * i < (uint32_t)NCHK) {
-                const uint32_t v[4] = {pf[c][i].x, pf[c][i].y, pf[c][i].z, pf[c][i].w};
+                const uint32_t v[4] = {pf[c % NPFSET][i].x, pf[c % NPFSET][i].y, pf[c % NPFSET][i].z, pf[c % NPFSET][i].w};
 #pragma unroll
                 for (int k = 0; k < 4; ++k)
                     *reinterpret_cast<uint32_t*>(buf + (k < X ? wlo[i] : whi[i]) + 4 * k) = v[k];
@@ -207,16 +210,21 @@ __global__ __launch_bounds__(D2D_M3_THREADS) void d2d_fir_mfma3_kernel(Mfma2Args
     // One chain: TP pair steps, two groups of eight phases; the LDS reads of a step are issued one step ahead; `hook(u)` is
     // whatever else the wave does during step u.
     auto chain_dense = [&](const uint8_t* rbc, v16i& acc0, v16i& acc1, auto&& hook) {
+        // M = 64: row block 1 reads its tap fragments again instead of holding block 0's for MB steps (64 registers the kernel does not
+        // have there; LDS has the room)
+        constexpr bool REREAD = MB >= 8;
         uint32_t W[TP];
-        v4i F[2 * NPG];
+        v4i F[2 * NPG], G[2 * NPG];
         auto rdW = [&](auto uc) { constexpr int u = decltype(uc)::value; W[u] = *reinterpret_cast<const uint32_t*>(rbc + 4 * (2 * u + ((2 * u) >> LSH))); };
         auto rdF = [&](auto uc) { constexpr int u = decltype(uc)::value; F[2 * u] = tp[64 * (2 * u)]; F[2 * u + 1] = tp[64 * (2 * u + 1)]; };
+        auto rdG = [&](auto uc) { constexpr int u = decltype(uc)::value; G[2 * u] = tp[64 * (2 * u)]; G[2 * u + 1] = tp[64 * (2 * u + 1)]; };
         constexpr int AHEAD = 2;                                    // LDS reads run this many steps ahead of their use
         static_for<0, AHEAD>([&](auto uc) { rdW(uc); rdF(uc); });
         static_for<0, TP>([&](auto uc) {
             constexpr int u = decltype(uc)::value;
             if constexpr (u + AHEAD < TP) rdW(std::integral_constant<int, u + AHEAD>{});
             if constexpr (u + AHEAD < NPG) rdF(std::integral_constant<int, u + AHEAD>{});
+            if constexpr (REREAD && u + AHEAD >= MB && u + AHEAD - MB < NPG) rdG(std::integral_constant<int, u + AHEAD - MB>{});
             const uint32_t w = W[u];
             const v4i lo = {(int)(w & km[0]), (int)(w & km[1]), (int)(w & km[2]), (int)(w & km[3])};   // every plane masked: a raw byte operand costs more power than its v_and saves
             const v4i hi = {(int)(w & km[4]), (int)(w & km[5]), (int)(w & km[6]), (int)(w & km[7])};
@@ -227,9 +235,10 @@ __global__ __launch_bounds__(D2D_M3_THREADS) void d2d_fir_mfma3_kernel(Mfma2Args
             }
             if constexpr (u >= MB && u - MB < NPG) {
                 constexpr int pp = u - MB;
-                if constexpr (pp == 0) acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(F[0], lo, cinit, 0, 0, 0);
-                else acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(F[2 * pp], lo, acc1, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(F[2 * pp + 1], hi, acc1, 0, 0, 0);
+                const v4i A0 = REREAD ? G[2 * pp] : F[2 * pp], A1 = REREAD ? G[2 * pp + 1] : F[2 * pp + 1];
+                if constexpr (pp == 0) acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(A0, lo, cinit, 0, 0, 0);
+                else acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(A0, lo, acc1, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(A1, hi, acc1, 0, 0, 0);
             }
             hook(uc);
             __builtin_amdgcn_sched_barrier(0);
@@ -504,13 +513,16 @@ __global__ __launch_bounds__(D2D_M3_THREADS) void d2d_fir_mfma3_kernel(Mfma2Args
     auto run_loop = [&](uint32_t t_begin, uint32_t t_end, auto af) {
         constexpr bool AF = decltype(af)::value;
         uint32_t wt = t_begin + wv;
-        u32x4 p4[2] = {u32x4{0, 0, 0, 0}, u32x4{0, 0, 0, 0}}, p2[2] = {u32x4{0, 0, 0, 0}, u32x4{0, 0, 0, 0}};
+        // the packed frames of the tile before: AF keeps them across trips (it stores on every trip), the general loop only from
+        // the pack to the store
+        u32x4 p4h[2] = {u32x4{0, 0, 0, 0}, u32x4{0, 0, 0, 0}}, p2h[2] = {u32x4{0, 0, 0, 0}, u32x4{0, 0, 0, 0}};
         if (wt < t_end) {
-            issue_loads(wt, C0{}, af); issue_loads(wt, C1{}, af);
+            issue_loads(wt, C0{}, af);
+            if constexpr (NPFSET == 2) issue_loads(wt, C1{}, af);
             // AF: every trip issues the same loads and stores in the same order (the first trip stores zeros to its own tile, rewritten one
             // trip later; the last trip re-requests its own tile), so that the compiler can count exactly how many younger requests
             // may stay in flight at each LDS write -- with a conditional load or store in the loop it waits for all of them
-            if (AF && !(dbg & 64)) store_packed(wt, p4, p2, true);
+            if (AF && !(dbg & 64)) store_packed(wt, p4h, p2h, true);
         }
         v16i accA[2], accB[2];                                  // channel 0's / channel 1's accumulators
 #pragma unroll
@@ -521,12 +533,16 @@ __global__ __launch_bounds__(D2D_M3_THREADS) void d2d_fir_mfma3_kernel(Mfma2Args
         for (; wt < t_end; wt += wstride) {
             const bool more = wt + wstride < t_end;
             const uint32_t nxt = more ? wt + wstride : wt;
+            u32x4 p4l[2], p2l[2];
+            auto& p4 = AF ? p4h : p4l;
+            auto& p2 = AF ? p2h : p2l;
             // ---- region A: channel 0's chain of tile wt, channel 1's epilogue of tile pw ----
             stamp(2);
             wave_sync2();
             if (!(dbg & 4)) {
                 write_lds(C0{});
-                if (AF || more) issue_loads(nxt, C0{}, af);
+                if constexpr (NPFSET == 2) { if (AF || more) issue_loads(nxt, C0{}, af); }
+                else issue_loads(wt, C1{}, af);
             }
             wave_sync2();
             stamp(0);
@@ -548,7 +564,7 @@ __global__ __launch_bounds__(D2D_M3_THREADS) void d2d_fir_mfma3_kernel(Mfma2Args
             wave_sync2();
             if (!(dbg & 4)) {
                 write_lds(C1{});
-                if (AF || more) issue_loads(nxt, C1{}, af);
+                if (AF || more) { if constexpr (NPFSET == 2) issue_loads(nxt, C1{}, af); else issue_loads(nxt, C0{}, af); }
             }
             if constexpr (AF) store_packed(pw, p4, p2, true);
             else if (have_prev) store_packed(pw, p4, p2);
@@ -574,8 +590,8 @@ __global__ __launch_bounds__(D2D_M3_THREADS) void d2d_fir_mfma3_kernel(Mfma2Args
             fast_begin(f, pw, 1);
             static_for<0, NJ>([&](auto jc) { fast_job(f, accB[0], accB[1], jc); });
             if (fast_failed(f, pw)) redo(1u, pw, 1, f.res); else merge_extremes(f, 1);
-            pack_tile(pw, held, f.res, p4, p2);
-            store_packed(pw, p4, p2);
+            pack_tile(pw, held, f.res, p4h, p2h);
+            store_packed(pw, p4h, p2h);
         }
     };
     // One tile the careful way, start to finish (call edges: the window reaches into the carried history or past the call's full
@@ -583,8 +599,9 @@ __global__ __launch_bounds__(D2D_M3_THREADS) void d2d_fir_mfma3_kernel(Mfma2Args
     auto slow_tile = [&](uint32_t t) {
         wave_sync2();
         issue_loads(t, C0{}, std::false_type{});
-        issue_loads(t, C1{}, std::false_type{});
+        if constexpr (NPFSET == 2) issue_loads(t, C1{}, std::false_type{});
         write_lds(C0{});
+        if constexpr (NPFSET == 1) issue_loads(t, C1{}, std::false_type{});
         write_lds(C1{});
         wave_sync2();
         int32_t o0[8], o1[8];
@@ -594,7 +611,7 @@ __global__ __launch_bounds__(D2D_M3_THREADS) void d2d_fir_mfma3_kernel(Mfma2Args
         pack_tile(t, o0, o1, p4, p2);
         store_packed(t, p4, p2);
     };
-    if (fast_layout) {
+    if (fast_layout && MB < 8) {       // (M = 64: the general loop is faster there, 3.01 against 3.18 ms)
         // the tiles [t_lo, t_hi) lie inside the call's full blocks: the loop without the gather path; the few around them one by one
         const int64_t T = (int64_t)M2_TILE * MB;
         auto is_fast = [&](uint32_t w) { const int32_t ab = tile_ab16(w); return ab >= 0 && (uint32_t)ab + 16u * NCHK <= full_bytes; };
