@@ -45,6 +45,8 @@ WORKLOADS = {
     "dsd64_to_88k2_s24_stereo_nodither": (1, 88200, 24, "X", 2, 32 / 8 + 3),
     "dsd64_to_88k2_s16_stereo": (1, 88200, 16, "T", 2, 32 / 8 + 2),
     "dsd64_to_88k2_f32_stereo": (1, 88200, 32, "X", 2, 32 / 8 + 4),
+    "dsd64_to_176k4_s24_stereo": (1, 176400, 24, "T", 2, 16 / 8 + 3),
+    "dsd64_to_352k8_s24_stereo": (1, 352800, 24, "T", 2, 8 / 8 + 3),
     "dsd64_to_352k8_f32_stereo": (1, 352800, 32, "X", 2, 8 / 8 + 4),
     "dsd128_to_88k2_s24_stereo": (2, 88200, 24, "T", 2, 64 / 8 + 3),
     "dsd128_to_88k2_s24_stereo_ns": (2, 88200, 24, "N", 2, 64 / 8 + 3),   # BASELINE config 3's noise-shaped variant (an extension)

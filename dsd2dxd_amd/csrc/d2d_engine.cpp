@@ -242,6 +242,12 @@ int d2d_create(const d2d_params* params, uint32_t n_files, d2d_engine** out) {
             mfma2_smem_bytes(e->M, e->N, e->C, e->epi.sample_bytes, &w2) <= 160 * 1024 && w2 >= 4) {
             e->mfma_v2 = true; mfma_ok = true; mfma_waves = w2;
         }
+        // M = 8 and 16: the two-group geometry only through the pipelined kernel (stereo 16/24-bit/float frames at 0 dB); every other
+        // format of those rates stays on the one-group kernel
+        if (!(v1 && atoi(v1)) && !e->mfma_v2 && e->M < 32 && e->p.kernel != D2D_KERNEL_LUT) {
+            FirArgs a{}; fir_args_static(e, a);
+            if (mfma2_pipelined(a, e->M, e->N)) { e->mfma_v2 = true; mfma_ok = true; mfma_waves = 8; }
+        }
     }
     // AUTO: the matrix-core kernel whenever a full 4-wave block fits in LDS (it works per channel pair,
     // so only an extremely long window can fail this; then the LUT kernel)

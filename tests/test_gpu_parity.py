@@ -259,7 +259,8 @@ def test_noise_shaped_segments_restart_and_carry(engine_lib, oracle_mod, kernel)
 
 @pytest.mark.parametrize("sparse,bits", [(0, 24), (1, 24), (0, 16), (0, 32)], ids=["dense_chain", "sparse_chain", "dense_chain_16bit", "dense_chain_float"])
 @pytest.mark.parametrize("dither", ["T", "R", "X"])
-@pytest.mark.parametrize("dsd_rate,out_rate,filt", [(1, 88200, "E"), (1, 88200, "X"), (2, 88200, "E"), (2, 176400, "C"), (4, 176400, "E")])
+@pytest.mark.parametrize("dsd_rate,out_rate,filt", [(1, 88200, "E"), (1, 88200, "X"), (2, 88200, "E"), (2, 176400, "C"), (4, 176400, "E"),
+                                                    (1, 176400, "E"), (1, 352800, "E")])
 def test_pipelined_stereo_kernel_fast_and_careful_tiles(engine_lib, oracle_mod, monkeypatch, dsd_rate, out_rate, filt, dither, sparse, bits):
     """Stereo 24-bit (and 16-bit, and float without the float dither) at 0 dB runs d2d_fir_mfma3_kernel: the requantiser rides on the next chain in its branch-free form and a
     tile that could clip, holds an exact rounding tie or is cut short by the end of the call is redone sample by sample.
@@ -267,8 +268,10 @@ def test_pipelined_stereo_kernel_fast_and_careful_tiles(engine_lib, oracle_mod, 
     call exercise those paths (an exact tie under triangular dither is a 2^-16 event per sample: likely here, certain in
     tests/test_gpu_fullsize.py).  D2D_SPARSE=1 swaps the kernel's dense MFMA chain for the structured-sparse one
     (v_smfmac_i32_32x32x64_i8, its own tap tables): same results."""
-    if sparse and filt != "E":
-        pytest.skip("the sparse chain is compiled for the E filters only")
+    if sparse and (filt != "E" or out_rate // dsd_rate > 88200):
+        pytest.skip("the sparse chain is compiled for the E filters at M = 32 and 64 only")
+    if bits == 32 and out_rate // dsd_rate == 352800:
+        pytest.skip("M = 8 float frames stay on the one-group kernel")
     monkeypatch.setenv("D2D_SPARSE", str(sparse))
     rng = np.random.default_rng(5)
     nbytes = 4096 * 40 * dsd_rate
