@@ -664,8 +664,8 @@ __global__ __launch_bounds__(D2D_M3_THREADS) void d2d_fir_mfma3_kernel(Mfma2Args
 #ifdef D2D_M2_DEV
 #define D2D_M3_SHAPES(X) X(4, 13, 560)
 #else
-// (the M = 8 and 16 shapes -- E filters -- are served by this kernel only: the two-group kernel loses to the one-group one there)
-#define D2D_M3_SHAPES(X) X(1, 4, 144) X(2, 7, 288) X(4, 10, 384) X(4, 12, 512) X(4, 13, 560) X(8, 24, 1024) X(8, 25, 1104)
+// (the M = 8 and 16 shapes are served by this kernel only: the two-group kernel loses to the one-group one there)
+#define D2D_M3_SHAPES(X) X(1, 3, 96) X(1, 4, 144) X(2, 6, 192) X(2, 7, 256) X(2, 7, 288) X(4, 10, 384) X(4, 12, 512) X(4, 13, 560) X(8, 24, 1024) X(8, 25, 1104)
 #endif
 
 #if D2D_M3_PART == 0

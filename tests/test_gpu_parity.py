@@ -260,7 +260,7 @@ def test_noise_shaped_segments_restart_and_carry(engine_lib, oracle_mod, kernel)
 @pytest.mark.parametrize("sparse,bits", [(0, 24), (1, 24), (0, 16), (0, 32)], ids=["dense_chain", "sparse_chain", "dense_chain_16bit", "dense_chain_float"])
 @pytest.mark.parametrize("dither", ["T", "R", "X"])
 @pytest.mark.parametrize("dsd_rate,out_rate,filt", [(1, 88200, "E"), (1, 88200, "X"), (2, 88200, "E"), (2, 176400, "C"), (4, 176400, "E"),
-                                                    (1, 176400, "E"), (1, 352800, "E")])
+                                                    (1, 176400, "E"), (1, 352800, "E"), (1, 176400, "X"), (2, 352800, "C"), (1, 352800, "D")])
 def test_pipelined_stereo_kernel_fast_and_careful_tiles(engine_lib, oracle_mod, monkeypatch, dsd_rate, out_rate, filt, dither, sparse, bits):
     """Stereo 24-bit (and 16-bit, and float without the float dither) at 0 dB runs d2d_fir_mfma3_kernel: the requantiser rides on the next chain in its branch-free form and a
     tile that could clip, holds an exact rounding tie or is cut short by the end of the call is redone sample by sample.
