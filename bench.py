@@ -43,6 +43,7 @@ WORKLOADS = {
     # name: (dsd_rate, out_rate, bit_depth, dither, channels, algorithmic bytes per output sample)
     "dsd64_to_88k2_s24_stereo": (1, 88200, 24, "T", 2, 32 / 8 + 3),
     "dsd64_to_88k2_s24_stereo_nodither": (1, 88200, 24, "X", 2, 32 / 8 + 3),
+    "dsd64_to_88k2_s24_6ch": (1, 88200, 24, "T", 6, 32 / 8 + 3),          # a 5.1 stream, planar
     "dsd64_to_88k2_s16_stereo": (1, 88200, 16, "T", 2, 32 / 8 + 2),
     "dsd64_to_88k2_f32_stereo": (1, 88200, 32, "X", 2, 32 / 8 + 4),
     "dsd64_to_176k4_s24_stereo": (1, 176400, 24, "T", 2, 16 / 8 + 3),
