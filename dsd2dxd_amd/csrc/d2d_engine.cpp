@@ -822,8 +822,9 @@ const char* d2d_kernel_name(const d2d_engine* e) {
         d2d_engine* m = const_cast<d2d_engine*>(e);
         if (e->mfma_pipe) {
             const int kind = e->epi.dither == 'T' ? 1 : e->epi.dither == 'R' ? 2 : 0;
+            const bool scr = e->fc.resamp || e->noise_shape;
             m->kname = "d2d_fir_mfma3_kernel<" + std::to_string(e->Mb) + ", " + std::to_string(mfma2_pairs(e->M, e->N)) + ", " +
-                       std::to_string(e->mfma_pipe == 4 ? e->N : 0) + ", " + std::to_string(kind) + ", " + std::to_string(e->epi.sample_bytes) + ">";
+                       std::to_string(e->mfma_pipe == 4 ? e->N : 0) + ", " + std::to_string(scr ? 0 : kind) + ", " + std::to_string(scr ? 0u : e->epi.sample_bytes) + ">";
             return m->kname.c_str();
         }
         m->kname = "d2d_fir_mfma2_kernel<" + std::to_string(e->Mb) + ", " + std::to_string(mfma2_pairs(e->M, e->N)) + ", " +

@@ -698,6 +698,9 @@ static int mfma2_epilogue(const FirArgs& a, const Mfma2Args& m) {
 // from -2^(S-18) in the limb-3 rows
 static bool mfma3_eligible(const FirArgs& a, const Mfma2Args& m, int MB, int NPG, int NT) {
     // stereo, 24-bit packed or 16-bit frames, the all-integer requantiser (unit gain)
+    // the exact integers for the stage-A scratch: every channel pair of an even channel count
+    if (a.to_scratch) return a.epi.channels >= 2 && a.epi.channels % 2 == 0 && !m.wide && a.scale_bits >= 18 && a.scale_bits <= 30 &&
+                             a.sum_abs_q != 0 && a.sum_abs_q < (1ull << 31) && mfma3_scr_supported(MB, NPG);
     const bool frames_ok = !a.to_scratch && a.epi.channels == 2 && (a.epi.sample_bytes == 3 || a.epi.sample_bytes == 2) && m.qsh == 0 && !m.wide;
     const bool shape_ok = a.scale_bits >= 18 && a.scale_bits <= 30 && mfma3_supported(MB, NPG, NT);
     // ... or 32-bit float at 0 dB without the float dither: the sample is (float)v * 2^-S
@@ -717,13 +720,13 @@ int mfma2_pipelined(const FirArgs& a, int M, int N) {
     const char* sparse = getenv("D2D_SPARSE");
     if (nopipe && atoi(nopipe)) return 0;
     const int MB = M / 8, NPG = mfma2_pairs(M, N);
-    if (!mfma2_supported(M, N) && !mfma3_supported(MB, NPG, N)) return 0;
+    if (!mfma2_supported(M, N) && !mfma3_supported(MB, NPG, N) && !(a.to_scratch && mfma3_scr_supported(MB, NPG))) return 0;
     Mfma2Args m{}; size_t smem = 0;
     mfma2_geometry(a, MB, NPG, m, smem);
     if (!mfma3_eligible(a, m, MB, NPG, N)) return 0;
     // the structured-sparse chain issues 27 % fewer MFMAs but 8 % more vector instructions, and the kernel is bound by vector issue:
     // measured 4-7 % slower than the dense chain; kept selectable (D2D_SPARSE=1), exact and tested
-    return sparse && atoi(sparse) && a.epi.sample_bytes == 3 && mfma3_sparse_compiled(MB, N) ? 4 : 3;
+    return sparse && atoi(sparse) && !a.to_scratch && a.epi.sample_bytes == 3 && mfma3_sparse_compiled(MB, N) ? 4 : 3;
 }
 
 static void mfma2_geometry(const FirArgs& a, int MB, int NPG, Mfma2Args& m, size_t& smem) {

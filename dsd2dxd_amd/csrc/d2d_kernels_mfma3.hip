@@ -95,7 +95,7 @@ __global__ __launch_bounds__(D2D_M3_THREADS) void d2d_fir_mfma3_kernel(Mfma2Args
     using G = M2Geom<MB>;
     constexpr int RS = G::RS, LSH = G::LSH;
     constexpr bool SP = NT > 0;
-    constexpr uint32_t FB = 2u * SBY;                               // bytes per stereo frame
+    constexpr uint32_t FB = 2u * (SBY ? SBY : 1);                   // bytes per stereo frame
     constexpr int TP = SP ? m4_nst(MB, NT) : NPG + MB;              // steps of one chain
     constexpr int NCHK = SP ? m4_chunks(MB, NT) : m2_chunks(MB, NPG);
     constexpr int PF = SP ? m4_pf(MB, NT) : m2_pf(MB, NPG);
@@ -104,12 +104,15 @@ __global__ __launch_bounds__(D2D_M3_THREADS) void d2d_fir_mfma3_kernel(Mfma2Args
     const FirArgs& a = m.f;
     constexpr uint32_t dbg = D2D_M3_ABL;                  // compile-time ablation mask (tools/ab_build.sh <name> -DD2D_M3_ABL=<mask>): 1 no chain, 2 no epilogue, 4 no staging, 8 never slow, 16 zero taps, 64 no stores
     extern __shared__ __align__(16) unsigned char smem[];
-    const uint32_t Ct = a.in_channels;                     // channels of the file (input layout); both channels of the frame are converted
-    const uint32_t fidx = blockIdx.y;
+    constexpr bool SCR = SBY == 0;                          // the exact integers y * 2^S to the stage-A scratch (48k cascade, noise-shaping pass)
+    const uint32_t Ct = a.in_channels;                     // channels of the file (input layout)
+    // a block row = one file (stereo frames) or one channel PAIR of a file (SCR: any even channel count, each channel has its own scratch line)
+    const uint32_t fidx = SCR ? blockIdx.y / m.ngroups : blockIdx.y;
+    const uint32_t cbase = SCR ? (blockIdx.y - fidx * m.ngroups) * 2u : 0u;
     const uint32_t tid = threadIdx.x, lane = tid & 63;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     uint8_t* wbase = smem + m.off_waves + wave * m.wave_lds;       // [channel 0 stream buffer | channel 1 stream buffer]
-    const StreamJob* jobs = a.jobs + (size_t)fidx * 2;
+    const StreamJob* jobs = a.jobs + (size_t)fidx * (SCR ? a.epi.channels : 2u) + cbase;
     const StreamJob j0 = jobs[0];          // in, L, e0, n0, nout are common to a file's channels
 
     const int64_t first0 = j0.e0 - (int64_t)a.Wb;          // first byte of output 0's window
@@ -396,15 +399,16 @@ __global__ __launch_bounds__(D2D_M3_THREADS) void d2d_fir_mfma3_kernel(Mfma2Args
                 if constexpr (i & 1) f.tie = m3_min3_u16(f.tie, f.wprev, w); else f.wprev = w;
             } else if constexpr (KIND == 2) {
                 s = v + (int32_t)f.T[i];
-            } else if constexpr (SBY == 4) {
+            } else if constexpr (SBY == 4 || SCR) {
                 s = 0;
             } else {
                 s = v + kHalf + (v >> 31);                                                 // round half away from zero
             }
             if constexpr (SBY == 4) f.res[i] = __float_as_int((float)v * kFs);
+            else if constexpr (SCR) f.res[i] = v;
             else f.res[i] = s >> kF;
             asm volatile("" : "+v"(f.res[i]));         // keep the whole job on this step (the value is only used after the region)
-            if constexpr (i & 1) { f.tmn = m3_min3(f.tmn, f.vprev, v); f.tmx = m3_max3(f.tmx, f.vprev, v); } else f.vprev = v;
+            if constexpr (!SCR) { if constexpr (i & 1) { f.tmn = m3_min3(f.tmn, f.vprev, v); f.tmx = m3_max3(f.tmx, f.vprev, v); } else f.vprev = v; }
         }
     };
     // the jobs of step u: job j rides on step (j * TP) / NJ
@@ -419,7 +423,7 @@ __global__ __launch_bounds__(D2D_M3_THREADS) void d2d_fir_mfma3_kernel(Mfma2Args
     auto fast_failed = [&](const Fast& f, uint32_t tile) -> bool {
         const uint32_t first = (uint32_t)j0.n0 + tile * (uint32_t)M2_TILE;
         const bool full = tile * (uint32_t)M2_TILE + (uint32_t)M2_TILE <= j0.nout;
-        if (dbg & 8) return false;                          // (8: never take the slow path, for timing experiments)
+        if (SCR || (dbg & 8)) return false;                 // (SCR: the integers need no second look; 8: never take the slow path, for timing experiments)
         if (!full || first > 0xFFFFFFFFu - (uint32_t)M2_TILE) return true;
         if constexpr (SBY == 4) return false;                // float: nothing clips, nothing ties
         const bool bad = (KIND == 1 && (f.tie & 0xFFFFu) == 0) || f.tmx > kSafe || f.tmn < -kSafe;
@@ -497,6 +501,18 @@ __global__ __launch_bounds__(D2D_M3_THREADS) void d2d_fir_mfma3_kernel(Mfma2Args
             if constexpr (SBY == 4) *reinterpret_cast<D2D_GLOBAL u32x4*>(as_global(gout + 8 * FB * g + 16)) = p2[g];
         }
     };
+    // SCR: the lane's 2 x 4 consecutive integers of channel c go straight to that channel's scratch line
+    auto store_scr = [&](uint32_t tile, uint32_t c, const int32_t (&v)[8]) {
+        D2D_GLOBAL int32_t* xs = as_global(jobs[c].xs) + (size_t)tile * M2_TILE + lane_fr;
+        const uint32_t nl = tile * (uint32_t)M2_TILE + lane_fr;
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            if (nl + 8u * g + 3u < j0.nout) *reinterpret_cast<D2D_GLOBAL i32x4*>(xs + 8 * g) = i32x4{v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]};
+            else
+#pragma unroll
+                for (int k = 0; k < 4; ++k) if (nl + 8u * g + k < j0.nout) xs[8 * g + k] = v[4 * g + k];
+        }
+    };
     auto merge_extremes = [&](const Fast& f, uint32_t c) { vmn[c] = min(vmn[c], f.tmn); vmx[c] = max(vmx[c], f.tmx); };
 
     const uint32_t wv = blockIdx.x * m.nwaves + wave;       // this wave's index among the file's waves
@@ -555,8 +571,11 @@ __global__ __launch_bounds__(D2D_M3_THREADS) void d2d_fir_mfma3_kernel(Mfma2Args
                 if (D2D_M3_STAMPS) asm volatile("" :: "v"(accA[0]), "v"(accA[1]));
                 stamp(1);
                 if (have_prev) {
-                    if (!(dbg & 3) && fast_failed(f, pw)) redo(1u, pw, 1, f.res); else merge_extremes(f, 1);
-                    pack_tile(pw, held, f.res, p4, p2);
+                    if constexpr (SCR) store_scr(pw, 1, f.res);
+                    else {
+                        if (!(dbg & 3) && fast_failed(f, pw)) redo(1u, pw, 1, f.res); else merge_extremes(f, 1);
+                        pack_tile(pw, held, f.res, p4, p2);
+                    }
                 }
             }
             // ---- region B: channel 1's chain of tile wt, channel 0's epilogue of tile wt ----
@@ -567,7 +586,7 @@ __global__ __launch_bounds__(D2D_M3_THREADS) void d2d_fir_mfma3_kernel(Mfma2Args
                 if (AF || more) { if constexpr (NPFSET == 2) issue_loads(nxt, C1{}, af); else issue_loads(nxt, C0{}, af); }
             }
             if constexpr (AF) store_packed(pw, p4, p2, true);
-            else if (have_prev) store_packed(pw, p4, p2);
+            else if (have_prev && !SCR) store_packed(pw, p4, p2);
             wave_sync2();
             stamp(0);
             {
@@ -578,9 +597,12 @@ __global__ __launch_bounds__(D2D_M3_THREADS) void d2d_fir_mfma3_kernel(Mfma2Args
                 else chain(1u, accB[0], accB[1], [&](auto uc) { fast_hook(f, accA[0], accA[1], uc); });
                 if (D2D_M3_STAMPS) asm volatile("" :: "v"(accB[0]), "v"(accB[1]));
                 stamp(1);
-                if (!(dbg & 3) && fast_failed(f, wt)) redo(0u, wt, 0, f.res); else merge_extremes(f, 0);
+                if constexpr (SCR) store_scr(wt, 0, f.res);
+                else {
+                    if (!(dbg & 3) && fast_failed(f, wt)) redo(0u, wt, 0, f.res); else merge_extremes(f, 0);
 #pragma unroll
-                for (int i = 0; i < 8; ++i) held[i] = f.res[i];
+                    for (int i = 0; i < 8; ++i) held[i] = f.res[i];
+                }
             }
             have_prev = true; pw = wt;
         }
@@ -589,9 +611,12 @@ __global__ __launch_bounds__(D2D_M3_THREADS) void d2d_fir_mfma3_kernel(Mfma2Args
             Fast f;
             fast_begin(f, pw, 1);
             static_for<0, NJ>([&](auto jc) { fast_job(f, accB[0], accB[1], jc); });
-            if (fast_failed(f, pw)) redo(1u, pw, 1, f.res); else merge_extremes(f, 1);
-            pack_tile(pw, held, f.res, p4h, p2h);
-            store_packed(pw, p4h, p2h);
+            if constexpr (SCR) store_scr(pw, 1, f.res);
+            else {
+                if (fast_failed(f, pw)) redo(1u, pw, 1, f.res); else merge_extremes(f, 1);
+                pack_tile(pw, held, f.res, p4h, p2h);
+                store_packed(pw, p4h, p2h);
+            }
         }
     };
     // One tile the careful way, start to finish (call edges: the window reaches into the carried history or past the call's full
@@ -611,7 +636,7 @@ __global__ __launch_bounds__(D2D_M3_THREADS) void d2d_fir_mfma3_kernel(Mfma2Args
         pack_tile(t, o0, o1, p4, p2);
         store_packed(t, p4, p2);
     };
-    if (fast_layout && MB < 8) {       // (M = 64: the general loop is faster there, 3.01 against 3.18 ms)
+    if (fast_layout && MB < 8 && !SCR) {       // (M = 64: the general loop is faster there, 3.01 against 3.18 ms)
         // the tiles [t_lo, t_hi) lie inside the call's full blocks: the loop without the gather path; the few around them one by one
         const int64_t T = (int64_t)M2_TILE * MB;
         auto is_fast = [&](uint32_t w) { const int32_t ab = tile_ab16(w); return ab >= 0 && (uint32_t)ab + 16u * NCHK <= full_bytes; };
@@ -640,6 +665,7 @@ __global__ __launch_bounds__(D2D_M3_THREADS) void d2d_fir_mfma3_kernel(Mfma2Args
         atomicAdd(&d2d_m3_stamps[7], __builtin_amdgcn_s_memrealtime() - rt_start);      // constant 100 MHz: sum[2] / sum[7] = core clock / 100 MHz
     }
 #endif
+    if constexpr (SCR) return;                              // (stage B / the noise shaper keep the peaks)
     // peak meter: |x| in LSB; undo the power-of-two part exactly
     const double unscale = 1.0 / (double)(1u << (a.epi.bits - 1));   // (float: fbits = S - 31, so dev * 2^-fbits * 2^-31 = dev * 2^-S)
 #pragma unroll
@@ -669,6 +695,16 @@ __global__ __launch_bounds__(D2D_M3_THREADS) void d2d_fir_mfma3_kernel(Mfma2Args
 #endif
 
 #if D2D_M3_PART == 0
+// (MB, NPG) of every filter that can write the scratch: the 44.1k-family filters above (noise-shaping pass) and the stage-A filters of the
+// 48k cascade (A_M8 96 taps, A_M16 176, A_M32 352, A_M64 688)
+#define D2D_M3_SCR_SHAPES(X) X(1, 3) X(1, 4) X(2, 5) X(2, 6) X(2, 7) X(4, 10) X(4, 12) X(4, 13) X(8, 19) X(8, 24) X(8, 25)
+bool mfma3_scr_supported(int MB, int NPG) {
+#define X(mb, npg) if (MB == mb && NPG == npg) return true;
+    D2D_M3_SCR_SHAPES(X)
+#undef X
+    return false;
+}
+
 bool mfma3_supported(int MB, int NPG, int NT) {
 #define X(mb, npg, nt) if (MB == mb && NPG == npg && NT == nt) return true;
     D2D_M3_SHAPES(X)
@@ -770,6 +806,13 @@ static hipError_t launch_mfma3_t(Mfma2Args& m, uint32_t nwt_max, uint32_t nrows,
       if (m.dkind == 2) return launch_mfma3_t<mb, npg, nt, 2, sby>(m, nwt_max, nrows, s);              \
       return launch_mfma3_t<mb, npg, nt, 0, sby>(m, nwt_max, nrows, s); }
 #if D2D_M3_PART == 1
+#define D2D_M3_SCR_SHAPES(X) X(1, 3) X(1, 4) X(2, 5) X(2, 6) X(2, 7) X(4, 10) X(4, 12) X(4, 13) X(8, 19) X(8, 24) X(8, 25)
+hipError_t launch_fir_mfma3_scr(Mfma2Args& m, int MB, int NPG, uint32_t nwt_max, uint32_t nrows, hipStream_t s) {
+#define X(mb, npg) if (MB == mb && NPG == npg) return launch_mfma3_t<mb, npg, 0, 0, 0>(m, nwt_max, nrows, s);
+    D2D_M3_SCR_SHAPES(X)
+#undef X
+    return hipErrorInvalidValue;
+}
 hipError_t launch_fir_mfma3_s16(Mfma2Args& m, int MB, int NPG, int NT, uint32_t nwt_max, uint32_t nrows, hipStream_t s) {
     if (m.f.epi.sample_bytes == 4) {       // float: no dither (the float dither 'F' stays with the two-group kernel)
 #define X(mb, npg, nt) if (MB == mb && NPG == npg && NT == nt) return launch_mfma3_t<mb, npg, 0, 0, 4>(m, nwt_max, nrows, s);
@@ -784,8 +827,10 @@ hipError_t launch_fir_mfma3_s16(Mfma2Args& m, int MB, int NPG, int NT, uint32_t 
 }
 #else
 hipError_t launch_fir_mfma3_s16(Mfma2Args& m, int MB, int NPG, int NT, uint32_t nwt_max, uint32_t nrows, hipStream_t s);
+hipError_t launch_fir_mfma3_scr(Mfma2Args& m, int MB, int NPG, uint32_t nwt_max, uint32_t nrows, hipStream_t s);
 // variant 3: the dense chain, 4: the structured-sparse chain (24-bit frames only)
 hipError_t launch_fir_mfma3(Mfma2Args& m, int variant, int MB, int NPG, int NT, uint32_t nwt_max, uint32_t nrows, hipStream_t s) {
+    if (m.f.to_scratch) return launch_fir_mfma3_scr(m, MB, NPG, nwt_max, nrows, s);
     if (m.f.epi.sample_bytes != 3) return launch_fir_mfma3_s16(m, MB, NPG, NT, nwt_max, nrows, s);     // 16-bit and float frames: part 1
     if (variant == 4) {          // the sparse chain is an experiment: compiled for the E filters only
         if (MB == 4 && NT == 560) K3(4, 13, 560, 3)

@@ -89,5 +89,6 @@ static __device__ __noinline__ u32x4 gather_chunk(const StreamJob* job, uint32_t
 hipError_t launch_fir_mfma3(Mfma2Args& m, int variant, int MB, int NPG, int NT, uint32_t nwt_max, uint32_t nrows, hipStream_t s);
 bool mfma3_supported(int MB, int NPG, int NT);
 bool mfma3_sparse_compiled(int MB, int NT);
+bool mfma3_scr_supported(int MB, int NPG);
 
 }  // namespace d2d
