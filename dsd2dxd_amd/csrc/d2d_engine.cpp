@@ -475,6 +475,7 @@ int d2d_translate_batch_device(d2d_engine* e, d2d_file_io* io, uint32_t n_files,
         NoiseShapeArgs ns{};
         ns.jobs = e->d_jobs; ns.state = e->d_ns[e->ns_cur]; ns.state_next = e->d_ns[e->ns_cur ^ 1];
         ns.scale_bits = e->S; ns.nstreams = e->nstreams; ns.max_nout = max_nx; ns.epi = e->epi;
+        { static const char* noint = getenv("D2D_NO_INTQ"); FirArgs fa{}; fir_args_static(e, fa); ns.intq = (!noint && fa.sum_abs_q + (1ull << 24) < (1ull << 31)) ? 1u : 0u; }
         // a stream whose call ends exactly on a segment boundary, or feeds nothing, writes no state: start the next buffer from the current one
         HIPCHK(e, hipMemcpyAsync(e->d_ns[e->ns_cur ^ 1], e->d_ns[e->ns_cur], sizeof(double) * 2 * e->nstreams, hipMemcpyDeviceToDevice, s));
         HIPCHK(e, launch_noise_shape(ns, s));

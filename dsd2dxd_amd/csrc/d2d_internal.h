@@ -73,6 +73,7 @@ struct NoiseShapeArgs {
     uint32_t nstreams;
     uint32_t max_nout;         // the longest stream's outputs this call (sizes the grid)
     uint32_t cp_bits;          // log2(channels rounded up to a power of two): filled by the launcher
+    uint32_t intq;             // 1: |y * 2^S| + a few LSB stay inside int32 (the engine checks the tap table): the all-integer loop may run at unit gain
     Epilogue epi;
 };
 

@@ -474,6 +474,170 @@ __global__ __launch_bounds__(256) void d2d_noise_shape_kernel(NoiseShapeArgs a) 
     if (active && pk > 0.0) atomicMax(reinterpret_cast<unsigned long long*>(job.peak), (unsigned long long)__double_as_longlong(pk));
 }
 
+
+// The same pass for STEREO frames of 16 or 24 bits (every configuration the bench names), built for the fact that it is bound by
+// the instruction stream of single waves (a 64-file batch has 83 k chains: 1.3 waves per SIMD; PMC: 42 vector + 12 scalar + 4 LDS
+// + 4 branch instructions per step in the general kernel above).  No LDS and no wave-level fences: the two channel lanes of a
+// segment sit side by side, the left lane takes the right one's sample with one DPP move, packs whole frames with v_perm_b32 and
+// stores a group's 48 (32) bytes itself -- one trip LATER, after the next group's integers have been requested, so that the wait
+// for those never sits behind a fresh store.  Whole groups run without a test per step.  INTQ (unit gain): the recurrence in
+// int32 -- x = v * 2^-F LSB, the dither has 16 fraction bits and the errors F, so every quantity of the loop is an exact
+// fixed-point number and the f64 operations of the definition never round: same results.
+template <int SB, bool INTQ>
+__global__ __launch_bounds__(256) void d2d_noise_shape_stereo_kernel(NoiseShapeArgs a) {
+    constexpr uint32_t FBY = 2u * SB;                                      // bytes per frame
+    constexpr int NW = NS_FRAMES * FBY / 4;                                // dwords per group of eight frames: 12 (24-bit) or 8 (16-bit)
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t ch = lane & 1u, sw = lane >> 1;                         // channel, segment slot inside the wave
+    const uint32_t file = blockIdx.y;
+    const StreamJob* jobs = a.jobs + (size_t)file * 2;
+    const StreamJob j0 = jobs[0];                                          // n0, nout, out are common to a file's channels
+    if (j0.nout == 0) return;
+    const uint64_t n_end = j0.n0 + j0.nout;
+    const uint64_t k0 = j0.n0 >> NS_SEG_BITS, k1 = (n_end - 1) >> NS_SEG_BITS;
+    const uint64_t k = k0 + (uint64_t)(blockIdx.x * (blockDim.x >> 6) + wave) * 32u + sw;
+    const bool active = k <= k1;
+    const uint64_t seg_lo = k << NS_SEG_BITS, seg_hi = (k + 1) << NS_SEG_BITS;
+    const uint32_t i0 = active ? (seg_lo > j0.n0 ? (uint32_t)(seg_lo - j0.n0) : 0u) : 0u;
+    const uint32_t i1 = active ? (uint32_t)((seg_hi < n_end ? seg_hi : n_end) - j0.n0) : 0u;
+    const StreamJob job = jobs[ch];
+    const D2D_GLOBAL int32_t* xs = as_global(job.xs);
+    const uint32_t sidx = file * 2 + ch;
+    const bool carried = active && seg_lo < j0.n0;                         // begun in an earlier call
+    double e1 = carried ? a.state[2 * sidx] : 0.0, e2 = carried ? a.state[2 * sidx + 1] : 0.0;
+    const int F = a.scale_bits - ((int)a.epi.bits - 1);                    // INTQ: fraction bits of x, 1..16
+    const uint32_t kSh = 16u - (uint32_t)(INTQ ? F : 8);
+    int32_t E1 = INTQ ? (int32_t)ldexp(e1, F) : 0, E2 = INTQ ? (int32_t)ldexp(e2, F) : 0;      // the errors scaled by 2^F (exact)
+    const int32_t qmin_i = -(1 << (a.epi.bits - 1)), qmax_i = (1 << (a.epi.bits - 1)) - 1;
+    const double lim = (double)(1u << (a.epi.bits - 1));
+    const double xscale = ldexp(a.epi.scale, -a.scale_bits);
+    uint32_t vmax = 0;                                                     // max |y * 2^S|: the peak, scaled back at the end
+    uint8_t* gout = reinterpret_cast<uint8_t*>(j0.out);
+    // the dither counter: lo32(n0 + i) + key, + kstep past the wrap of lo32 (at most once per call; tested per group)
+    const uint32_t zbase = (uint32_t)job.n0 + job.rng_key;
+    uint32_t len = i1 - i0;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) len = max(len, (uint32_t)__shfl_xor((int)len, o));
+    uint32_t len_full = active ? ((i1 - i0) / NS_FRAMES) * NS_FRAMES : 0xFFFFFFF8u;     // steps in whole groups: the minimum over the active lanes
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) len_full = min(len_full, (uint32_t)__shfl_xor((int)len_full, o));
+
+    auto fetch = [&](uint32_t ib, int32_t (&v)[NS_FRAMES]) {
+        if (active && ib + NS_FRAMES <= i1) {
+            typedef int32_t i32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
+            const i32x4_a4 lo4 = *reinterpret_cast<D2D_GLOBAL const i32x4_a4*>(xs + ib), hi4 = *reinterpret_cast<D2D_GLOBAL const i32x4_a4*>(xs + ib + 4);
+            v[0] = lo4.x; v[1] = lo4.y; v[2] = lo4.z; v[3] = lo4.w; v[4] = hi4.x; v[5] = hi4.y; v[6] = hi4.z; v[7] = hi4.w;
+        } else {
+#pragma unroll
+            for (uint32_t u = 0; u < NS_FRAMES; ++u) v[u] = (active && ib + u < i1) ? xs[ib + u] : 0;
+        }
+    };
+    // a group's packed frames (left lanes), stored one trip later
+    uint32_t pk[NW];
+    uint32_t pk_ib = 0, pk_n = 0;                                          // its first frame and how many of the eight exist
+    auto flush = [&]() {
+        if (ch == 0 && pk_n) {
+            uint8_t* g = gout + (size_t)pk_ib * FBY;                       // 4-byte aligned: a group starts on an even frame
+            if (pk_n == NS_FRAMES) {
+                typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
+#pragma unroll
+                for (int w = 0; w < NW; w += 4)
+                    *reinterpret_cast<D2D_GLOBAL u32x4_a4*>(as_global(g + 4 * w)) = u32x4_a4{pk[w], pk[w + 1], pk[w + 2], pk[w + 3]};
+            } else {
+                for (uint32_t b = 0; b < pk_n * FBY; b += 2) {
+                    uint32_t wv = 0;
+#pragma unroll
+                    for (int w = 0; w < NW; ++w) wv = (b >> 2) == (uint32_t)w ? pk[w] : wv;
+                    *reinterpret_cast<D2D_GLOBAL uint16_t*>(as_global(g + b)) = (uint16_t)(wv >> (8 * (b & 2)));
+                }
+            }
+        }
+    };
+    int32_t vn[NS_FRAMES];
+    fetch(i0, vn);
+    for (uint32_t t0 = 0; t0 < len; t0 += NS_FRAMES) {
+        int32_t v[NS_FRAMES], r8[NS_FRAMES];
+        const uint32_t ib = i0 + t0;
+#pragma unroll
+        for (uint32_t u = 0; u < NS_FRAMES; ++u) v[u] = vn[u];
+        flush();                                                           // the group before
+        if (t0 + NS_FRAMES < len) fetch(ib + NS_FRAMES, vn);
+        // this group's dither counter; the general form where lo32 wraps inside the group
+        const uint32_t lo = (uint32_t)job.n0 + ib;
+        const bool plain = lo + NS_FRAMES >= lo && (lo >= job.rng_lo0) == (lo + NS_FRAMES - 1 >= job.rng_lo0);
+        const uint32_t zg = zbase + ib + (lo < job.rng_lo0 ? job.rng_kstep : 0u);
+        auto step = [&](uint32_t u) {
+            vmax = max(vmax, (uint32_t)(v[u] < 0 ? -v[u] : v[u]));
+            uint32_t z = zg + u;
+            if (!plain) { const uint32_t l = lo + u; z = l + job.rng_key + (l < job.rng_lo0 ? job.rng_kstep : 0u); }
+            z ^= z >> 16; z *= 0x7feb352dU;
+            z ^= z >> 15; z *= 0x846ca68bU;
+            z ^= z >> 16;
+            int32_t iv;
+            if constexpr (INTQ) {
+                // w = x - (2 e1 - e2), q = w + d, r = round half away (q), e = r - w: W, E in units of 2^-F LSB, T in 2^-16
+                const int32_t W = v[u] - (2 * E1 - E2);
+                const int32_t T = (int32_t)((z & 0xFFFFu) + (z >> 16)) - 32767;             // (d + 1/2) * 2^16
+                int32_t r = (W + (T >> kSh)) >> F;                                          // floor(q + 1/2)
+                const bool tie = ((((uint32_t)W << kSh) + (uint32_t)T) & 0xFFFFu) == 0;    // q + 1/2 an integer: then q = r - 1/2
+                r -= (tie && r <= 0) ? 1 : 0;                                               // ... and a negative q rounds away from zero
+                E2 = E1;
+                E1 = (int32_t)((uint32_t)r << F) - W;
+                iv = min(max(r, qmin_i), qmax_i);
+            } else {
+                // y = v * 2^-S is exact and x = y * scale rounds once: v * (scale * 2^-S) is the same product, rounded the same
+                const double x = (double)v[u] * xscale;
+                const double d = (double)((z & 0xFFFFu) + (z >> 16) + 1u) * 0x1p-16 - 1.0;
+                const double fbk = 2.0 * e1 - e2;
+                const double w = x - fbk;
+                const double q = w + d;
+                const double r = trunc(q + copysign(0.5, q));
+                e2 = e1;
+                e1 = r - w;
+                iv = (int32_t)fmax(fmin(r, lim - 1.0), -lim);
+            }
+            r8[u] = iv;
+        };
+        if (t0 + NS_FRAMES <= len_full) {
+#pragma unroll
+            for (uint32_t u = 0; u < NS_FRAMES; ++u) step(u);
+        } else {
+#pragma unroll
+            for (uint32_t u = 0; u < NS_FRAMES; ++u) { r8[u] = 0; if (active && ib + u < i1) step(u); }
+        }
+        // the right channel's samples come over from the neighbouring lane; the left lane packs the frames
+        uint32_t L[NS_FRAMES], R[NS_FRAMES];
+#pragma unroll
+        for (uint32_t u = 0; u < NS_FRAMES; ++u) {
+            L[u] = (uint32_t)r8[u];
+            R[u] = (uint32_t)__builtin_amdgcn_mov_dpp(r8[u], 0xF5, 0xF, 0xF, true);     // quad_perm [1,1,3,3]: every even lane reads its right neighbour
+        }
+        if constexpr (SB == 3) {
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                // frames k, k+1 -> 12 bytes: [L0 L1 L2 R0 | R1 R2 L0' L1' | L2' R0' R1' R2']
+                const uint32_t La = L[4 * g], Ra = R[4 * g], Lb = L[4 * g + 1], Rb = R[4 * g + 1];
+                const uint32_t Lc = L[4 * g + 2], Rc = R[4 * g + 2], Ld = L[4 * g + 3], Rd = R[4 * g + 3];
+                pk[6 * g + 0] = __builtin_amdgcn_perm(Ra, La, 0x04020100u); pk[6 * g + 1] = __builtin_amdgcn_perm(Lb, Ra, 0x05040201u);
+                pk[6 * g + 2] = __builtin_amdgcn_perm(Rb, Lb, 0x06050402u); pk[6 * g + 3] = __builtin_amdgcn_perm(Rc, Lc, 0x04020100u);
+                pk[6 * g + 4] = __builtin_amdgcn_perm(Ld, Rc, 0x05040201u); pk[6 * g + 5] = __builtin_amdgcn_perm(Rd, Ld, 0x06050402u);
+            }
+        } else {
+#pragma unroll
+            for (uint32_t u = 0; u < NS_FRAMES; ++u) pk[u] = __builtin_amdgcn_perm(R[u], L[u], 0x05040100u);
+        }
+        pk_ib = ib;
+        pk_n = active && ib < i1 ? min(NS_FRAMES, i1 - ib) : 0u;
+    }
+    flush();
+    // the open segment's state travels on -- into the OTHER state buffer: the lane that reads a stream's carried state and
+    // the lane that writes its new one may sit in different blocks
+    if (INTQ) { e1 = ldexp((double)E1, -F); e2 = ldexp((double)E2, -F); }
+    if (active && k == k1) { a.state_next[2 * sidx] = e1; a.state_next[2 * sidx + 1] = e2; }
+    const double pkv = fabs(ldexp((double)vmax, -a.scale_bits) * a.epi.gain);          // |y * gain| is monotonic in |y|
+    if (active && pkv > 0.0) atomicMax(reinterpret_cast<unsigned long long*>(job.peak), (unsigned long long)__double_as_longlong(pkv));
+}
+
 // new_hist[j] = stream byte (L - keep + j), j in [0, keep)
 __global__ void d2d_history_kernel(const StreamJob* jobs, uint32_t C, uint32_t B, uint32_t keep) {
     const StreamJob job = jobs[blockIdx.x];
@@ -600,6 +764,20 @@ hipError_t launch_noise_shape(const NoiseShapeArgs& a0, hipStream_t s) {
     const uint32_t fb = a.epi.sample_bytes * C;
     const size_t smem = (size_t)waves * spw * (NS_FRAMES * fb + 4);
     const uint32_t nfiles = a.nstreams / C;
+    static const char* gen = getenv("D2D_NS_GENERAL");                          // diagnostic: the general kernel for stereo too
+    if (C == 2 && (a.epi.bits == 16 || a.epi.bits == 24) && !(gen && atoi(gen))) {
+        const int F = a.scale_bits - ((int)a.epi.bits - 1);
+        const bool intq = a.intq && a.epi.gain == 1.0 && F >= 1 && F <= 16;
+        const dim3 grid((max_seg + waves * 32 - 1) / (waves * 32), nfiles);
+        if (a.epi.bits == 24) {
+            if (intq) hipLaunchKernelGGL((d2d_noise_shape_stereo_kernel<3, true>), grid, dim3(64 * waves), 0, s, a);
+            else hipLaunchKernelGGL((d2d_noise_shape_stereo_kernel<3, false>), grid, dim3(64 * waves), 0, s, a);
+        } else {
+            if (intq) hipLaunchKernelGGL((d2d_noise_shape_stereo_kernel<2, true>), grid, dim3(64 * waves), 0, s, a);
+            else hipLaunchKernelGGL((d2d_noise_shape_stereo_kernel<2, false>), grid, dim3(64 * waves), 0, s, a);
+        }
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(d2d_noise_shape_kernel, dim3((max_seg + waves * spw - 1) / (waves * spw), nfiles), dim3(64 * waves), smem, s, a);
     return hipGetLastError();
 }
