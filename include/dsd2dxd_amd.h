@@ -45,7 +45,7 @@ enum { D2D_DITHER_TPDF = 'T', D2D_DITHER_RECT = 'R', D2D_DITHER_FPD = 'F', D2D_D
        /* extension (no counterpart in src/main.rs:171-181): TPDF dither inside a second-order error-feedback
         * loop, noise transfer function (1 - z^-1)^2; integer depths, 44.1 kHz-family output rates.  The loop is a
         * recurrence through a rounding; it restarts from zero error at every output index that is a multiple of
-        * 65536, so that those segments run side by side in a pass of their own. */
+        * 8192, so that those segments run side by side in a pass of their own. */
        D2D_DITHER_NOISE_SHAPED = 'N' };
 /* which device kernel evaluates the FIR (same numbers either way) */
 enum { D2D_KERNEL_AUTO = 0, D2D_KERNEL_LUT = 1, D2D_KERNEL_MFMA = 2 };
