@@ -515,53 +515,19 @@ __global__ __launch_bounds__(256) void d2d_noise_shape_stereo_kernel(NoiseShapeA
     uint8_t* gout = reinterpret_cast<uint8_t*>(j0.out);
     // the dither counter: lo32(n0 + i) + key, + kstep past the wrap of lo32 (at most once per call; tested per group)
     const uint32_t zbase = (uint32_t)job.n0 + job.rng_key;
-    uint32_t len = i1 - i0;
+    // Whole groups of eight frames first, in a loop whose memory operations are the same on every trip (two stores, two loads, no
+    // test in front of any of them): the compiler can then count how many younger requests may stay in flight when a group's integers
+    // are needed, and these are requested TWO groups ahead.  A lane whose segment is shorter than the longest of the wave (the call's
+    // first and last segments) keeps requesting its own last group and re-storing its own last frames -- harmless -- while the
+    // arithmetic is switched off for it.
+    const uint32_t my_ngrp = active ? (i1 - i0) / NS_FRAMES : 0u;
+    uint32_t ngrp_max = my_ngrp;
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) len = max(len, (uint32_t)__shfl_xor((int)len, o));
-    uint32_t len_full = active ? ((i1 - i0) / NS_FRAMES) * NS_FRAMES : 0xFFFFFFF8u;     // steps in whole groups: the minimum over the active lanes
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) len_full = min(len_full, (uint32_t)__shfl_xor((int)len_full, o));
+    for (int o = 32; o > 0; o >>= 1) ngrp_max = max(ngrp_max, (uint32_t)__shfl_xor((int)ngrp_max, o));
+    ngrp_max = __builtin_amdgcn_readfirstlane(ngrp_max);
 
-    auto fetch = [&](uint32_t ib, int32_t (&v)[NS_FRAMES]) {
-        if (active && ib + NS_FRAMES <= i1) {
-            typedef int32_t i32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
-            const i32x4_a4 lo4 = *reinterpret_cast<D2D_GLOBAL const i32x4_a4*>(xs + ib), hi4 = *reinterpret_cast<D2D_GLOBAL const i32x4_a4*>(xs + ib + 4);
-            v[0] = lo4.x; v[1] = lo4.y; v[2] = lo4.z; v[3] = lo4.w; v[4] = hi4.x; v[5] = hi4.y; v[6] = hi4.z; v[7] = hi4.w;
-        } else {
-#pragma unroll
-            for (uint32_t u = 0; u < NS_FRAMES; ++u) v[u] = (active && ib + u < i1) ? xs[ib + u] : 0;
-        }
-    };
-    // a group's packed frames (left lanes), stored one trip later
-    uint32_t pk[NW];
-    uint32_t pk_ib = 0, pk_n = 0;                                          // its first frame and how many of the eight exist
-    auto flush = [&]() {
-        if (ch == 0 && pk_n) {
-            uint8_t* g = gout + (size_t)pk_ib * FBY;                       // 4-byte aligned: a group starts on an even frame
-            if (pk_n == NS_FRAMES) {
-                typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
-#pragma unroll
-                for (int w = 0; w < NW; w += 4)
-                    *reinterpret_cast<D2D_GLOBAL u32x4_a4*>(as_global(g + 4 * w)) = u32x4_a4{pk[w], pk[w + 1], pk[w + 2], pk[w + 3]};
-            } else {
-                for (uint32_t b = 0; b < pk_n * FBY; b += 2) {
-                    uint32_t wv = 0;
-#pragma unroll
-                    for (int w = 0; w < NW; ++w) wv = (b >> 2) == (uint32_t)w ? pk[w] : wv;
-                    *reinterpret_cast<D2D_GLOBAL uint16_t*>(as_global(g + b)) = (uint16_t)(wv >> (8 * (b & 2)));
-                }
-            }
-        }
-    };
-    int32_t vn[NS_FRAMES];
-    fetch(i0, vn);
-    for (uint32_t t0 = 0; t0 < len; t0 += NS_FRAMES) {
-        int32_t v[NS_FRAMES], r8[NS_FRAMES];
-        const uint32_t ib = i0 + t0;
-#pragma unroll
-        for (uint32_t u = 0; u < NS_FRAMES; ++u) v[u] = vn[u];
-        flush();                                                           // the group before
-        if (t0 + NS_FRAMES < len) fetch(ib + NS_FRAMES, vn);
+    // eight steps of the loop on v[]; `checked`: only the steps below i1 (the segment's last, partial group)
+    auto steps8 = [&](uint32_t ib, const int32_t (&v)[NS_FRAMES], int32_t (&r8)[NS_FRAMES], auto checked) {
         // this group's dither counter; the general form where lo32 wraps inside the group
         const uint32_t lo = (uint32_t)job.n0 + ib;
         const bool plain = lo + NS_FRAMES >= lo && (lo >= job.rng_lo0) == (lo + NS_FRAMES - 1 >= job.rng_lo0);
@@ -598,14 +564,86 @@ __global__ __launch_bounds__(256) void d2d_noise_shape_stereo_kernel(NoiseShapeA
             }
             r8[u] = iv;
         };
-        if (t0 + NS_FRAMES <= len_full) {
 #pragma unroll
-            for (uint32_t u = 0; u < NS_FRAMES; ++u) step(u);
-        } else {
-#pragma unroll
-            for (uint32_t u = 0; u < NS_FRAMES; ++u) { r8[u] = 0; if (active && ib + u < i1) step(u); }
+        for (uint32_t u = 0; u < NS_FRAMES; ++u) {
+            if constexpr (decltype(checked)::value) { r8[u] = 0; if (ib + u < i1) step(u); } else step(u);
         }
-        // the right channel's samples come over from the neighbouring lane; the left lane packs the frames
+    };
+
+    typedef int32_t i32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
+    typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
+    typedef uint32_t u32x2_a4 __attribute__((ext_vector_type(2), aligned(4)));
+    constexpr int NH = NW / 2;                                             // each lane of the pair stores half of the group: frames 0-3 (left lane) or 4-7
+    uint32_t ph[NH];
+    uint32_t ph_ib = 0;
+    if (my_ngrp) {
+        auto load8 = [&](uint32_t g, int32_t (&v)[NS_FRAMES]) {           // the lane's group min(g, last): always inside its segment
+            const D2D_GLOBAL int32_t* p = xs + (i0 + NS_FRAMES * min(g, my_ngrp - 1u));
+            const i32x4_a4 lo4 = *reinterpret_cast<D2D_GLOBAL const i32x4_a4*>(p), hi4 = *reinterpret_cast<D2D_GLOBAL const i32x4_a4*>(p + 4);
+            v[0] = lo4.x; v[1] = lo4.y; v[2] = lo4.z; v[3] = lo4.w; v[4] = hi4.x; v[5] = hi4.y; v[6] = hi4.z; v[7] = hi4.w;
+        };
+        auto store_half = [&]() {
+            uint8_t* g = gout + (size_t)ph_ib * FBY + ch * (4u * NH);      // (4-byte aligned when the group starts on an even frame)
+            *reinterpret_cast<D2D_GLOBAL u32x4_a4*>(as_global(g)) = u32x4_a4{ph[0], ph[1], ph[2], ph[3]};
+            if constexpr (NH == 6) *reinterpret_cast<D2D_GLOBAL u32x2_a4*>(as_global(g + 16)) = u32x2_a4{ph[4], ph[5]};
+        };
+        auto process = [&](uint32_t g, const int32_t (&v)[NS_FRAMES]) {
+            const uint32_t ib = i0 + NS_FRAMES * g;
+            int32_t r8[NS_FRAMES];
+            steps8(ib, v, r8, std::false_type{});
+            // the pair's lanes swap samples (quad_perm [1,0,3,2]); frame j of this lane's half: A = left channel, B = right channel
+            uint32_t A[4], B[4];
+#pragma unroll
+            for (uint32_t j = 0; j < 4; ++j) {
+                const uint32_t nlo = (uint32_t)__builtin_amdgcn_mov_dpp(r8[j], 0xB1, 0xF, 0xF, true);
+                const uint32_t nhi = (uint32_t)__builtin_amdgcn_mov_dpp(r8[4 + j], 0xB1, 0xF, 0xF, true);
+                A[j] = ch ? nhi : (uint32_t)r8[j];
+                B[j] = ch ? (uint32_t)r8[4 + j] : nlo;
+            }
+            if constexpr (SB == 3) {
+                // frames k, k+1 -> 12 bytes: [L0 L1 L2 R0 | R1 R2 L0' L1' | L2' R0' R1' R2']
+                ph[0] = __builtin_amdgcn_perm(B[0], A[0], 0x04020100u); ph[1] = __builtin_amdgcn_perm(A[1], B[0], 0x05040201u);
+                ph[2] = __builtin_amdgcn_perm(B[1], A[1], 0x06050402u); ph[3] = __builtin_amdgcn_perm(B[2], A[2], 0x04020100u);
+                ph[4] = __builtin_amdgcn_perm(A[3], B[2], 0x05040201u); ph[5] = __builtin_amdgcn_perm(B[3], A[3], 0x06050402u);
+            } else {
+#pragma unroll
+                for (uint32_t j = 0; j < 4; ++j) ph[j] = __builtin_amdgcn_perm(B[j], A[j], 0x05040100u);
+            }
+            ph_ib = ib;
+        };
+        // Four groups = one 128-byte line of the lane's integers per round, requested a round ahead and consumed from registers: a
+        // line is then fetched once and need not survive in L2 between trips (83 k lanes x (an input line + an output line being
+        // filled) is the whole L2; with the input lines passing through, the pass lost 0.9 of its 2.3 ms).  The first store of a
+        // lane writes zeros over its own first half-group, which the next store rewrites.
+        constexpr uint32_t NR = 4;
+#pragma unroll
+        for (int w = 0; w < NH; ++w) ph[w] = 0u;
+        ph_ib = i0;
+        int32_t va[NR][NS_FRAMES], vb[NR][NS_FRAMES];
+#pragma unroll
+        for (uint32_t j = 0; j < NR; ++j) load8(j, va[j]);
+        auto round = [&](uint32_t g0, const int32_t (&cur)[NR][NS_FRAMES], int32_t (&nxt)[NR][NS_FRAMES]) {
+#pragma unroll
+            for (uint32_t j = 0; j < NR; ++j) load8(g0 + NR + j, nxt[j]);
+#pragma unroll
+            for (uint32_t j = 0; j < NR; ++j) {
+                store_half();                                              // the group before (or the lane's last, again)
+                if (g0 + j < my_ngrp) process(g0 + j, cur[j]);
+            }
+        };
+        uint32_t g0 = 0;
+        for (; g0 + NR < ngrp_max; g0 += 2 * NR) { round(g0, va, vb); round(g0 + NR, vb, va); }
+        if (g0 < ngrp_max) round(g0, va, vb);
+        store_half();
+    }
+    // the segment's last, partial group (the call ends inside it): step by step, the left lane stores what exists two bytes at a time
+    if (active && ((i1 - i0) % NS_FRAMES)) {
+        const uint32_t ib = i0 + NS_FRAMES * my_ngrp;
+        int32_t v[NS_FRAMES], r8[NS_FRAMES];
+#pragma unroll
+        for (uint32_t u = 0; u < NS_FRAMES; ++u) v[u] = ib + u < i1 ? xs[ib + u] : 0;
+        steps8(ib, v, r8, std::true_type{});
+        uint32_t pk[NW];
         uint32_t L[NS_FRAMES], R[NS_FRAMES];
 #pragma unroll
         for (uint32_t u = 0; u < NS_FRAMES; ++u) {
@@ -615,7 +653,6 @@ __global__ __launch_bounds__(256) void d2d_noise_shape_stereo_kernel(NoiseShapeA
         if constexpr (SB == 3) {
 #pragma unroll
             for (int g = 0; g < 2; ++g) {
-                // frames k, k+1 -> 12 bytes: [L0 L1 L2 R0 | R1 R2 L0' L1' | L2' R0' R1' R2']
                 const uint32_t La = L[4 * g], Ra = R[4 * g], Lb = L[4 * g + 1], Rb = R[4 * g + 1];
                 const uint32_t Lc = L[4 * g + 2], Rc = R[4 * g + 2], Ld = L[4 * g + 3], Rd = R[4 * g + 3];
                 pk[6 * g + 0] = __builtin_amdgcn_perm(Ra, La, 0x04020100u); pk[6 * g + 1] = __builtin_amdgcn_perm(Lb, Ra, 0x05040201u);
@@ -626,10 +663,16 @@ __global__ __launch_bounds__(256) void d2d_noise_shape_stereo_kernel(NoiseShapeA
 #pragma unroll
             for (uint32_t u = 0; u < NS_FRAMES; ++u) pk[u] = __builtin_amdgcn_perm(R[u], L[u], 0x05040100u);
         }
-        pk_ib = ib;
-        pk_n = active && ib < i1 ? min(NS_FRAMES, i1 - ib) : 0u;
+        if (ch == 0) {
+            uint8_t* g = gout + (size_t)ib * FBY;
+            for (uint32_t b = 0; b < (i1 - ib) * FBY; b += 2) {
+                uint32_t wv = 0;
+#pragma unroll
+                for (int w = 0; w < NW; ++w) wv = (b >> 2) == (uint32_t)w ? pk[w] : wv;
+                *reinterpret_cast<D2D_GLOBAL uint16_t*>(as_global(g + b)) = (uint16_t)(wv >> (8 * (b & 2)));
+            }
+        }
     }
-    flush();
     // the open segment's state travels on -- into the OTHER state buffer: the lane that reads a stream's carried state and
     // the lane that writes its new one may sit in different blocks
     if (INTQ) { e1 = ldexp((double)E1, -F); e2 = ldexp((double)E2, -F); }
