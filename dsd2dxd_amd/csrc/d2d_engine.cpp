@@ -64,6 +64,7 @@ struct d2d_engine {
     int32_t* d_scratch = nullptr; size_t scratch_stride = 0;  // stage-A integers per stream (multiple of 4)
     bool noise_shape = false;             // 'N' dither: the FIR writes integers, a sequential pass requantises
     double* d_ns[2] = {nullptr, nullptr}; int ns_cur = 0;   // its state: two errors per stream, ping-pong between calls
+    uint8_t* d_ns_dump = nullptr;                            // NoiseShapeArgs::dump
     uint32_t xs_hist = 0;                 // samples carried in front of each scratch line (P of the resampler, else 0)
     StreamJob* d_jobs = nullptr;
     StreamJob* h_jobs = nullptr;          // pinned, JOB_SLOTS x nstreams
@@ -142,6 +143,7 @@ static void free_device(d2d_engine* e) {
     if (e->d_peak) hipFree(e->d_peak);
     if (e->d_scratch) hipFree(e->d_scratch);
     for (int i = 0; i < 2; ++i) if (e->d_ns[i]) hipFree(e->d_ns[i]);
+    if (e->d_ns_dump) hipFree(e->d_ns_dump);
     if (e->d_jobs) hipFree(e->d_jobs);
     if (e->h_jobs) hipHostFree(e->h_jobs);
     if (e->d_in) hipFree(e->d_in);
@@ -301,6 +303,7 @@ int d2d_create(const d2d_params* params, uint32_t n_files, d2d_engine** out) {
         e->scratch_stride = 4096;
         CK(hipMalloc((void**)&e->d_scratch, sizeof(int32_t) * e->scratch_stride * e->nstreams));
         for (int i = 0; i < 2; ++i) CK(hipMalloc((void**)&e->d_ns[i], sizeof(double) * 2 * e->nstreams));
+        CK(hipMalloc((void**)&e->d_ns_dump, 1024));
     }
     const size_t hbytes = (size_t)e->nstreams * e->keep;
     CK(hipMalloc((void**)&e->d_hist[0], hbytes));
@@ -473,7 +476,7 @@ int d2d_translate_batch_device(d2d_engine* e, d2d_file_io* io, uint32_t n_files,
     if (pe) HIPCHK(e, hipEventRecord(pe->second, s));
     if (e->noise_shape) {
         NoiseShapeArgs ns{};
-        ns.jobs = e->d_jobs; ns.state = e->d_ns[e->ns_cur]; ns.state_next = e->d_ns[e->ns_cur ^ 1];
+        ns.jobs = e->d_jobs; ns.state = e->d_ns[e->ns_cur]; ns.state_next = e->d_ns[e->ns_cur ^ 1]; ns.dump = e->d_ns_dump;
         ns.scale_bits = e->S; ns.nstreams = e->nstreams; ns.max_nout = max_nx; ns.epi = e->epi;
         { static const char* noint = getenv("D2D_NO_INTQ"); FirArgs fa{}; fir_args_static(e, fa); ns.intq = (!noint && fa.sum_abs_q + (1ull << 24) < (1ull << 31)) ? 1u : 0u; }
         // a stream whose call ends exactly on a segment boundary, or feeds nothing, writes no state: start the next buffer from the current one

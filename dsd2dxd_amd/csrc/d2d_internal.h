@@ -69,6 +69,7 @@ struct NoiseShapeArgs {
     const StreamJob* jobs;
     const double* state;       // [nstreams][2]: the last two requantisation errors carried INTO this call
     double*  state_next;       // ... and out of it (ping-pong: reader and writer of a stream's state may be different blocks)
+    uint8_t* dump;             // 1 KiB nobody reads: where the stereo kernel's cooperative stores put the pieces that belong to no group
     int32_t  scale_bits;       // S: the scratch holds y * 2^S
     uint32_t nstreams;
     uint32_t max_nout;         // the longest stream's outputs this call (sizes the grid)

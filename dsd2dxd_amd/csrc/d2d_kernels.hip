@@ -572,53 +572,72 @@ __global__ __launch_bounds__(256) void d2d_noise_shape_stereo_kernel(NoiseShapeA
 
     typedef int32_t i32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
     typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
-    typedef uint32_t u32x2_a4 __attribute__((ext_vector_type(2), aligned(4)));
-    constexpr int NH = NW / 2;                                             // each lane of the pair stores half of the group: frames 0-3 (left lane) or 4-7
-    uint32_t ph[NH];
-    uint32_t ph_ib = 0;
-    if (my_ngrp) {
-        auto load8 = [&](uint32_t g, int32_t (&v)[NS_FRAMES]) {           // the lane's group min(g, last): always inside its segment
-            const D2D_GLOBAL int32_t* p = xs + (i0 + NS_FRAMES * min(g, my_ngrp - 1u));
+    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+    constexpr int NH = NW / 2;                                             // each lane of the pair packs half of the group: frames 0-3 (left lane) or 4-7
+    // Rounds of four groups = one 128-byte line of a lane's integers, requested a round ahead and consumed from registers (a line is
+    // fetched once and need not survive in L2 between trips).  The round's frames go through LDS -- a row per segment -- and leave
+    // in 16-byte pieces that are consecutive along each segment: a store instruction then covers whole lines of five or six
+    // segments instead of 24 bytes in each of 64 lines (the scattered form cost 0.55 ms of the pass's 2.15).  Every memory
+    // operation of the loop is unconditional, so the compiler counts its waits: a lane whose segment is shorter keeps requesting
+    // its last group (arithmetic switched off by exec), and a piece that belongs to no group of its segment goes to a dump line.
+    constexpr uint32_t NR = 4;                                             // groups per round
+    constexpr uint32_t CPG = NW / 4;                                       // 16-byte pieces per group: 3 (24-bit) or 2 (16-bit)
+    constexpr uint32_t CPR = CPG * NR;                                     // ... per segment and round
+    constexpr uint32_t ROW = CPR * 16 + 16;                                // LDS row pitch (one spare piece: rows start on different banks)
+    constexpr uint32_t NI = 32 * CPR / 64;                                 // store instructions per round
+    __shared__ __align__(16) unsigned char stage_all[4][32 * ROW];
+    unsigned char* stage = stage_all[wave];
+    if (ngrp_max) {
+        const uint32_t g_last = my_ngrp ? my_ngrp - 1u : 0u;
+        const uint32_t ld_max = j0.nout - NS_FRAMES;                       // (some lane of the wave has a whole group: nout >= 8)
+        auto load8 = [&](uint32_t g, int32_t (&v)[NS_FRAMES]) {           // the lane's group min(g, last): always inside the stream
+            const D2D_GLOBAL int32_t* p = xs + min(i0 + NS_FRAMES * min(g, g_last), ld_max);
             const i32x4_a4 lo4 = *reinterpret_cast<D2D_GLOBAL const i32x4_a4*>(p), hi4 = *reinterpret_cast<D2D_GLOBAL const i32x4_a4*>(p + 4);
             v[0] = lo4.x; v[1] = lo4.y; v[2] = lo4.z; v[3] = lo4.w; v[4] = hi4.x; v[5] = hi4.y; v[6] = hi4.z; v[7] = hi4.w;
         };
-        auto store_half = [&]() {
-            uint8_t* g = gout + (size_t)ph_ib * FBY + ch * (4u * NH);      // (4-byte aligned when the group starts on an even frame)
-            *reinterpret_cast<D2D_GLOBAL u32x4_a4*>(as_global(g)) = u32x4_a4{ph[0], ph[1], ph[2], ph[3]};
-            if constexpr (NH == 6) *reinterpret_cast<D2D_GLOBAL u32x2_a4*>(as_global(g + 16)) = u32x2_a4{ph[4], ph[5]};
-        };
-        auto process = [&](uint32_t g, const int32_t (&v)[NS_FRAMES]) {
+        // piece c = 64 i + lane of a round: segment slot c / CPR, piece c % CPR of that segment's CPR * 16 bytes
+        uint32_t pc_lds[NI], pc_grp[NI], pc_ngrp[NI];
+        uint64_t pc_out[NI];
+#pragma unroll
+        for (uint32_t i = 0; i < NI; ++i) {
+            const uint32_t c = 64u * i + lane, sl = c / CPR, w = c - sl * CPR;
+            pc_lds[i] = sl * ROW + w * 16u;
+            pc_grp[i] = w / CPG;
+            pc_ngrp[i] = (uint32_t)__shfl((int)my_ngrp, (int)(2u * sl));
+            const uint32_t i0s = (uint32_t)__shfl((int)i0, (int)(2u * sl));
+            pc_out[i] = (uint64_t)(uintptr_t)gout + (uint64_t)i0s * FBY + w * 16u;
+        }
+        const uint64_t dump = (uint64_t)(uintptr_t)a.dump + lane * 16u;
+        auto process = [&](uint32_t g, uint32_t j, const int32_t (&v)[NS_FRAMES]) {
             const uint32_t ib = i0 + NS_FRAMES * g;
             int32_t r8[NS_FRAMES];
             steps8(ib, v, r8, std::false_type{});
             // the pair's lanes swap samples (quad_perm [1,0,3,2]); frame j of this lane's half: A = left channel, B = right channel
             uint32_t A[4], B[4];
 #pragma unroll
-            for (uint32_t j = 0; j < 4; ++j) {
-                const uint32_t nlo = (uint32_t)__builtin_amdgcn_mov_dpp(r8[j], 0xB1, 0xF, 0xF, true);
-                const uint32_t nhi = (uint32_t)__builtin_amdgcn_mov_dpp(r8[4 + j], 0xB1, 0xF, 0xF, true);
-                A[j] = ch ? nhi : (uint32_t)r8[j];
-                B[j] = ch ? (uint32_t)r8[4 + j] : nlo;
+            for (uint32_t q = 0; q < 4; ++q) {
+                const uint32_t nlo = (uint32_t)__builtin_amdgcn_mov_dpp(r8[q], 0xB1, 0xF, 0xF, true);
+                const uint32_t nhi = (uint32_t)__builtin_amdgcn_mov_dpp(r8[4 + q], 0xB1, 0xF, 0xF, true);
+                A[q] = ch ? nhi : (uint32_t)r8[q];
+                B[q] = ch ? (uint32_t)r8[4 + q] : nlo;
             }
+            unsigned char* row = stage + sw * ROW + j * (16u * CPG) + ch * (4u * NH);
             if constexpr (SB == 3) {
                 // frames k, k+1 -> 12 bytes: [L0 L1 L2 R0 | R1 R2 L0' L1' | L2' R0' R1' R2']
-                ph[0] = __builtin_amdgcn_perm(B[0], A[0], 0x04020100u); ph[1] = __builtin_amdgcn_perm(A[1], B[0], 0x05040201u);
-                ph[2] = __builtin_amdgcn_perm(B[1], A[1], 0x06050402u); ph[3] = __builtin_amdgcn_perm(B[2], A[2], 0x04020100u);
-                ph[4] = __builtin_amdgcn_perm(A[3], B[2], 0x05040201u); ph[5] = __builtin_amdgcn_perm(B[3], A[3], 0x06050402u);
+                u32x2* d = reinterpret_cast<u32x2*>(row);                  // 8-byte aligned
+                d[0] = u32x2{__builtin_amdgcn_perm(B[0], A[0], 0x04020100u), __builtin_amdgcn_perm(A[1], B[0], 0x05040201u)};
+                d[1] = u32x2{__builtin_amdgcn_perm(B[1], A[1], 0x06050402u), __builtin_amdgcn_perm(B[2], A[2], 0x04020100u)};
+                d[2] = u32x2{__builtin_amdgcn_perm(A[3], B[2], 0x05040201u), __builtin_amdgcn_perm(B[3], A[3], 0x06050402u)};
             } else {
-#pragma unroll
-                for (uint32_t j = 0; j < 4; ++j) ph[j] = __builtin_amdgcn_perm(B[j], A[j], 0x05040100u);
+                *reinterpret_cast<u32x4*>(row) = u32x4{__builtin_amdgcn_perm(B[0], A[0], 0x05040100u), __builtin_amdgcn_perm(B[1], A[1], 0x05040100u),
+                                                       __builtin_amdgcn_perm(B[2], A[2], 0x05040100u), __builtin_amdgcn_perm(B[3], A[3], 0x05040100u)};
             }
-            ph_ib = ib;
         };
-        // Four groups = one 128-byte line of the lane's integers per round, requested a round ahead and consumed from registers: a
-        // line is then fetched once and need not survive in L2 between trips (83 k lanes x (an input line + an output line being
-        // filled) is the whole L2; with the input lines passing through, the pass lost 0.9 of its 2.3 ms).  The first store of a
-        // lane writes zeros over its own first half-group, which the next store rewrites.
-        constexpr uint32_t NR = 4;
-#pragma unroll
-        for (int w = 0; w < NH; ++w) ph[w] = 0u;
-        ph_ib = i0;
+        auto wave_sync = [&]() {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        };
         int32_t va[NR][NS_FRAMES], vb[NR][NS_FRAMES];
 #pragma unroll
         for (uint32_t j = 0; j < NR; ++j) load8(j, va[j]);
@@ -626,15 +645,21 @@ __global__ __launch_bounds__(256) void d2d_noise_shape_stereo_kernel(NoiseShapeA
 #pragma unroll
             for (uint32_t j = 0; j < NR; ++j) load8(g0 + NR + j, nxt[j]);
 #pragma unroll
-            for (uint32_t j = 0; j < NR; ++j) {
-                store_half();                                              // the group before (or the lane's last, again)
-                if (g0 + j < my_ngrp) process(g0 + j, cur[j]);
+            for (uint32_t j = 0; j < NR; ++j)
+                if (g0 + j < my_ngrp) process(g0 + j, j, cur[j]);
+            wave_sync();
+            const uint64_t rofs = (uint64_t)g0 * (NS_FRAMES * FBY);        // the round's first byte inside every segment
+#pragma unroll
+            for (uint32_t i = 0; i < NI; ++i) {
+                const u32x4 piece = *reinterpret_cast<const u32x4*>(stage + pc_lds[i]);
+                const uint64_t dst = g0 + pc_grp[i] < pc_ngrp[i] ? pc_out[i] + rofs : dump;
+                *reinterpret_cast<D2D_GLOBAL u32x4_a4*>(as_global(reinterpret_cast<uint8_t*>((uintptr_t)dst))) = u32x4_a4{piece.x, piece.y, piece.z, piece.w};
             }
+            wave_sync();
         };
         uint32_t g0 = 0;
         for (; g0 + NR < ngrp_max; g0 += 2 * NR) { round(g0, va, vb); round(g0 + NR, vb, va); }
         if (g0 < ngrp_max) round(g0, va, vb);
-        store_half();
     }
     // the segment's last, partial group (the call ends inside it): step by step, the left lane stores what exists two bytes at a time
     if (active && ((i1 - i0) % NS_FRAMES)) {
