@@ -257,6 +257,25 @@ def test_noise_shaped_segments_restart_and_carry(engine_lib, oracle_mod, kernel)
     assert np.array_equal(one, g)                          # one call (nine segments side by side) == nine calls
 
 
+@pytest.mark.parametrize("bits", [24, 16])
+def test_noise_shaped_many_segments_many_waves(engine_lib, oracle_mod, bits):
+    """171 segments per channel = six waves in two blocks of the stereo noise-shaping kernel (a wave's lanes hand their frames to
+    each other through LDS and store them along the segments): odd call sizes, a call that ends inside a group, segments that
+    finish at different rounds inside one wave -- all equal to the oracle's sequential loop, and one call == five calls"""
+    nbytes = 8192 * 171 - 3001                            # M = 8: one output per byte
+    chans = [synth("sine", nbytes, seed=13, msb_first=True, amp=0.45), synth("pink", nbytes, seed=14, amp=0.098, msb_first=True)]
+    cuts = [0, 300001, 300004, 8192 * 100 + 5, nbytes - 7, nbytes]
+    bufs = [pack_layout([ch[a:b] for ch in chans], "I", 1) for a, b in zip(cuts[:-1], cuts[1:])]
+    kw = dict(dsd_rate=1, output_rate=352800, channels=2, fmt="I", endianness="M", block_size=1,
+              filter="E", bit_depth=bits, dither="N", seed=77)
+    g, r, e, o = run_pair(engine_lib, oracle_mod, bufs, kw, 2)
+    assert g.size == r.size and g.size == nbytes * 2 * (bits // 8)
+    assert np.array_equal(g, r)
+    assert e.peak_dbfs() == o.peak_dbfs()
+    one, _, _, _ = run_pair(engine_lib, oracle_mod, [pack_layout(chans, "I", 1)], kw, 2)
+    assert np.array_equal(one, g)
+
+
 @pytest.mark.parametrize("sparse,bits", [(0, 24), (1, 24), (0, 16), (0, 32)], ids=["dense_chain", "sparse_chain", "dense_chain_16bit", "dense_chain_float"])
 @pytest.mark.parametrize("dither", ["T", "R", "X"])
 @pytest.mark.parametrize("dsd_rate,out_rate,filt", [(1, 88200, "E"), (1, 88200, "X"), (2, 88200, "E"), (2, 176400, "C"), (4, 176400, "E"),
