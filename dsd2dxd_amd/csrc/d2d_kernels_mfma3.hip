@@ -32,6 +32,9 @@
 namespace d2d {
 
 #define D2D_M3_THREADS 512
+#ifndef D2D_M3_STAGED
+#define D2D_M3_STAGED 1     // M = 8: a full tile's frames go through LDS and leave as aligned 1-KiB rows (0: straight from registers, A/B builds)
+#endif
 
 #ifndef D2D_M3_ABL
 #define D2D_M3_ABL 0
@@ -492,6 +495,28 @@ __global__ __launch_bounds__(D2D_M3_THREADS) void d2d_fir_mfma3_kernel(Mfma2Args
     };
     auto store_packed = [&](uint32_t tile, const u32x4 (&p4)[2], const u32x4 (&p2)[2], bool known_full = false) {
         if (!known_full && !tile_full(tile)) return;
+        if constexpr (D2D_M3_STAGED && MB == 1 && !SCR) {
+            // M = 8: the stores are what this shape waits for (profiles/r02_experiments.txt item 17): the tile's frames through
+            // LDS, then 16 bytes per lane along the tile -- every store instruction writes eight whole, aligned lines
+            uint8_t* ob = wbase + m.off_out;
+            typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                u32x2* d = reinterpret_cast<u32x2*>(ob + FB * lane_fr + 8 * FB * g);      // 8-byte aligned
+                d[0] = u32x2{p4[g].x, p4[g].y}; d[1] = u32x2{p4[g].z, p4[g].w};
+                if constexpr (SBY >= 3) d[2] = u32x2{p2[g].x, p2[g].y};
+                if constexpr (SBY == 4) d[3] = u32x2{p2[g].z, p2[g].w};
+            }
+            wave_sync2();
+            uint8_t* gt = reinterpret_cast<uint8_t*>(j0.out) + (size_t)tile * (M2_TILE * FB) + 16u * lane;
+#pragma unroll
+            for (uint32_t j = 0; j < (uint32_t)M2_TILE * FB / 1024u; ++j) {
+                const u32x4 v = *reinterpret_cast<const u32x4*>(ob + 1024u * j + 16u * lane);
+                if (dbg & 64) { asm volatile("" :: "v"(v)); continue; }
+                *reinterpret_cast<D2D_GLOBAL u32x4_a4*>(as_global(gt + 1024u * j)) = u32x4_a4{v.x, v.y, v.z, v.w};
+            }
+            return;
+        }
         uint8_t* gout = reinterpret_cast<uint8_t*>(j0.out) + (size_t)tile * (M2_TILE * FB) + FB * lane_fr;
 #pragma unroll
         for (int g = 0; g < 2; ++g) {
@@ -771,6 +796,7 @@ static hipError_t launch_mfma3_t(Mfma2Args& m, uint32_t nwt_max, uint32_t nrows,
     m.off_waves = NT ? (uint32_t)m4_nfr(MB, NT) * M4_FRAG_BYTES : (uint32_t)(2 * NPG) * 1024u;
     m.wave_lds = 2u * (uint32_t)(NT ? m4_stream_bytes(MB, NT) : m2_stream_bytes(MB, NPG));
     m.off_out = m.wave_lds;
+    if (D2D_M3_STAGED && MB == 1 && SBY != 0) m.wave_lds += (uint32_t)M2_TILE * 2u * SBY;     // the tile's frames, staged for whole-line stores
     static const char* wenv = getenv("D2D_MFMA_WAVES");   // diagnostic override
     m.nwaves = wenv ? (uint32_t)atoi(wenv) : 8u;
     if (m.nwaves < 1 || m.nwaves > 8) m.nwaves = 8;

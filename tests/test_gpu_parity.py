@@ -289,8 +289,6 @@ def test_pipelined_stereo_kernel_fast_and_careful_tiles(engine_lib, oracle_mod, 
     (v_smfmac_i32_32x32x64_i8, its own tap tables): same results."""
     if sparse and (filt != "E" or out_rate // dsd_rate > 88200):
         pytest.skip("the sparse chain is compiled for the E filters at M = 32 and 64 only")
-    if bits == 32 and out_rate // dsd_rate == 352800:
-        pytest.skip("M = 8 float frames stay on the one-group kernel")
     monkeypatch.setenv("D2D_SPARSE", str(sparse))
     rng = np.random.default_rng(5)
     nbytes = 4096 * 40 * dsd_rate
