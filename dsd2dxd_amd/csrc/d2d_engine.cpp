@@ -21,6 +21,7 @@
 #include "d2d_internal.h"
 #include "d2d_launch.h"
 #include "d2d_mfma.h"
+#include "d2d_mx.h"
 
 using namespace d2d;
 
@@ -188,6 +189,7 @@ static void fir_args_static(const d2d_engine* e, FirArgs& a) {
     a.sum_abs_q = sa;
     a.epi = e->epi;
     a.pipelined = (uint32_t)e->mfma_pipe;
+    a.mx_exact = mx_exact(*e->fc.fir) ? 1u : 0u;
 }
 
 extern "C" {
@@ -284,7 +286,7 @@ int d2d_create(const d2d_params* params, uint32_t n_files, d2d_engine** out) {
         CK(hipMemcpy(e->d_fir_tables, t.data(), e->fir_table_bytes, hipMemcpyHostToDevice));
     } else {
         if (e->mfma_v2) { FirArgs a{}; fir_args_static(e, a); e->mfma_pipe = mfma2_pipelined(a, e->M, e->N); }
-        std::vector<int8_t> t = e->mfma_pipe == 4 ? build_mfma4_tables(f, msb)
+        std::vector<int8_t> t = e->mfma_pipe == 5 ? build_mx_tables(f, msb) : e->mfma_pipe == 4 ? build_mfma4_tables(f, msb)
                               : e->mfma_v2 ? build_mfma2_tables(f, msb, !e->mfma_pipe) : build_mfma_tables(f, e->mfma, msb);
         e->fir_table_bytes = t.size();
         CK(hipMalloc(&e->d_fir_tables, e->fir_table_bytes));
@@ -768,6 +770,7 @@ static TableBlobHeader make_header(const d2d_engine* e) {
     TableBlobHeader h{};
     h.magic = 0x54443244u; h.abi = D2D_ABI_VERSION; h.kernel = e->kernel; h.endianness = e->p.endianness;
     h.ntaps = (uint32_t)e->N; h.M = (uint32_t)e->M; h.scale_bits = (uint32_t)e->S; h.filter_type = (uint32_t)e->fc.fir->type;
+    h.table_variant = e->kernel == D2D_KERNEL_MFMA && e->mfma_v2 ? (e->mfma_pipe ? (uint32_t)e->mfma_pipe : 2u) : 0u;
     h.fir_bytes = e->fir_table_bytes; h.resamp_bytes = e->resamp_bytes;
     return h;
 }
@@ -824,6 +827,13 @@ const char* d2d_kernel_name(const d2d_engine* e) {
     if (!e) return "";
     if (e->kernel == D2D_KERNEL_MFMA && e->mfma_v2) {
         d2d_engine* m = const_cast<d2d_engine*>(e);
+        if (e->mfma_pipe == 5) {
+            const int kind = e->epi.dither == 'T' ? 1 : e->epi.dither == 'R' ? 2 : 0;
+            const bool scr = e->fc.resamp || e->noise_shape;
+            m->kname = "d2d_fir_mx_kernel<" + std::to_string(e->Mb) + ", " + std::to_string(e->N) + ", " + std::to_string(mx_groups()) + ", " +
+                       std::to_string(scr || e->epi.sample_bytes == 4 ? 0 : kind) + ", " + std::to_string(scr ? 0u : e->epi.sample_bytes) + ">";
+            return m->kname.c_str();
+        }
         if (e->mfma_pipe) {
             const int kind = e->epi.dither == 'T' ? 1 : e->epi.dither == 'R' ? 2 : 0;
             const bool scr = e->fc.resamp || e->noise_shape;

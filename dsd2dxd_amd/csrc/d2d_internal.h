@@ -60,7 +60,9 @@ struct FirArgs {
     int32_t  scale_bits;       // S of the tap table (h = q * 2^-S)
     uint32_t in_channels;      // channels of the input layout (epi.channels = channels of the output frame; fewer for a channel subset)
     uint64_t sum_abs_q;        // sum |q_j| of the tap table (bounds |y*2^S|)
-    uint32_t pipelined;        // two-group MFMA kernels: 0, or the variant of the pipelined kernel whose tap table the engine built (3 dense, 4 sparse)
+    uint32_t pipelined;        // two-group MFMA kernels: 0, or the variant of the pipelined kernel whose tap table the engine built (3 dense, 4 sparse,
+                               // 5 the fp6 x fp4 kernel of d2d_kernels_mx.hip)
+    uint32_t mx_exact;         // 1: the table's base-32 digit sums recombine exactly in f32 (d2d_mx.h: mx_exact)
     Epilogue epi;
 };
 
@@ -103,6 +105,9 @@ struct TableBlobHeader {
     uint32_t M;
     uint32_t scale_bits;
     uint32_t filter_type;
+    uint32_t table_variant;    // layout of the FIR table: 0 LUT / one-group MFMA, 2 two-group (plane 0 unmasked), 3 pipelined (every plane masked),
+                               // 4 structured-sparse, 5 fp6 digits -- it depends on channels, depth, gain and dither, not only on the filter
+    uint32_t reserved;
     uint64_t fir_bytes;
     uint64_t resamp_bytes;
 };

@@ -26,6 +26,7 @@
 #include <stdlib.h>
 
 #include "d2d_mfma2_dev.h"
+#include "d2d_mx.h"
 
 namespace d2d {
 
@@ -714,15 +715,29 @@ static bool mfma3_eligible(const FirArgs& a, const Mfma2Args& m, int MB, int NPG
 
 static void mfma2_geometry(const FirArgs& a, int MB, int NPG, Mfma2Args& m, size_t& smem);
 
+// the same conversions as mfma3_eligible, shape apart (the caller checks mx_supported and the engine mx_exact)
+static bool mx_eligible(const FirArgs& a, const Mfma2Args& m) {
+    const bool range_ok = a.scale_bits >= 20 && a.scale_bits <= 30 && a.sum_abs_q != 0 && a.sum_abs_q < (1ull << 31) && a.mx_exact;
+    if (a.to_scratch) return a.epi.channels >= 2 && a.epi.channels % 2 == 0 && range_ok;
+    static const char* noint = getenv("D2D_NO_INTQ");
+    const bool stereo = a.epi.channels == 2 && m.qsh == 0;
+    const bool float_ok = !noint && stereo && a.epi.bits == 32 && a.epi.dither != 'F' && a.epi.gain == 1.0;
+    const bool frames_ok = stereo && (a.epi.sample_bytes == 3 || a.epi.sample_bytes == 2) && m.intq;
+    return range_ok && (float_ok || frames_ok);
+}
+
 int mfma2_pipelined(const FirArgs& a, int M, int N) {
     // (read at every engine creation, not cached: the tests switch variants inside one process)
     const char* nopipe = getenv("D2D_NO_PIPE");
     const char* sparse = getenv("D2D_SPARSE");
     if (nopipe && atoi(nopipe)) return 0;
     const int MB = M / 8, NPG = mfma2_pairs(M, N);
-    if (!mfma2_supported(M, N) && !mfma3_supported(MB, NPG, N) && !(a.to_scratch && mfma3_scr_supported(MB, NPG))) return 0;
+    const char* nomx = getenv("D2D_NO_MX");
     Mfma2Args m{}; size_t smem = 0;
     mfma2_geometry(a, MB, NPG, m, smem);
+    // the fp6 x fp4 kernel (d2d_kernels_mx.hip) serves what the pipelined int8 kernel serves at M = 32 and 64: 5
+    if (!(nomx && atoi(nomx)) && mx_supported(MB, N) && mx_eligible(a, m)) return 5;
+    if (!mfma2_supported(M, N) && !mfma3_supported(MB, NPG, N) && !(a.to_scratch && mfma3_scr_supported(MB, NPG))) return 0;
     if (!mfma3_eligible(a, m, MB, NPG, N)) return 0;
     // the structured-sparse chain issues 27 % fewer MFMAs but 8 % more vector instructions, and the kernel is bound by vector issue:
     // measured 4-7 % slower than the dense chain; kept selectable (D2D_SPARSE=1), exact and tested
@@ -824,6 +839,7 @@ hipError_t launch_fir_mfma2(const FirArgs& a, int M, int N, uint32_t max_nout, u
     const int epi = mfma2_epilogue(a, m);
     // stereo 24-bit at 0 dB: the software-pipelined kernel (d2d_kernels_mfma3.hip), same results; the engine chose it (and its
     // table variant) when it was created
+    if (a.pipelined == 5) return launch_fir_mx(m, MB, N, max_nout, nrows, s);
     if (a.pipelined) return launch_fir_mfma3(m, (int)a.pipelined, MB, NPG, N, nwt, nrows, s);
 #define X(mb, npg)                                                                                  \
     if (MB == mb && NPG == npg) {                                                                   \

@@ -1,0 +1,730 @@
+// d2d_kernels_mx.hip -- the FIR decimator on the fp6 x fp4 matrix-core instruction (gfx950), exact, software-pipelined.
+//
+// Same arithmetic contract, staging, pipelining and epilogue as d2d_kernels_mfma3.hip (stereo at 0 dB: 24-bit, 16-bit, float frames,
+// and the exact integers for the stage-A / noise-shaper scratch); what changes is the instruction that carries the dot product and,
+// with it, the geometry.  v_mfma_i32_32x32x32_i8 spends 32 cycles on 32 stream bits per column; v_mfma_scale_f32_32x32x64_f8f6f4
+// with an fp6 (e2m3) A operand and an fp4 (e2m1) B operand spends the same 32 cycles on 64 (tools/ubench/mfma_shapes.hip), and one
+// v_and turns a stream dword into EIGHT operand slots instead of four:
+//
+//   * B operand = the bit stream.  A nibble that holds one stream bit is an e2m1 number: 0b0001 = 0.5, 0b0010 = 1.0.  A stream dword W
+//     becomes the lane's four operand registers W & 0x11111111, W & 0x22222222, (W >> 2) & 0x11111111, (W >> 2) & 0x22222222 (five
+//     vector instructions for 32 bits; the int8 form needs eight): K slot 8p + n of the lane is bit 4n + p of its dword.
+//   * A operand = the taps.  2q (q the 24-bit tap) is written in five balanced base-32 digits d in [-16, 15]; the slot that meets a
+//     0.5-valued bit holds d/4, the slot that meets a 1.0-valued bit d/8 -- both exact in e2m3 (multiples of 1/8 up to 2, of 1/4 up to
+//     4) -- and the B scale of the instruction is 2^3, so every product is the integer d * bit and the f32 accumulators hold the exact
+//     digit sums (|sum| <= 16 * 752 << 2^24).  Matrix row = (phase, digit): 6 phases x 5 digits = 30 of the 32 rows; a lane half owns
+//     the three phases 3h .. 3h+2 of every group with all five digits of a sample in its own registers.
+//   * v = sum q s = S0 + 32 S1 + 2^10 S2 + 2^15 (S3 + 32 S4), accumulators started from -2^S in the digit-4 rows: two f32 fma
+//     (|.| < 2^24: exact), one more for the high part, two conversions, one shift-add.
+//   * One matrix column serves 6 G consecutive outputs (G groups of six phases); group g reads the tap fragments of group 0
+//     6 M / 64 steps later, a step being 64 stream bits (lane half h takes dword 2u + h).  M = 32, E filter: 12 fragments, 15 steps and
+//     24 MFMAs per 384 outputs = 32 per 512 (the int8 form: 52), 100 operand-expansion instructions per 512 outputs (136).
+//
+// Frames leave through a per-wave LDS slice (a lane owns runs of three samples, not of four): samples in as dwords, out as groups of
+// four frames, packed and stored as in the int8 kernel.
+//
+// Replaces: the per-block translate loop inside Rdsd2Pcm::do_conversion
+// (/root/reference/src/main.rs:345,429); the crate that holds it is absent from the reference.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "d2d_mfma2_dev.h"
+#include "d2d_mx.h"
+
+namespace d2d {
+
+#define D2D_MX_THREADS 512
+#ifndef D2D_MX_ABL
+#define D2D_MX_ABL 0
+#endif
+
+typedef int v8i __attribute__((ext_vector_type(8)));
+typedef float v16f __attribute__((ext_vector_type(16)));
+typedef int32_t i32x3 __attribute__((ext_vector_type(3)));
+
+__device__ __forceinline__ int32_t mx_lshl_add(int32_t x, uint32_t sh, int32_t y) {
+    int32_t d;
+    asm("v_lshl_add_u32 %0, %1, %2, %3" : "=v"(d) : "v"(x), "v"(sh), "v"(y));
+    return d;
+}
+__device__ __forceinline__ uint32_t mx_min3_u16(uint32_t x, uint32_t y, uint32_t z) {
+    uint32_t d;
+    asm("v_min3_u16 %0, %1, %2, %3" : "=v"(d) : "v"(x), "v"(y), "v"(z));
+    return d;
+}
+__device__ __forceinline__ int32_t mx_min3(int32_t x, int32_t y, int32_t z) {
+    int32_t d;
+    asm("v_min3_i32 %0, %1, %2, %3" : "=v"(d) : "v"(x), "v"(y), "v"(z));
+    return d;
+}
+__device__ __forceinline__ int32_t mx_max3(int32_t x, int32_t y, int32_t z) {
+    int32_t d;
+    asm("v_max3_i32 %0, %1, %2, %3" : "=v"(d) : "v"(x), "v"(y), "v"(z));
+    return d;
+}
+
+// KIND: 0 no dither, 1 triangular, 2 rectangular.  Stereo, unit gain; SBY = bytes per sample: 3 (24-bit packed frames), 2 (16-bit),
+// 4 (32-bit float, KIND 0 only) or 0 (the exact integers y * 2^S to the scratch lines of a channel pair).
+template <int MB, int NT, int G, int KIND, int SBY>
+__global__ __launch_bounds__(D2D_MX_THREADS) void d2d_fir_mx_kernel(Mfma2Args m) {
+    constexpr int CS = mx_cs(MB, G), DLY = mx_dly(MB), NF = mx_nf(MB, NT), TP = mx_nstep(MB, NT, G);
+    constexpr int OC = 6 * G, TILE = 32 * OC, NS = 3 * G;           // outputs per column / per tile; samples per lane and channel
+    constexpr int NCHK = mx_chunks(MB, NT, G), PF = mx_pf(MB, NT, G);
+    constexpr uint32_t SB = (uint32_t)mx_stream_bytes(MB, NT, G);
+    constexpr uint32_t FB = 2u * (SBY ? SBY : 1);                   // bytes per stereo frame
+    constexpr uint32_t TBL16 = (uint32_t)NF * (MX_FRAG_BYTES / 16); // 16-byte units of one table variant
+    constexpr bool SCR = SBY == 0;
+    constexpr uint32_t dbg = D2D_MX_ABL;                  // compile-time ablation mask: 1 no chain, 2 no epilogue, 4 no staging, 8 never slow, 64 no stores
+    const FirArgs& a = m.f;
+    extern __shared__ __align__(16) unsigned char smem[];
+    const uint32_t Ct = a.in_channels;
+    const uint32_t fidx = SCR ? blockIdx.y / m.ngroups : blockIdx.y;
+    const uint32_t cbase = SCR ? (blockIdx.y - fidx * m.ngroups) * 2u : 0u;
+    const uint32_t tid = threadIdx.x, lane = tid & 63;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    uint8_t* wbase = smem + m.off_waves + wave * m.wave_lds;       // [channel 0 stream buffer | channel 1 stream buffer | output slice]
+    const StreamJob* jobs = a.jobs + (size_t)fidx * (SCR ? a.epi.channels : 2u) + cbase;
+    const StreamJob j0 = jobs[0];          // in, L, e0, n0, nout are common to a file's channels
+
+    const int64_t first0 = j0.e0 - (int64_t)a.Wb;          // first byte of output 0's window
+    const uint32_t sh = (uint32_t)(first0 & 3);            // its misalignment inside the staged dword
+    {   // tap fragments: L2 -> LDS once per block; the variant for this byte misalignment
+        const uint4* s = reinterpret_cast<const uint4*>(a.tables) + (size_t)sh * TBL16;
+        uint4* dl = reinterpret_cast<uint4*>(smem);
+        for (uint32_t i = tid; i < TBL16; i += blockDim.x) dl[i] = s[i];
+    }
+    __syncthreads();
+
+    const uint32_t nwt = (j0.nout + (TILE - 1)) / TILE;            // wave-tiles in this file
+    const uint32_t wstride = gridDim.x * m.nwaves;
+    const uint32_t r = lane & 31, h = lane >> 5;
+
+    // ---- staging geometry: window dword L of a tile sits at LDS dword L + L / CS (one pad dword per column stride: CS is even) ----
+    const uint32_t X0 = (uint32_t)(first0 >> 2) & 3u;
+    constexpr uint32_t DUMMY = SB - 16u;
+    uint32_t wlo[PF], whi[PF];
+#pragma unroll
+    for (int i = 0; i < PF; ++i) {
+        const uint32_t q = lane + 64u * i;
+        const uint32_t Lh = 4u * q;
+        whi[i] = 4u * (Lh + Lh / (uint32_t)CS) - 4u * X0;
+        const uint32_t Ll = 4u * q - X0;
+        wlo[i] = q == 0 ? DUMMY : 4u * (Ll + Ll / (uint32_t)CS);
+    }
+    const uint32_t Bsz = a.B, Lcall = (uint32_t)j0.L;
+    const bool pow2B = Bsz >= 16 && (Bsz & (Bsz - 1)) == 0;
+    const uint32_t bshift = pow2B ? 31 - __builtin_clz(Bsz) : 0;
+    const uint32_t full_bytes = pow2B ? (Lcall >> bshift) << bshift : 0;
+    const uint32_t jump = (Ct - 1u) * Bsz;
+    const bool fast_layout = pow2B && (uint64_t)full_bytes * Ct < (1ull << 32) && jump < (1u << 24);
+    auto tile_ab16 = [&](uint32_t w) -> int32_t { return (int32_t)((first0 + (int64_t)w * (TILE * MB)) & ~(int64_t)15); };
+
+    uint32_t lofs[PF];
+#pragma unroll
+    for (int i = 0; i < PF; ++i) { const uint32_t q = lane + 64u * i; lofs[i] = 16u * (q < (uint32_t)NCHK ? q : (uint32_t)NCHK - 1u); }
+    const uint32_t chf[2] = {(uint32_t)__builtin_amdgcn_readfirstlane((int)jobs[0].ch), (uint32_t)__builtin_amdgcn_readfirstlane((int)jobs[1].ch)};
+    constexpr int NPFSET = 2;
+    u32x4 pf[NPFSET][PF];
+    auto issue_loads = [&](uint32_t w, auto cc, auto af) {
+        constexpr int c = decltype(cc)::value;
+        constexpr bool AF = decltype(af)::value;
+        const int32_t ab = tile_ab16(w);
+        if (AF || (fast_layout && ab >= 0 && (uint32_t)ab + 16u * NCHK <= full_bytes)) {
+            const uint32_t blk0 = (uint32_t)ab >> bshift, r0 = (uint32_t)ab & (Bsz - 1);
+            const uint8_t* base = j0.in + ((uint64_t)(blk0 * Ct + chf[c]) << bshift);
+#pragma unroll
+            for (int i = 0; i < PF; ++i) {
+                const uint32_t off = r0 + lofs[i];
+                const uint32_t o = __umul24(off >> bshift, jump) + off;
+                pf[c][i] = *reinterpret_cast<D2D_GLOBAL const u32x4*>(as_global(base) + o);
+            }
+        } else {
+            if constexpr (!AF) {
+#pragma unroll
+                for (int i = 0; i < PF; ++i) pf[c][i] = gather_chunk(jobs + c, Ct, a.B, a.keep, ab + (int32_t)lofs[i]);
+            }
+        }
+    };
+    auto write_lds_x = [&](auto cc, auto xc) {
+        constexpr int X = decltype(xc)::value;
+        constexpr int c = decltype(cc)::value;
+        uint8_t* buf = wbase + c * SB;
+#pragma unroll
+        for (int i = 0; i < PF; ++i)
+            if (lane + 64u * i < (uint32_t)NCHK) {
+                const uint32_t v[4] = {pf[c][i].x, pf[c][i].y, pf[c][i].z, pf[c][i].w};
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    *reinterpret_cast<uint32_t*>(buf + (k < X ? wlo[i] : whi[i]) + 4 * k) = v[k];
+            }
+    };
+    auto write_lds = [&](auto cc) {
+        if (X0 == 0) write_lds_x(cc, std::integral_constant<int, 0>{});
+        else if (X0 == 1) write_lds_x(cc, std::integral_constant<int, 1>{});
+        else if (X0 == 2) write_lds_x(cc, std::integral_constant<int, 2>{});
+        else write_lds_x(cc, std::integral_constant<int, 3>{});
+    };
+
+    // tap fragment f: 16 bytes per lane at f * 1536 + 16 lane, 8 more at f * 1536 + 1024 + 8 lane
+    const uint8_t* tp16 = smem + 16u * lane;
+    const uint8_t* tp8 = smem + 1024u + 8u * lane;
+    uint32_t kmA = 0x11111111u, kmB = 0x22222222u;
+    asm volatile("" : "+v"(kmA), "+v"(kmB));
+    int scA = 0x7f7f7f7f, scB = (int)0x82828282u;          // e8m0 scales: A x 1, B x 8 (every product becomes an integer)
+    asm volatile("" : "+v"(scA), "+v"(scB));
+    // accumulators start from -2^S: the digit-4 rows (weight 2^20) of every sample
+    v16f cinit;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) cinit[i] = (i < 15 && (i % 5) == 4) ? -(float)(1 << (a.scale_bits - 20)) : 0.0f;
+    asm volatile("" : "+v"(cinit));
+
+    // One chain: TP steps of 64 stream bits; group g runs its NF MFMAs from step DLY g on, with the fragments group 0 read
+    // DLY g steps earlier; LDS reads are issued AHEAD steps before their use; `hook(u)` is whatever else the wave does during step u.
+    auto chain = [&](uint32_t c, v16f (&acc)[G], auto&& hook) {
+        const uint8_t* rbc = wbase + c * SB + 4u * ((CS + 1) * r + h);
+        uint32_t W[TP];
+        v4i F4[NF]; u32x2 F2[NF];
+        auto rdW = [&](auto uc) { constexpr int u = decltype(uc)::value; W[u] = *reinterpret_cast<const uint32_t*>(rbc + 4 * (2 * u + (2 * u) / CS)); };
+        auto rdF = [&](auto fc) {
+            constexpr int f = decltype(fc)::value;
+            F4[f] = *reinterpret_cast<const v4i*>(tp16 + MX_FRAG_BYTES * f);
+            F2[f] = *reinterpret_cast<const u32x2*>(tp8 + MX_FRAG_BYTES * f);
+        };
+        constexpr int AHEAD = 2;
+        static_for<0, AHEAD>([&](auto uc) { rdW(uc); rdF(uc); });
+        static_for<0, TP>([&](auto uc) {
+            constexpr int u = decltype(uc)::value;
+            if constexpr (u + AHEAD < TP) rdW(std::integral_constant<int, u + AHEAD>{});
+            if constexpr (u + AHEAD < NF) rdF(std::integral_constant<int, u + AHEAD>{});
+            const uint32_t w = W[u], w2 = w >> 2;
+            const v8i Bv = {(int)(w & kmA), (int)(w & kmB), (int)(w2 & kmA), (int)(w2 & kmB), 0, 0, 0, 0};
+            static_for<0, G>([&](auto gc) {
+                constexpr int g = decltype(gc)::value;
+                constexpr int f = u - DLY * g;
+                if constexpr (f >= 0 && f < NF) {
+                    const v8i Av = {F4[f].x, F4[f].y, F4[f].z, F4[f].w, (int)F2[f].x, (int)F2[f].y, 0, 0};
+                    if constexpr (f == 0) acc[g] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(Av, Bv, cinit, 2, 4, 0, scA, 0, scB);
+                    else acc[g] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(Av, Bv, acc[g], 2, 4, 0, scA, 0, scB);
+                }
+            });
+            hook(uc);
+            __builtin_amdgcn_sched_barrier(0);
+        });
+    };
+    auto no_hook = [](auto) {};
+    auto pin = [&](v16f (&acc)[G]) {
+#pragma unroll
+        for (int g = 0; g < G; ++g) asm volatile("" : "+v"(acc[g]));
+    };
+
+    // dither keys of the two channels (uniform)
+    uint32_t rkey[2], rstep[2], rlo0[2];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) { rkey[c] = jobs[c].rng_key; rstep[c] = jobs[c].rng_kstep; rlo0[c] = jobs[c].rng_lo0; }
+    double pk[2] = {0.0, 0.0};                              // peaks met on the slow path, in LSB
+    int32_t vmn[2] = {0, 0}, vmx[2] = {0, 0};               // running extremes of v on the fast path
+
+    // constants of the fast epilogue, parked in VGPRs
+    const int F_ = SBY == 4 ? 1 : m.fbits;                  // 0 < F <= 16 (integer depths)
+    float kFs = ldexpf(1.0f, -a.scale_bits);                // float output: y = v * 2^-S
+    asm volatile("" : "+v"(kFs));
+    uint32_t kF = (uint32_t)F_, kSh = 16u - (uint32_t)F_, kShR = 32u - (uint32_t)F_;
+    uint32_t kC1 = 0x7feb352dU, kC2 = 0x846ca68bU, kTm = (uint32_t)-32767;
+    uint32_t k15 = 15u;
+    float k32 = 32.0f, k1024 = 1024.0f;
+    int32_t kHalf = 1 << (F_ - 1);
+    asm volatile("" : "+v"(kF), "+v"(kSh), "+v"(kShR), "+v"(kC1), "+v"(kC2), "+v"(kTm), "+v"(k15), "+v"(k32), "+v"(k1024), "+v"(kHalf));
+    const int32_t kSafe = (int32_t)(((uint32_t)m.qmax_i - 2u) << F_);
+    const uint32_t lane_fr = (uint32_t)OC * r + 3u * h;     // the lane's first sample inside a tile; sample i = 3 g + q sits at lane_fr + 6 g + q
+
+    // v = sum q s of sample q of a group's accumulators: digits S0..S4 = registers 5q .. 5q+4 (exact integers)
+    auto recombine = [&](const v16f& A, int q) -> int32_t {
+        const float lo = __builtin_fmaf(A[5 * q + 2], k1024, __builtin_fmaf(A[5 * q + 1], k32, A[5 * q]));
+        const float hi = __builtin_fmaf(A[5 * q + 4], k32, A[5 * q + 3]);
+        return mx_lshl_add((int32_t)hi, k15, (int32_t)lo);
+    };
+    auto noise = [&](uint32_t c, uint32_t nl) -> uint32_t {
+        const uint32_t nlo = (uint32_t)j0.n0 + nl;
+        uint32_t z = nlo + rkey[c] + (nlo < rlo0[c] ? rstep[c] : 0u);
+        z ^= z >> 16; z *= 0x7feb352dU;
+        z ^= z >> 15; z *= 0x846ca68bU;
+        z ^= z >> 16;
+        return z;
+    };
+    // the general per-sample requantiser (any tile): x = v * 2^-F LSB, dither in 2^-16 (2^-17) LSB, round half away, clip
+    auto quant_slow = [&](int32_t v, uint32_t c, uint32_t nl) -> int32_t {
+        const int F = m.fbits;
+        const int32_t vh = v >> F;
+        const uint32_t vl = (uint32_t)v & ((1u << F) - 1u);
+        int32_t rr;
+        if constexpr (KIND == 2) {
+            const uint32_t z = noise(c, nl);
+            const int32_t w = (int32_t)(vl << (17 - F)) + (int32_t)(2u * (z >> 16) + 1u) - 65536;
+            const int32_t neg = (vh + (w >> 17)) >> 31;
+            rr = vh + ((w + 65536 + neg) >> 17);
+        } else {
+            int32_t w = (int32_t)(vl << (16 - F));
+            if constexpr (KIND == 1) {
+                const uint32_t z = noise(c, nl);
+                w += (int32_t)((z & 0xFFFFu) + (z >> 16)) - 65535;
+            }
+            const int32_t neg = (vh + (w >> 16)) >> 31;
+            rr = vh + ((w + 32768 + neg) >> 16);
+        }
+        return min(max(rr, m.qmin_i), m.qmax_i);
+    };
+
+    // ---- the fast epilogue of one (tile, channel), cut into jobs that ride on the steps of a chain ----
+    struct Fast {
+        uint32_t zb;            // hash input of the lane's first sample
+        uint32_t T[NS];         // per sample: the dither term
+        int32_t res[NS];
+        int32_t vprev; uint32_t wprev;
+        int32_t tmn, tmx; uint32_t tie;
+    };
+    auto fast_begin = [&](Fast& f, uint32_t tile, uint32_t c) {
+        const uint32_t first = (uint32_t)j0.n0 + tile * (uint32_t)TILE;
+        const uint32_t key_eff = rkey[c] + (first < rlo0[c] ? rstep[c] : 0u);
+        f.zb = first + key_eff + lane_fr;
+        f.tmn = 0; f.tmx = 0; f.tie = 0xFFFFu;
+    };
+    constexpr int NJ = (KIND == 0 ? NS : 2 * NS);           // jobs per epilogue
+    auto fast_job = [&](Fast& f, const v16f (&o)[G], auto jc) {
+        constexpr int j = decltype(jc)::value;
+        constexpr int i = KIND == 0 ? j : j >> 1;           // sample 0..NS-1: group i / 3, q = i % 3
+        constexpr bool HASH = KIND != 0 && (j & 1) == 0;
+        if constexpr (HASH) {
+            uint32_t z = f.zb + (uint32_t)(6 * (i / 3) + (i % 3));
+            z ^= z >> 16; z *= kC1;
+            z ^= z >> 15; z *= kC2;
+            z ^= z >> 16;
+            if constexpr (KIND == 1) f.T[i] = __builtin_amdgcn_sad_u16(z, 0u, kTm);      // lo16 + hi16 - 32767, units of 2^-16 LSB
+            else f.T[i] = z >> kShR;                                                       // (2*hi16 + 1) >> (17 - F)
+        } else {
+            const int32_t v = recombine(o[i / 3], i % 3);
+            int32_t s;
+            if constexpr (KIND == 1) {
+                s = v + ((int32_t)f.T[i] >> kSh);
+                const uint32_t w = (uint32_t)mx_lshl_add(v, kSh, (int32_t)f.T[i]);         // low 16 bits zero: an exact tie
+                if constexpr (i & 1) f.tie = mx_min3_u16(f.tie, f.wprev, w);
+                else if constexpr (i == NS - 1) f.tie = mx_min3_u16(f.tie, w, w);
+                else f.wprev = w;
+            } else if constexpr (KIND == 2) {
+                s = v + (int32_t)f.T[i];
+            } else if constexpr (SBY == 4 || SCR) {
+                s = 0;
+            } else {
+                s = v + kHalf + (v >> 31);                                                 // round half away from zero
+            }
+            if constexpr (SBY == 4) f.res[i] = __float_as_int((float)v * kFs);
+            else if constexpr (SCR) f.res[i] = v;
+            else f.res[i] = s >> kF;
+            asm volatile("" : "+v"(f.res[i]));         // keep the whole job on this step (the value is only used after the region)
+            if constexpr (!SCR) {
+                if constexpr (i & 1) { f.tmn = mx_min3(f.tmn, f.vprev, v); f.tmx = mx_max3(f.tmx, f.vprev, v); }
+                else if constexpr (i == NS - 1) { f.tmn = min(f.tmn, v); f.tmx = max(f.tmx, v); }
+                else f.vprev = v;
+            }
+        }
+    };
+    auto fast_hook = [&](Fast& f, const v16f (&o)[G], auto uc) {
+        constexpr int u = decltype(uc)::value;
+        static_for<0, NJ>([&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+            if constexpr ((j * TP) / NJ == u) fast_job(f, o, jc);
+        });
+    };
+    auto fast_failed = [&](const Fast& f, uint32_t tile) -> bool {
+        const uint32_t first = (uint32_t)j0.n0 + tile * (uint32_t)TILE;
+        const bool full = tile * (uint32_t)TILE + (uint32_t)TILE <= j0.nout;
+        if (SCR || (dbg & 8)) return false;
+        if (!full || first > 0xFFFFFFFFu - (uint32_t)TILE) return true;
+        if constexpr (SBY == 4) return false;                // float: nothing clips, nothing ties
+        const bool bad = (KIND == 1 && (f.tie & 0xFFFFu) == 0) || f.tmx > kSafe || f.tmn < -kSafe;
+        return __builtin_amdgcn_ballot_w64(bad) != 0;
+    };
+    // the careful way: the channel's chain again (its stream bytes are still in that channel's buffer), then sample by sample
+    auto redo = [&](uint32_t cbuf, uint32_t tile, uint32_t c, int32_t (&out)[NS]) {
+        v16f t[G];
+        chain(cbuf, t, no_hook);
+        const bool full = tile * (uint32_t)TILE + (uint32_t)TILE <= j0.nout;
+        const uint32_t nl_base = tile * (uint32_t)TILE + lane_fr;
+        uint32_t vmax = 0;
+#pragma unroll
+        for (int i = 0; i < NS; ++i) {
+            const uint32_t nl = nl_base + 6u * (i / 3) + (i % 3);
+            const int32_t v = recombine(t[i / 3], i % 3);
+            if constexpr (SBY == 4) out[i] = __float_as_int((float)v * kFs); else out[i] = quant_slow(v, c, nl);
+            const uint32_t va = (uint32_t)(v < 0 ? -v : v);
+            vmax = max(vmax, full || nl < j0.nout ? va : 0u);
+        }
+        pk[c] = fmax(pk[c], ldexp((double)vmax, -m.fbits));   // |x| = |v| * 2^-F exactly
+    };
+    auto tile_full = [&](uint32_t tile) -> bool { return tile * (uint32_t)TILE + (uint32_t)TILE <= j0.nout; };
+    // a channel's samples of the tile in flight -> the wave's output slice [channel][TILE] (dwords): a lane owns runs of three
+    int32_t* ob = reinterpret_cast<int32_t*>(wbase + m.off_out);
+    auto put_samples = [&](uint32_t c, const int32_t (&v)[NS]) {
+        int32_t* d = ob + c * TILE + lane_fr;
+#pragma unroll
+        for (int g = 0; g < G; ++g) { d[6 * g] = v[3 * g]; d[6 * g + 1] = v[3 * g + 1]; d[6 * g + 2] = v[3 * g + 2]; }
+    };
+    // the tile's frames out of the slice: a lane takes groups of four consecutive frames (24 / 16 / 32 contiguous bytes)
+    constexpr int NQ = TILE / 4, QPASS = (NQ + 63) / 64;
+    auto store_tile = [&](uint32_t tile, bool known_full = false) {
+        const bool full = known_full || tile_full(tile);
+        uint8_t* gout = reinterpret_cast<uint8_t*>(j0.out) + (size_t)tile * (TILE * FB);
+        const uint32_t nl0 = tile * (uint32_t)TILE;
+#pragma unroll
+        for (int p = 0; p < QPASS; ++p) {
+            const uint32_t Q = lane + 64u * p;
+            if ((NQ % 64) != 0 && p == QPASS - 1 && Q >= (uint32_t)NQ) continue;
+            const i32x4 Lq = *reinterpret_cast<const i32x4*>(ob + 4 * Q), Rq = *reinterpret_cast<const i32x4*>(ob + TILE + 4 * Q);
+            const uint32_t La = Lq.x, Lb = Lq.y, Lc = Lq.z, Ld = Lq.w, Ra = Rq.x, Rb = Rq.y, Rc = Rq.z, Rd = Rq.w;
+            uint8_t* gq = gout + 4u * FB * Q;
+            if (full) {
+                if (dbg & 64) { asm volatile("" :: "v"(Lq), "v"(Rq)); continue; }
+                if constexpr (SBY == 3) {
+                    // frames k, k+1 -> 12 bytes: [L0 L1 L2 R0 | R1 R2 L0' L1' | L2' R0' R1' R2']
+                    const u32x4 p4 = {__builtin_amdgcn_perm(Ra, La, 0x04020100u), __builtin_amdgcn_perm(Lb, Ra, 0x05040201u),
+                                      __builtin_amdgcn_perm(Rb, Lb, 0x06050402u), __builtin_amdgcn_perm(Rc, Lc, 0x04020100u)};
+                    const u32x2 p2 = {__builtin_amdgcn_perm(Ld, Rc, 0x05040201u), __builtin_amdgcn_perm(Rd, Ld, 0x06050402u)};
+                    *reinterpret_cast<D2D_GLOBAL u32x4*>(as_global(gq)) = p4;
+                    *reinterpret_cast<D2D_GLOBAL u32x2*>(as_global(gq + 16)) = p2;
+                } else if constexpr (SBY == 4) {
+                    *reinterpret_cast<D2D_GLOBAL u32x4*>(as_global(gq)) = u32x4{La, Ra, Lb, Rb};
+                    *reinterpret_cast<D2D_GLOBAL u32x4*>(as_global(gq + 16)) = u32x4{Lc, Rc, Ld, Rd};
+                } else {
+                    *reinterpret_cast<D2D_GLOBAL u32x4*>(as_global(gq)) =
+                        u32x4{__builtin_amdgcn_perm(Ra, La, 0x05040100u), __builtin_amdgcn_perm(Rb, Lb, 0x05040100u),
+                              __builtin_amdgcn_perm(Rc, Lc, 0x05040100u), __builtin_amdgcn_perm(Rd, Ld, 0x05040100u)};
+                }
+            } else {
+                // the file's last, partial tile: frame by frame (24-bit: three 2-byte stores each)
+                const uint32_t Ls[4] = {La, Lb, Lc, Ld}, Rs[4] = {Ra, Rb, Rc, Rd};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    if (nl0 + 4u * Q + k < j0.nout) {
+                        const uint32_t Lv = Ls[k], Rv = Rs[k];
+                        D2D_GLOBAL uint16_t* p16 = reinterpret_cast<D2D_GLOBAL uint16_t*>(as_global(gq + FB * k));
+                        if constexpr (SBY == 3) { p16[0] = (uint16_t)Lv; p16[1] = (uint16_t)(((Lv >> 16) & 0xFFu) | (Rv << 8)); p16[2] = (uint16_t)(Rv >> 8); }
+                        else if constexpr (SBY == 4) { p16[0] = (uint16_t)Lv; p16[1] = (uint16_t)(Lv >> 16); p16[2] = (uint16_t)Rv; p16[3] = (uint16_t)(Rv >> 16); }
+                        else { p16[0] = (uint16_t)Lv; p16[1] = (uint16_t)Rv; }
+                    }
+                }
+            }
+        }
+    };
+    // SCR: the lane's runs of three consecutive integers of channel c go straight to that channel's scratch line
+    auto store_scr = [&](uint32_t tile, uint32_t c, const int32_t (&v)[NS]) {
+        D2D_GLOBAL int32_t* xs = as_global(jobs[c].xs) + (size_t)tile * TILE + lane_fr;
+        const uint32_t nl = tile * (uint32_t)TILE + lane_fr;
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            if (nl + 6u * g + 2u < j0.nout) { xs[6 * g] = v[3 * g]; xs[6 * g + 1] = v[3 * g + 1]; xs[6 * g + 2] = v[3 * g + 2]; }
+            else
+#pragma unroll
+                for (int k = 0; k < 3; ++k) if (nl + 6u * g + k < j0.nout) xs[6 * g + k] = v[3 * g + k];
+        }
+    };
+    auto merge_extremes = [&](const Fast& f, uint32_t c) { vmn[c] = min(vmn[c], f.tmn); vmx[c] = max(vmx[c], f.tmx); };
+
+    const uint32_t wv = blockIdx.x * m.nwaves + wave;       // this wave's index among the file's waves
+    using C0 = std::integral_constant<int, 0>;
+    using C1 = std::integral_constant<int, 1>;
+    // The pipelined loop over the tiles t_begin + wv + k * wstride < t_end:
+    //   region A (tile t):  chain of channel 0  ||  requantise channel 1 of tile t-1; its frames leave after the next prefetch is out
+    //   region B (tile t):  chain of channel 1  ||  requantise channel 0 of tile t
+    auto run_loop = [&](uint32_t t_begin, uint32_t t_end, auto af) {
+        constexpr bool AF = decltype(af)::value;
+        uint32_t wt = t_begin + wv;
+        if (wt < t_end) {
+            issue_loads(wt, C0{}, af);
+            issue_loads(wt, C1{}, af);
+            // AF: every trip issues the same loads and stores in the same order (the first trip stores whatever the slice holds to its
+            // own tile, rewritten one trip later; the last trip re-requests its own tile): the compiler can then count its waits
+            if (AF && !SCR && !(dbg & 64)) store_tile(wt, true);
+        }
+        v16f accA[G], accB[G];                                  // channel 0's / channel 1's accumulators
+#pragma unroll
+        for (int g = 0; g < G; ++g)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) accB[g][i] = 0.0f;
+        bool have_prev = false;
+        uint32_t pw = wt;                                       // the tile whose channel 1 still waits for its epilogue
+        for (; wt < t_end; wt += wstride) {
+            const bool more = wt + wstride < t_end;
+            const uint32_t nxt = more ? wt + wstride : wt;
+            // ---- region A ----
+            wave_sync2();
+            if (!(dbg & 4)) {
+                write_lds(C0{});
+                if (AF || more) issue_loads(nxt, C0{}, af);
+            }
+            wave_sync2();
+            {
+                Fast f;
+                fast_begin(f, pw, 1);
+                if (dbg & 2) chain(0u, accA, no_hook);
+                else if (dbg & 1) { static_for<0, NJ>([&](auto jc) { fast_job(f, accB, jc); }); for (int g = 0; g < G; ++g) accA[g] = cinit + (float)lane; }
+                else chain(0u, accA, [&](auto uc) { fast_hook(f, accB, uc); });
+                pin(accA);                      // the chain ends HERE (or the compiler sinks its MFMAs into the blocks that use them, behind the epilogue)
+                if (have_prev) {
+                    if constexpr (SCR) store_scr(pw, 1, f.res);
+                    else {
+                        if (!(dbg & 3) && fast_failed(f, pw)) redo(1u, pw, 1, f.res); else merge_extremes(f, 1);
+                        put_samples(1, f.res);
+                    }
+                }
+            }
+            // ---- region B ----
+            wave_sync2();
+            if (!(dbg & 4)) {
+                write_lds(C1{});
+                if (AF || more) issue_loads(nxt, C1{}, af);
+            }
+            if constexpr (AF) { if (!SCR) store_tile(pw, true); }
+            else if (have_prev && !SCR) store_tile(pw);
+            wave_sync2();
+            {
+                Fast f;
+                fast_begin(f, wt, 0);
+                if (dbg & 2) chain(1u, accB, no_hook);
+                else if (dbg & 1) { static_for<0, NJ>([&](auto jc) { fast_job(f, accA, jc); }); for (int g = 0; g < G; ++g) accB[g] = cinit - (float)lane; }
+                else chain(1u, accB, [&](auto uc) { fast_hook(f, accA, uc); });
+                pin(accB);
+                if constexpr (SCR) store_scr(wt, 0, f.res);
+                else {
+                    if (!(dbg & 3) && fast_failed(f, wt)) redo(0u, wt, 0, f.res); else merge_extremes(f, 0);
+                    put_samples(0, f.res);
+                }
+            }
+            have_prev = true; pw = wt;
+        }
+        if (have_prev) {
+            // drain: channel 1 of the wave's last tile
+            Fast f;
+            fast_begin(f, pw, 1);
+            static_for<0, NJ>([&](auto jc) { fast_job(f, accB, jc); });
+            if constexpr (SCR) store_scr(pw, 1, f.res);
+            else {
+                if (fast_failed(f, pw)) redo(1u, pw, 1, f.res); else merge_extremes(f, 1);
+                put_samples(1, f.res);
+                wave_sync2();
+                store_tile(pw);
+                wave_sync2();
+            }
+        }
+    };
+    // One tile the careful way, start to finish (call edges: the window reaches into the carried history or past the call's full
+    // blocks, so its bytes are gathered one by one).
+    auto slow_tile = [&](uint32_t t) {
+        wave_sync2();
+        issue_loads(t, C0{}, std::false_type{});
+        issue_loads(t, C1{}, std::false_type{});
+        write_lds(C0{});
+        write_lds(C1{});
+        wave_sync2();
+        int32_t o0[NS], o1[NS];
+        redo(0u, t, 0, o0);
+        redo(1u, t, 1, o1);
+        if constexpr (SCR) { store_scr(t, 0, o0); store_scr(t, 1, o1); }
+        else {
+            put_samples(0, o0);
+            put_samples(1, o1);
+            wave_sync2();
+            store_tile(t);
+        }
+    };
+    if (fast_layout && !SCR) {
+        // the tiles [t_lo, t_hi) lie inside the call's full blocks: the loop without the gather path; the few around them one by one
+        const int64_t T = (int64_t)TILE * MB;
+        auto is_fast = [&](uint32_t w) { const int32_t ab = tile_ab16(w); return ab >= 0 && (uint32_t)ab + 16u * NCHK <= full_bytes; };
+        uint32_t t_lo = first0 >= 0 ? 0u : (uint32_t)((-first0 + T - 1) / T);
+        if (t_lo > nwt) t_lo = nwt;
+        uint32_t t_hi = t_lo;
+        {
+            const int64_t room = (int64_t)full_bytes - 16 * NCHK - first0;
+            if (room >= 0) { const int64_t e = room / T + 1; t_hi = e > (int64_t)nwt ? nwt : (uint32_t)e; if (t_hi < t_lo) t_hi = t_lo; }
+            while (t_hi > t_lo && !is_fast(t_hi - 1)) --t_hi;
+            while (t_hi < nwt && t_hi >= t_lo && is_fast(t_hi) && (t_hi > t_lo || is_fast(t_lo))) ++t_hi;
+        }
+        { const uint32_t nfull = j0.nout / (uint32_t)TILE; if (t_hi > nfull) t_hi = nfull > t_lo ? nfull : t_lo; }     // whole tiles only
+        run_loop(t_lo, t_hi, std::true_type{});
+        const uint32_t n_edge = t_lo + (nwt - t_hi);
+        for (uint32_t i = wv; i < n_edge; i += wstride) slow_tile(i < t_lo ? i : t_hi + (i - t_lo));
+    } else {
+        run_loop(0u, nwt, std::false_type{});
+    }
+
+    if constexpr (SCR) return;                              // (stage B / the noise shaper keep the peaks)
+    // peak meter: |x| in LSB; undo the power-of-two part exactly
+    const double unscale = 1.0 / (double)(1u << (a.epi.bits - 1));   // (float: fbits = S - 31, so dev * 2^-fbits * 2^-31 = dev * 2^-S)
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        const int32_t dev = max(vmx[c], -vmn[c]);
+        double p = fmax(pk[c], ldexp((double)dev, -m.fbits)) * unscale;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) p = fmax(p, __shfl_xor(p, o));
+        if (lane == 0 && p > 0.0)
+            atomicMax(reinterpret_cast<unsigned long long*>(jobs[c].peak), (unsigned long long)__double_as_longlong(p));
+    }
+}
+
+// ---- host side -------------------------------------------------------------------------------
+// (MB, taps) of the filters this kernel serves: X_M32, C_M32, E_M32, A_M32, A_M64, C_M64, E_M64
+#ifdef D2D_MX_DEV
+#define D2D_MX_SHAPES(X) X(4, 560)
+#else
+#define D2D_MX_SHAPES(X) X(4, 384) X(4, 512) X(4, 560) X(4, 352) X(8, 688) X(8, 1024) X(8, 1104)
+#endif
+#ifndef D2D_MX_G
+#define D2D_MX_G 2
+#endif
+
+bool mx_supported(int MB, int NT) {
+#define X(mb, nt) if (MB == mb && NT == nt) return true;
+    D2D_MX_SHAPES(X)
+#undef X
+    return false;
+}
+
+// e2m3 code of x (a multiple of 1/8 up to 2, of 1/4 up to 4, of 1/2 up to 7.5)
+static uint32_t e2m3_code(double x) {
+    const uint32_t s = x < 0 ? 32u : 0u;
+    const double ax = fabs(x);
+    for (uint32_t c = 0; c < 32; ++c) {
+        const uint32_t e = c >> 3, mm = c & 7;
+        const double v = e ? (1.0 + mm / 8.0) * (double)(1 << (e - 1)) : mm * 0.125;
+        if (v == ax) return ax == 0 ? 0u : (s | c);
+    }
+    fprintf(stderr, "d2d: %g is not an e2m3 number\n", x);
+    abort();
+}
+// balanced base-32 digit l of v: v = sum d_l 32^l, every d in [-16, 15]
+static int digit32(int64_t v, int l) {
+    int dd = 0;
+    for (int i = 0; i <= l; ++i) {
+        dd = (int)(((v + 16) & 31) - 16);
+        v = (v - dd) / 32;
+    }
+    return dd;
+}
+
+// The recombination v = lo + 2^15 hi with lo = S0 + 32 S1 + 2^10 S2 and hi = S3 + 32 S4 is done in f32: exact while every value that can
+// occur stays below 2^24.  A digit sum over ANY subset of the window's bits is bounded by the sum of the digits' magnitudes.
+bool mx_exact(const d2d_filter_def& f) {
+    int64_t sa[5] = {0, 0, 0, 0, 0};
+    for (int k = 0; k < f.ntaps; ++k)
+        for (int l = 0; l < 5; ++l) { const int d = digit32(2 * (int64_t)tap_q(f, k), l); sa[l] += d < 0 ? -d : d; }
+    const int64_t lo = sa[0] + 32 * sa[1] + 1024 * sa[2];
+    const int64_t hi = sa[3] + 32 * (sa[4] + ((int64_t)1 << (f.S - 20)));
+    // 2 q has to fit five digits: |2q| <= 16 * (32^5 - 1) / 31
+    for (int k = 0; k < f.ntaps; ++k) { const int64_t q2 = 2 * (int64_t)tap_q(f, k); if (q2 > 16236247 || q2 < -17318416) return false; }
+    return f.S >= 20 && f.S <= 30 && lo < (1 << 24) && hi < (1 << 24);
+}
+
+// Tap fragments: [4 byte shifts][NF fragments][64 lanes x 16 bytes | 64 lanes x 8 bytes].  Fragment f multiplies the stream dwords
+// 2f (lane half 0) and 2f + 1 (half 1) of a column's window.  A lane l = matrix row l & 31, K half l >> 5; its element j (a 6-bit
+// e2m3 code at bits [6j, 6j+6) of the lane's 192) meets B register p = j >> 3, nibble n = j & 7 = bit 4n + p of the dword, which
+// arrives as 0.5 (p even) or 1.0 (p odd).  D row i lands in lane half (i >> 2) & 1, register 4 (i >> 3) + (i & 3) = 5 q + digit:
+// phase 3 half + q.
+std::vector<int8_t> build_mx_tables(const d2d_filter_def& f, bool msb_first) {
+    const int M = f.M, N = f.ntaps, MB = M / 8;
+    const int NF = mx_nf(MB, N);
+    const size_t per = (size_t)NF * MX_FRAG_BYTES;
+    std::vector<int8_t> t(4 * per, 0);
+    for (int sh = 0; sh < 4; ++sh)
+        for (int fr = 0; fr < NF; ++fr)
+            for (int l = 0; l < 64; ++l) {
+                const int row = l & 31, kh = l >> 5;
+                const int half = (row >> 2) & 1, rho = 4 * (row >> 3) + (row & 3);
+                uint32_t regs[6] = {0, 0, 0, 0, 0, 0};
+                if (rho < 15) {
+                    const int ph = 3 * half + rho / 5, dg = rho % 5;
+                    for (int j = 0; j < 32; ++j) {
+                        const int p = j >> 3, n = j & 7;
+                        const int wb = 32 * (2 * fr + kh) + 4 * n + p;                             // bit of the staged window
+                        const int tau = (msb_first ? (wb & ~7) + 7 - (wb & 7) : wb) - 8 * sh;     // its time index in the window
+                        const int tap = tau - ph * M;
+                        if (tau < 0 || tap < 0 || tap >= N) continue;
+                        const int d = digit32(2 * (int64_t)tap_q(f, tap), dg);
+                        const uint32_t code = e2m3_code((p & 1) ? d * 0.125 : d * 0.25);
+                        for (int b = 0; b < 6; ++b) if ((code >> b) & 1) regs[(6 * j + b) >> 5] |= 1u << ((6 * j + b) & 31);
+                    }
+                }
+                int8_t* fb = &t[sh * per + (size_t)fr * MX_FRAG_BYTES];
+                memcpy(fb + (size_t)l * 16, regs, 16);
+                memcpy(fb + 1024 + (size_t)l * 8, regs + 4, 8);
+            }
+    return t;
+}
+
+template <int MB, int NT, int G, int KIND, int SBY>
+static hipError_t launch_mx_t(Mfma2Args& m, uint32_t max_nout, uint32_t nrows, hipStream_t s) {
+    static KernelPrep prep;
+    int dev = 0;
+    const void* fn = reinterpret_cast<const void*>(&d2d_fir_mx_kernel<MB, NT, G, KIND, SBY>);
+    hipError_t e = prep.max_dynamic_lds(fn, 160 * 1024, &dev);
+    if (e != hipSuccess) return e;
+    constexpr uint32_t TILE = 32u * 6u * G;
+    // LDS: the shared tap table, then per wave two stream buffers and the output slice; eight waves per block = two per SIMD
+    m.off_waves = (uint32_t)mx_nf(MB, NT) * MX_FRAG_BYTES;
+    m.off_out = 2u * (uint32_t)mx_stream_bytes(MB, NT, G);
+    m.wave_lds = m.off_out + (SBY ? 2u * TILE * 4u : 0u);
+    static const char* wenv = getenv("D2D_MFMA_WAVES");   // diagnostic override
+    uint32_t nwaves = wenv ? (uint32_t)atoi(wenv) : 8u;
+    if (nwaves < 1 || nwaves > 8) nwaves = 8;
+    while (nwaves > 1 && (size_t)m.off_waves + (size_t)nwaves * m.wave_lds > 160 * 1024) nwaves >>= 1;
+    m.nwaves = nwaves;
+    const size_t smem = (size_t)m.off_waves + (size_t)m.nwaves * m.wave_lds;
+    if (smem > 160 * 1024) return hipErrorInvalidValue;
+    int blocks_per_cu, ncu;
+    {
+        std::lock_guard<std::mutex> g(prep.mu);
+        if (prep.blocks_per_cu[dev] == 0 || smem != prep.smem_seen[dev] || m.nwaves != prep.nwaves_seen[dev]) {
+            hipDeviceProp_t prop;
+            if ((e = hipGetDeviceProperties(&prop, dev)) != hipSuccess) return e;
+            int nb = 0;
+            e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, d2d_fir_mx_kernel<MB, NT, G, KIND, SBY>, (int)(64 * m.nwaves), smem);
+            if (e != hipSuccess) return e;
+            prep.ncu[dev] = prop.multiProcessorCount;
+            prep.blocks_per_cu[dev] = nb < 1 ? 1 : nb;
+            prep.smem_seen[dev] = smem; prep.nwaves_seen[dev] = m.nwaves;
+        }
+        blocks_per_cu = prep.blocks_per_cu[dev]; ncu = prep.ncu[dev];
+    }
+    // every wave loops over its share of the wave-tiles: launch what is resident at once
+    const uint32_t nwt_max = (max_nout + TILE - 1) / TILE;
+    uint32_t gx = (uint32_t)(ncu * blocks_per_cu) / nrows;
+    if (gx < 1) gx = 1;
+    const uint32_t need = (nwt_max + m.nwaves - 1) / m.nwaves;
+    if (gx > need) gx = need;
+    hipLaunchKernelGGL((d2d_fir_mx_kernel<MB, NT, G, KIND, SBY>), dim3(gx, nrows), dim3(64 * m.nwaves), smem, s, m);
+    return hipGetLastError();
+}
+
+hipError_t launch_fir_mx(Mfma2Args& m, int MB, int NT, uint32_t max_nout, uint32_t nrows, hipStream_t s) {
+    constexpr int G = D2D_MX_G;
+#define X(mb, nt)                                                                                                  \
+    if (MB == mb && NT == nt) {                                                                                    \
+        if (m.f.to_scratch) return launch_mx_t<mb, nt, G, 0, 0>(m, max_nout, nrows, s);                             \
+        if (m.f.epi.sample_bytes == 4) return launch_mx_t<mb, nt, G, 0, 4>(m, max_nout, nrows, s);                  \
+        if (m.f.epi.sample_bytes == 2) {                                                                           \
+            if (m.dkind == 1) return launch_mx_t<mb, nt, G, 1, 2>(m, max_nout, nrows, s);                           \
+            if (m.dkind == 2) return launch_mx_t<mb, nt, G, 2, 2>(m, max_nout, nrows, s);                           \
+            return launch_mx_t<mb, nt, G, 0, 2>(m, max_nout, nrows, s);                                             \
+        }                                                                                                          \
+        if (m.dkind == 1) return launch_mx_t<mb, nt, G, 1, 3>(m, max_nout, nrows, s);                               \
+        if (m.dkind == 2) return launch_mx_t<mb, nt, G, 2, 3>(m, max_nout, nrows, s);                               \
+        return launch_mx_t<mb, nt, G, 0, 3>(m, max_nout, nrows, s);                                                 \
+    }
+    D2D_MX_SHAPES(X)
+#undef X
+    return hipErrorInvalidValue;
+}
+
+int mx_groups() { return D2D_MX_G; }
+
+}  // namespace d2d

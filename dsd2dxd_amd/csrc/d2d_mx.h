@@ -1,0 +1,35 @@
+// d2d_mx.h -- geometry of the fp6 x fp4 matrix-core FIR kernel (d2d_kernels_mx.hip), shared by host and device.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <vector>
+
+#include "d2d_filters.h"
+#include "d2d_internal.h"
+
+namespace d2d {
+
+constexpr int MX_FRAG_BYTES = 1536;          // a tap fragment: 64 lanes x 16 bytes, then 64 lanes x 8 bytes (32 e2m3 codes per lane)
+
+// MB = bytes per output (M / 8), NT = taps, G = groups of six phases per matrix column
+__host__ __device__ constexpr int mx_cs(int MB, int G) { return 6 * G * MB / 4; }                 // column stride in dwords (6 G outputs)
+__host__ __device__ constexpr int mx_dly(int MB) { return 3 * MB / 4; }                           // steps (64 bits) between two groups: 6 M / 64
+__host__ __device__ constexpr int mx_nf(int MB, int NT) { return (NT + 5 * 8 * MB + 24 + 63) / 64; }   // fragments: window of six phases + up to 3 bytes of misalignment
+__host__ __device__ constexpr int mx_nstep(int MB, int NT, int G) { return mx_nf(MB, NT) + mx_dly(MB) * (G - 1); }
+__host__ __device__ constexpr int mx_span_dw(int MB, int NT, int G) { return 31 * mx_cs(MB, G) + 2 * mx_nstep(MB, NT, G); }
+__host__ __device__ constexpr int mx_chunks(int MB, int NT, int G) { return (mx_span_dw(MB, NT, G) + 3 + 3) / 4; }   // + up to 3 dwords in front
+__host__ __device__ constexpr int mx_pf(int MB, int NT, int G) { return (mx_chunks(MB, NT, G) + 63) / 64; }
+__host__ __device__ constexpr int mx_stream_bytes(int MB, int NT, int G) {
+    const int dw = 4 * mx_chunks(MB, NT, G);
+    return (((dw + dw / mx_cs(MB, G) + 4) * 4 + 15) & ~15) + 16;   // + a dummy slot for the dwords in front of the window
+}
+
+struct Mfma2Args;
+bool mx_supported(int MB, int NT);                 // is a kernel compiled for this shape?
+bool mx_exact(const d2d_filter_def& f);            // do the digit sums of this table recombine exactly in f32?
+int mx_groups();
+std::vector<int8_t> build_mx_tables(const d2d_filter_def& f, bool msb_first);
+hipError_t launch_fir_mx(Mfma2Args& m, int MB, int NT, uint32_t max_nout, uint32_t nrows, hipStream_t s);
+
+}  // namespace d2d

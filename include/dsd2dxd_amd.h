@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define D2D_ABI_VERSION 2
+#define D2D_ABI_VERSION 3   /* 3: the table blob header names the table variant */
 
 /* status codes */
 enum {

@@ -276,20 +276,27 @@ def test_noise_shaped_many_segments_many_waves(engine_lib, oracle_mod, bits):
     assert np.array_equal(one, g)
 
 
-@pytest.mark.parametrize("sparse,bits", [(0, 24), (1, 24), (0, 16), (0, 32)], ids=["dense_chain", "sparse_chain", "dense_chain_16bit", "dense_chain_float"])
+@pytest.mark.parametrize("chain,bits", [("mx", 24), ("mx", 16), ("mx", 32), ("dense", 24), ("sparse", 24), ("dense", 16), ("dense", 32)],
+                         ids=["fp6_chain", "fp6_chain_16bit", "fp6_chain_float", "dense_chain", "sparse_chain", "dense_chain_16bit", "dense_chain_float"])
 @pytest.mark.parametrize("dither", ["T", "R", "X"])
 @pytest.mark.parametrize("dsd_rate,out_rate,filt", [(1, 88200, "E"), (1, 88200, "X"), (2, 88200, "E"), (2, 176400, "C"), (4, 176400, "E"),
                                                     (1, 176400, "E"), (1, 352800, "E"), (1, 176400, "X"), (2, 352800, "C"), (1, 352800, "D")])
-def test_pipelined_stereo_kernel_fast_and_careful_tiles(engine_lib, oracle_mod, monkeypatch, dsd_rate, out_rate, filt, dither, sparse, bits):
-    """Stereo 24-bit (and 16-bit, and float without the float dither) at 0 dB runs d2d_fir_mfma3_kernel: the requantiser rides on the next chain in its branch-free form and a
+def test_pipelined_stereo_kernel_fast_and_careful_tiles(engine_lib, oracle_mod, monkeypatch, dsd_rate, out_rate, filt, dither, chain, bits):
+    """Stereo 24-bit (and 16-bit, and float without the float dither) at 0 dB runs a software-pipelined kernel -- d2d_fir_mx_kernel (fp6 x fp4
+    matrix-core chain, M = 32 and 64) or d2d_fir_mfma3_kernel (int8 chain; every M up to 64 with D2D_NO_MX=1): the requantiser rides on the next chain in its branch-free form and a
     tile that could clip, holds an exact rounding tie or is cut short by the end of the call is redone sample by sample.
     Full-scale stretches (all-ones / all-zeros bytes clip at both rails), quiet stretches, ragged call sizes and a short last
     call exercise those paths (an exact tie under triangular dither is a 2^-16 event per sample: likely here, certain in
     tests/test_gpu_fullsize.py).  D2D_SPARSE=1 swaps the kernel's dense MFMA chain for the structured-sparse one
     (v_smfmac_i32_32x32x64_i8, its own tap tables): same results."""
+    sparse = 1 if chain == "sparse" else 0
+    M = 2822400 * dsd_rate // out_rate
     if sparse and (filt != "E" or out_rate // dsd_rate > 88200):
         pytest.skip("the sparse chain is compiled for the E filters at M = 32 and 64 only")
+    if chain == "mx" and M < 32:
+        pytest.skip("the fp6 chain serves M = 32 and 64 (at M = 8 and 16 the groups of six phases do not share tap fragments)")
     monkeypatch.setenv("D2D_SPARSE", str(sparse))
+    monkeypatch.setenv("D2D_NO_MX", "0" if chain == "mx" else "1")
     rng = np.random.default_rng(5)
     nbytes = 4096 * 40 * dsd_rate
     chans = []
@@ -306,9 +313,13 @@ def test_pipelined_stereo_kernel_fast_and_careful_tiles(engine_lib, oracle_mod, 
     cuts = [0, 4096 * 7, 4096 * 7 + 4096 * 20, nbytes - 4096, nbytes]
     bufs = [pack_layout([ch[a:b] for ch in chans], "P", 4096) for a, b in zip(cuts[:-1], cuts[1:])]
     g, r, e, o = run_pair(engine_lib, oracle_mod, bufs, kw, 2)
-    assert e.kernel_name().startswith("d2d_fir_mfma3_kernel")
-    targs = [t.strip() for t in e.kernel_name().split("<")[1].rstrip(">").split(",")]      # <MB, NPG, taps (0 = dense chain), dither kind, bytes per sample>
-    assert (targs[2] == "0") == (sparse == 0) and targs[4] == str(bits // 8)
+    targs = [t.strip() for t in e.kernel_name().split("<")[1].rstrip(">").split(",")]
+    if chain == "mx":
+        assert e.kernel_name().startswith("d2d_fir_mx_kernel")                             # <MB, taps, groups, dither kind, bytes per sample>
+        assert targs[0] == str(M // 8) and targs[4] == str(bits // 8)
+    else:
+        assert e.kernel_name().startswith("d2d_fir_mfma3_kernel")                          # <MB, NPG, taps (0 = dense chain), dither kind, bytes per sample>
+        assert (targs[2] == "0") == (sparse == 0) and targs[4] == str(bits // 8)
     assert g.size == r.size and g.size > 0
     assert np.array_equal(g, r)
     pcm = decode_pcm(g, bits, 2)
