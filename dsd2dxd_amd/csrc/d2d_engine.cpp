@@ -821,7 +821,7 @@ int d2d_get_info(const d2d_engine* e, d2d_info* out) {
 // diagnostic, not part of the public header: per-phase wave-cycle sums of the MFMA kernel (D2D_DBG=16)
 void d2d_debug_stamps(unsigned long long* out8) { hipDeviceSynchronize(); mfma_debug_stamps(out8); }
 void d2d_debug_stamps2(unsigned long long* out8) { hipDeviceSynchronize(); mfma2_debug_stamps(out8); }
-void d2d_debug_stamps3(unsigned long long* out8) { hipDeviceSynchronize(); mfma3_debug_stamps(out8); }
+void d2d_debug_stamps3(unsigned long long* out8) { hipDeviceSynchronize(); mfma3_debug_stamps(out8); if (out8[3] == 0) mx_debug_stamps(out8); }
 
 const char* d2d_kernel_name(const d2d_engine* e) {
     if (!e) return "";
@@ -830,7 +830,7 @@ const char* d2d_kernel_name(const d2d_engine* e) {
         if (e->mfma_pipe == 5) {
             const int kind = e->epi.dither == 'T' ? 1 : e->epi.dither == 'R' ? 2 : 0;
             const bool scr = e->fc.resamp || e->noise_shape;
-            m->kname = "d2d_fir_mx_kernel<" + std::to_string(e->Mb) + ", " + std::to_string(e->N) + ", " + std::to_string(mx_groups()) + ", " +
+            m->kname = "d2d_fir_mx_kernel<" + std::to_string(e->Mb) + ", " + std::to_string(e->N) + ", " + std::to_string(mx_groups(e->Mb)) + ", " +
                        std::to_string(scr || e->epi.sample_bytes == 4 ? 0 : kind) + ", " + std::to_string(scr ? 0u : e->epi.sample_bytes) + ">";
             return m->kname.c_str();
         }

@@ -40,6 +40,15 @@ namespace d2d {
 #define D2D_MX_ABL 0
 #endif
 
+#ifndef D2D_MX_STAMPS
+#define D2D_MX_STAMPS 0
+#endif
+#if D2D_MX_STAMPS
+// per-wave s_memtime ticks (-DD2D_MX_STAMPS=1, tools/ab_mx.sh): [0] min, [1] max, [2] sum, [3] count of the waves' lifetimes; sums over all waves of
+// [4] staging (LDS writes, next prefetch, stores), [5] the two regions (chain + epilogue), [6] what follows a region; [7] sum of s_memrealtime
+__device__ unsigned long long d2d_mx_stamps[8] = {~0ull, 0, 0, 0, 0, 0, 0, 0};
+#endif
+
 typedef int v8i __attribute__((ext_vector_type(8)));
 typedef float v16f __attribute__((ext_vector_type(16)));
 typedef int32_t i32x3 __attribute__((ext_vector_type(3)));
@@ -101,18 +110,18 @@ __global__ __launch_bounds__(D2D_MX_THREADS) void d2d_fir_mx_kernel(Mfma2Args m)
     const uint32_t wstride = gridDim.x * m.nwaves;
     const uint32_t r = lane & 31, h = lane >> 5;
 
-    // ---- staging geometry: window dword L of a tile sits at LDS dword L + L / CS (one pad dword per column stride: CS is even) ----
+    // ---- staging geometry: window dword L of a tile sits at LDS dword L + L / CS (one pad dword per column stride: CS is even, so the
+    // 32 lanes of a half read distinct banks); a chunk's four dwords each carry their own address (CS need not be a multiple of 4) ----
     const uint32_t X0 = (uint32_t)(first0 >> 2) & 3u;
     constexpr uint32_t DUMMY = SB - 16u;
-    uint32_t wlo[PF], whi[PF];
+    uint32_t wad[PF][4];
 #pragma unroll
-    for (int i = 0; i < PF; ++i) {
-        const uint32_t q = lane + 64u * i;
-        const uint32_t Lh = 4u * q;
-        whi[i] = 4u * (Lh + Lh / (uint32_t)CS) - 4u * X0;
-        const uint32_t Ll = 4u * q - X0;
-        wlo[i] = q == 0 ? DUMMY : 4u * (Ll + Ll / (uint32_t)CS);
-    }
+    for (int i = 0; i < PF; ++i)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int32_t L = (int32_t)(4u * (lane + 64u * i)) - (int32_t)X0 + k;
+            wad[i][k] = L < 0 ? DUMMY + 4u * k : 4u * ((uint32_t)L + (uint32_t)L / (uint32_t)CS);
+        }
     const uint32_t Bsz = a.B, Lcall = (uint32_t)j0.L;
     const bool pow2B = Bsz >= 16 && (Bsz & (Bsz - 1)) == 0;
     const uint32_t bshift = pow2B ? 31 - __builtin_clz(Bsz) : 0;
@@ -125,8 +134,8 @@ __global__ __launch_bounds__(D2D_MX_THREADS) void d2d_fir_mx_kernel(Mfma2Args m)
 #pragma unroll
     for (int i = 0; i < PF; ++i) { const uint32_t q = lane + 64u * i; lofs[i] = 16u * (q < (uint32_t)NCHK ? q : (uint32_t)NCHK - 1u); }
     const uint32_t chf[2] = {(uint32_t)__builtin_amdgcn_readfirstlane((int)jobs[0].ch), (uint32_t)__builtin_amdgcn_readfirstlane((int)jobs[1].ch)};
-    constexpr int NPFSET = 2;
-    u32x4 pf[NPFSET][PF];
+    // one prefetch register set: a channel's bytes are requested one chain ahead (about two microseconds)
+    u32x4 pf[PF];
     auto issue_loads = [&](uint32_t w, auto cc, auto af) {
         constexpr int c = decltype(cc)::value;
         constexpr bool AF = decltype(af)::value;
@@ -138,33 +147,25 @@ __global__ __launch_bounds__(D2D_MX_THREADS) void d2d_fir_mx_kernel(Mfma2Args m)
             for (int i = 0; i < PF; ++i) {
                 const uint32_t off = r0 + lofs[i];
                 const uint32_t o = __umul24(off >> bshift, jump) + off;
-                pf[c][i] = *reinterpret_cast<D2D_GLOBAL const u32x4*>(as_global(base) + o);
+                pf[i] = *reinterpret_cast<D2D_GLOBAL const u32x4*>(as_global(base) + o);
             }
         } else {
             if constexpr (!AF) {
 #pragma unroll
-                for (int i = 0; i < PF; ++i) pf[c][i] = gather_chunk(jobs + c, Ct, a.B, a.keep, ab + (int32_t)lofs[i]);
+                for (int i = 0; i < PF; ++i) pf[i] = gather_chunk(jobs + c, Ct, a.B, a.keep, ab + (int32_t)lofs[i]);
             }
         }
     };
-    auto write_lds_x = [&](auto cc, auto xc) {
-        constexpr int X = decltype(xc)::value;
+    auto write_lds = [&](auto cc) {
         constexpr int c = decltype(cc)::value;
         uint8_t* buf = wbase + c * SB;
 #pragma unroll
         for (int i = 0; i < PF; ++i)
             if (lane + 64u * i < (uint32_t)NCHK) {
-                const uint32_t v[4] = {pf[c][i].x, pf[c][i].y, pf[c][i].z, pf[c][i].w};
+                const uint32_t v[4] = {pf[i].x, pf[i].y, pf[i].z, pf[i].w};
 #pragma unroll
-                for (int k = 0; k < 4; ++k)
-                    *reinterpret_cast<uint32_t*>(buf + (k < X ? wlo[i] : whi[i]) + 4 * k) = v[k];
+                for (int k = 0; k < 4; ++k) *reinterpret_cast<uint32_t*>(buf + wad[i][k]) = v[k];
             }
-    };
-    auto write_lds = [&](auto cc) {
-        if (X0 == 0) write_lds_x(cc, std::integral_constant<int, 0>{});
-        else if (X0 == 1) write_lds_x(cc, std::integral_constant<int, 1>{});
-        else if (X0 == 2) write_lds_x(cc, std::integral_constant<int, 2>{});
-        else write_lds_x(cc, std::integral_constant<int, 3>{});
     };
 
     // tap fragment f: 16 bytes per lane at f * 1536 + 16 lane, 8 more at f * 1536 + 1024 + 8 lane
@@ -175,13 +176,17 @@ __global__ __launch_bounds__(D2D_MX_THREADS) void d2d_fir_mx_kernel(Mfma2Args m)
     int scA = 0x7f7f7f7f, scB = (int)0x82828282u;          // e8m0 scales: A x 1, B x 8 (every product becomes an integer)
     asm volatile("" : "+v"(scA), "+v"(scB));
     // accumulators start from -2^S: the digit-4 rows (weight 2^20) of every sample
+    // (EB, the dithered integer depths: the accumulators start from zero instead -- sixteen registers less -- and the -2^S rides in the
+    // three-operand add that applies the dither; the extremes are then kept on v + 2^S)
+    constexpr bool EB = (KIND == 1 || KIND == 2) && (SBY == 2 || SBY == 3);
     v16f cinit;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) cinit[i] = (i < 15 && (i % 5) == 4) ? -(float)(1 << (a.scale_bits - 20)) : 0.0f;
-    asm volatile("" : "+v"(cinit));
+    for (int i = 0; i < 16; ++i) cinit[i] = (!EB && i < 15 && (i % 5) == 4) ? -(float)(1 << (a.scale_bits - 20)) : 0.0f;
+    if constexpr (!EB) asm volatile("" : "+v"(cinit));
+    const int32_t kBias = EB ? (1 << a.scale_bits) : 0;
 
     // One chain: TP steps of 64 stream bits; group g runs its NF MFMAs from step DLY g on, with the fragments group 0 read
-    // DLY g steps earlier; LDS reads are issued AHEAD steps before their use; `hook(u)` is whatever else the wave does during step u.
+    // DLY g steps earlier; LDS reads are issued AHEAD steps before their use; `hook(k)` is whatever else the wave does behind its k-th MFMA.
     auto chain = [&](uint32_t c, v16f (&acc)[G], auto&& hook) {
         const uint8_t* rbc = wbase + c * SB + 4u * ((CS + 1) * r + h);
         uint32_t W[TP];
@@ -207,10 +212,12 @@ __global__ __launch_bounds__(D2D_MX_THREADS) void d2d_fir_mx_kernel(Mfma2Args m)
                     const v8i Av = {F4[f].x, F4[f].y, F4[f].z, F4[f].w, (int)F2[f].x, (int)F2[f].y, 0, 0};
                     if constexpr (f == 0) acc[g] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(Av, Bv, cinit, 2, 4, 0, scA, 0, scB);
                     else acc[g] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(Av, Bv, acc[g], 2, 4, 0, scA, 0, scB);
+                    // whatever else the wave does rides BEHIND an MFMA: an in-order wave that issues two MFMAs back to back sits out the
+                    // first one's 32 cycles in the matrix pipe
+                    hook(std::integral_constant<int, mx_slot(MB, NT, G, u, g)>{});
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             });
-            hook(uc);
-            __builtin_amdgcn_sched_barrier(0);
         });
     };
     auto no_hook = [](auto) {};
@@ -224,7 +231,7 @@ __global__ __launch_bounds__(D2D_MX_THREADS) void d2d_fir_mx_kernel(Mfma2Args m)
 #pragma unroll
     for (int c = 0; c < 2; ++c) { rkey[c] = jobs[c].rng_key; rstep[c] = jobs[c].rng_kstep; rlo0[c] = jobs[c].rng_lo0; }
     double pk[2] = {0.0, 0.0};                              // peaks met on the slow path, in LSB
-    int32_t vmn[2] = {0, 0}, vmx[2] = {0, 0};               // running extremes of v on the fast path
+    int32_t vmn[2] = {kBias, kBias}, vmx[2] = {kBias, kBias};   // running extremes of v (EB: of v + 2^S) on the fast path
 
     // constants of the fast epilogue, parked in VGPRs
     const int F_ = SBY == 4 ? 1 : m.fbits;                  // 0 < F <= 16 (integer depths)
@@ -237,6 +244,8 @@ __global__ __launch_bounds__(D2D_MX_THREADS) void d2d_fir_mx_kernel(Mfma2Args m)
     int32_t kHalf = 1 << (F_ - 1);
     asm volatile("" : "+v"(kF), "+v"(kSh), "+v"(kShR), "+v"(kC1), "+v"(kC2), "+v"(kTm), "+v"(k15), "+v"(k32), "+v"(k1024), "+v"(kHalf));
     const int32_t kSafe = (int32_t)(((uint32_t)m.qmax_i - 2u) << F_);
+    int32_t kNegBias = -kBias;
+    asm volatile("" : "+v"(kNegBias));
     const uint32_t lane_fr = (uint32_t)OC * r + 3u * h;     // the lane's first sample inside a tile; sample i = 3 g + q sits at lane_fr + 6 g + q
 
     // v = sum q s of sample q of a group's accumulators: digits S0..S4 = registers 5q .. 5q+4 (exact integers)
@@ -276,11 +285,14 @@ __global__ __launch_bounds__(D2D_MX_THREADS) void d2d_fir_mx_kernel(Mfma2Args m)
         return min(max(rr, m.qmin_i), m.qmax_i);
     };
 
+    int32_t* ob = reinterpret_cast<int32_t*>(wbase + m.off_out);       // the wave's output slice [channel][TILE] (dwords)
     // ---- the fast epilogue of one (tile, channel), cut into jobs that ride on the steps of a chain ----
     struct Fast {
         uint32_t zb;            // hash input of the lane's first sample
-        uint32_t T[NS];         // per sample: the dither term
-        int32_t res[NS];
+        uint32_t T;             // the sample in work: its dither term ...
+        int32_t v;              // ... and its v = sum q s
+        int32_t res[SCR ? NS : 1];
+        int32_t* slot;          // the lane's first sample of this channel in the wave's output slice
         int32_t vprev; uint32_t wprev;
         int32_t tmn, tmx; uint32_t tie;
     };
@@ -288,40 +300,51 @@ __global__ __launch_bounds__(D2D_MX_THREADS) void d2d_fir_mx_kernel(Mfma2Args m)
         const uint32_t first = (uint32_t)j0.n0 + tile * (uint32_t)TILE;
         const uint32_t key_eff = rkey[c] + (first < rlo0[c] ? rstep[c] : 0u);
         f.zb = first + key_eff + lane_fr;
-        f.tmn = 0; f.tmx = 0; f.tie = 0xFFFFu;
+        f.tmn = kBias; f.tmx = kBias; f.tie = 0xFFFFu;
+        f.slot = ob + c * TILE + lane_fr;
     };
-    constexpr int NJ = (KIND == 0 ? NS : 2 * NS);           // jobs per epilogue
+    constexpr int JPS = KIND == 0 ? 2 : 3;                  // jobs per sample: [hash,] recombine, finish
+    constexpr int NJ = JPS * NS;                            // jobs per epilogue
+    constexpr int NSLOT = NF * G;                           // MFMAs of a chain
     auto fast_job = [&](Fast& f, const v16f (&o)[G], auto jc) {
         constexpr int j = decltype(jc)::value;
-        constexpr int i = KIND == 0 ? j : j >> 1;           // sample 0..NS-1: group i / 3, q = i % 3
-        constexpr bool HASH = KIND != 0 && (j & 1) == 0;
-        if constexpr (HASH) {
+        constexpr int i = j / JPS;                          // sample 0..NS-1: group i / 3, q = i % 3
+        constexpr int t = j % JPS + (KIND == 0 ? 1 : 0);    // 0 hash, 1 recombine, 2 finish
+        if constexpr (t == 0) {
             uint32_t z = f.zb + (uint32_t)(6 * (i / 3) + (i % 3));
             z ^= z >> 16; z *= kC1;
             z ^= z >> 15; z *= kC2;
             z ^= z >> 16;
-            if constexpr (KIND == 1) f.T[i] = __builtin_amdgcn_sad_u16(z, 0u, kTm);      // lo16 + hi16 - 32767, units of 2^-16 LSB
-            else f.T[i] = z >> kShR;                                                       // (2*hi16 + 1) >> (17 - F)
+            if constexpr (KIND == 1) f.T = __builtin_amdgcn_sad_u16(z, 0u, kTm);        // lo16 + hi16 - 32767, units of 2^-16 LSB
+            else f.T = z >> kShR;                                                         // (2*hi16 + 1) >> (17 - F)
+            asm volatile("" : "+v"(f.T));
+        } else if constexpr (t == 1) {
+            f.v = recombine(o[i / 3], i % 3);
+            asm volatile("" : "+v"(f.v));
         } else {
-            const int32_t v = recombine(o[i / 3], i % 3);
+            const int32_t v = f.v;
             int32_t s;
             if constexpr (KIND == 1) {
-                s = v + ((int32_t)f.T[i] >> kSh);
-                const uint32_t w = (uint32_t)mx_lshl_add(v, kSh, (int32_t)f.T[i]);         // low 16 bits zero: an exact tie
+                if constexpr (EB) s = v + ((int32_t)f.T >> kSh) + kNegBias; else s = v + ((int32_t)f.T >> kSh);
+                const uint32_t w = (uint32_t)mx_lshl_add(v, kSh, (int32_t)f.T);            // low 16 bits zero: an exact tie
                 if constexpr (i & 1) f.tie = mx_min3_u16(f.tie, f.wprev, w);
                 else if constexpr (i == NS - 1) f.tie = mx_min3_u16(f.tie, w, w);
                 else f.wprev = w;
             } else if constexpr (KIND == 2) {
-                s = v + (int32_t)f.T[i];
+                if constexpr (EB) s = v + (int32_t)f.T + kNegBias; else s = v + (int32_t)f.T;
             } else if constexpr (SBY == 4 || SCR) {
                 s = 0;
             } else {
                 s = v + kHalf + (v >> 31);                                                 // round half away from zero
             }
-            if constexpr (SBY == 4) f.res[i] = __float_as_int((float)v * kFs);
-            else if constexpr (SCR) f.res[i] = v;
-            else f.res[i] = s >> kF;
-            asm volatile("" : "+v"(f.res[i]));         // keep the whole job on this step (the value is only used after the region)
+            int32_t rv;
+            if constexpr (SBY == 4) rv = __float_as_int((float)v * kFs);
+            else if constexpr (SCR) rv = v;
+            else rv = s >> kF;
+            // the sample goes straight into the wave's output slice (the tile that sat there left before this region began); the scratch
+            // flavour keeps it in a register for its store after the region
+            if constexpr (SCR) { f.res[i] = rv; asm volatile("" : "+v"(f.res[i])); }
+            else f.slot[6 * (i / 3) + (i % 3)] = rv;
             if constexpr (!SCR) {
                 if constexpr (i & 1) { f.tmn = mx_min3(f.tmn, f.vprev, v); f.tmx = mx_max3(f.tmx, f.vprev, v); }
                 else if constexpr (i == NS - 1) { f.tmn = min(f.tmn, v); f.tmx = max(f.tmx, v); }
@@ -329,11 +352,12 @@ __global__ __launch_bounds__(D2D_MX_THREADS) void d2d_fir_mx_kernel(Mfma2Args m)
             }
         }
     };
-    auto fast_hook = [&](Fast& f, const v16f (&o)[G], auto uc) {
-        constexpr int u = decltype(uc)::value;
+    // job j rides behind MFMA (j * NSLOT) / NJ of the chain
+    auto fast_hook = [&](Fast& f, const v16f (&o)[G], auto kc) {
+        constexpr int k = decltype(kc)::value;
         static_for<0, NJ>([&](auto jc) {
             constexpr int j = decltype(jc)::value;
-            if constexpr ((j * TP) / NJ == u) fast_job(f, o, jc);
+            if constexpr ((j * NSLOT) / NJ == k) fast_job(f, o, jc);
         });
     };
     auto fast_failed = [&](const Fast& f, uint32_t tile) -> bool {
@@ -342,29 +366,32 @@ __global__ __launch_bounds__(D2D_MX_THREADS) void d2d_fir_mx_kernel(Mfma2Args m)
         if (SCR || (dbg & 8)) return false;
         if (!full || first > 0xFFFFFFFFu - (uint32_t)TILE) return true;
         if constexpr (SBY == 4) return false;                // float: nothing clips, nothing ties
-        const bool bad = (KIND == 1 && (f.tie & 0xFFFFu) == 0) || f.tmx > kSafe || f.tmn < -kSafe;
+        const bool bad = (KIND == 1 && (f.tie & 0xFFFFu) == 0) || f.tmx > kSafe + kBias || f.tmn < kBias - kSafe;
         return __builtin_amdgcn_ballot_w64(bad) != 0;
     };
-    // the careful way: the channel's chain again (its stream bytes are still in that channel's buffer), then sample by sample
-    auto redo = [&](uint32_t cbuf, uint32_t tile, uint32_t c, int32_t (&out)[NS]) {
-        v16f t[G];
-        chain(cbuf, t, no_hook);
+    // the careful way, sample by sample, from a chain's accumulators
+    auto redo_acc = [&](const v16f (&t)[G], uint32_t tile, uint32_t c, int32_t (&out)[NS]) {
         const bool full = tile * (uint32_t)TILE + (uint32_t)TILE <= j0.nout;
         const uint32_t nl_base = tile * (uint32_t)TILE + lane_fr;
         uint32_t vmax = 0;
 #pragma unroll
         for (int i = 0; i < NS; ++i) {
             const uint32_t nl = nl_base + 6u * (i / 3) + (i % 3);
-            const int32_t v = recombine(t[i / 3], i % 3);
+            const int32_t v = recombine(t[i / 3], i % 3) - kBias;
             if constexpr (SBY == 4) out[i] = __float_as_int((float)v * kFs); else out[i] = quant_slow(v, c, nl);
             const uint32_t va = (uint32_t)(v < 0 ? -v : v);
             vmax = max(vmax, full || nl < j0.nout ? va : 0u);
         }
         pk[c] = fmax(pk[c], ldexp((double)vmax, -m.fbits));   // |x| = |v| * 2^-F exactly
     };
+    // ... after the channel's chain run again (its stream bytes are still in that channel's buffer): the tiles at a call's edges
+    auto redo = [&](uint32_t cbuf, uint32_t tile, uint32_t c, int32_t (&out)[NS]) {
+        v16f t[G];
+        chain(cbuf, t, no_hook);
+        redo_acc(t, tile, c, out);
+    };
     auto tile_full = [&](uint32_t tile) -> bool { return tile * (uint32_t)TILE + (uint32_t)TILE <= j0.nout; };
     // a channel's samples of the tile in flight -> the wave's output slice [channel][TILE] (dwords): a lane owns runs of three
-    int32_t* ob = reinterpret_cast<int32_t*>(wbase + m.off_out);
     auto put_samples = [&](uint32_t c, const int32_t (&v)[NS]) {
         int32_t* d = ob + c * TILE + lane_fr;
 #pragma unroll
@@ -431,6 +458,13 @@ __global__ __launch_bounds__(D2D_MX_THREADS) void d2d_fir_mx_kernel(Mfma2Args m)
     auto merge_extremes = [&](const Fast& f, uint32_t c) { vmn[c] = min(vmn[c], f.tmn); vmx[c] = max(vmx[c], f.tmx); };
 
     const uint32_t wv = blockIdx.x * m.nwaves + wave;       // this wave's index among the file's waves
+#if D2D_MX_STAMPS
+    const unsigned long long t_start = __builtin_amdgcn_s_memtime(), rt_start = __builtin_amdgcn_s_memrealtime();
+    unsigned long long st_sum[3] = {0, 0, 0}, st_last = t_start;
+    auto stamp = [&](int slot) { const unsigned long long t = __builtin_amdgcn_s_memtime(); st_sum[slot] += t - st_last; st_last = t; };
+#else
+    auto stamp = [](int) {};
+#endif
     using C0 = std::integral_constant<int, 0>;
     using C1 = std::integral_constant<int, 1>;
     // The pipelined loop over the tiles t_begin + wv + k * wstride < t_end:
@@ -441,7 +475,6 @@ __global__ __launch_bounds__(D2D_MX_THREADS) void d2d_fir_mx_kernel(Mfma2Args m)
         uint32_t wt = t_begin + wv;
         if (wt < t_end) {
             issue_loads(wt, C0{}, af);
-            issue_loads(wt, C1{}, af);
             // AF: every trip issues the same loads and stores in the same order (the first trip stores whatever the slice holds to its
             // own tile, rewritten one trip later; the last trip re-requests its own tile): the compiler can then count its waits
             if (AF && !SCR && !(dbg & 64)) store_tile(wt, true);
@@ -457,12 +490,14 @@ __global__ __launch_bounds__(D2D_MX_THREADS) void d2d_fir_mx_kernel(Mfma2Args m)
             const bool more = wt + wstride < t_end;
             const uint32_t nxt = more ? wt + wstride : wt;
             // ---- region A ----
+            stamp(2);
             wave_sync2();
             if (!(dbg & 4)) {
                 write_lds(C0{});
-                if (AF || more) issue_loads(nxt, C0{}, af);
+                issue_loads(wt, C1{}, af);
             }
             wave_sync2();
+            stamp(0);
             {
                 Fast f;
                 fast_begin(f, pw, 1);
@@ -470,23 +505,25 @@ __global__ __launch_bounds__(D2D_MX_THREADS) void d2d_fir_mx_kernel(Mfma2Args m)
                 else if (dbg & 1) { static_for<0, NJ>([&](auto jc) { fast_job(f, accB, jc); }); for (int g = 0; g < G; ++g) accA[g] = cinit + (float)lane; }
                 else chain(0u, accA, [&](auto uc) { fast_hook(f, accB, uc); });
                 pin(accA);                      // the chain ends HERE (or the compiler sinks its MFMAs into the blocks that use them, behind the epilogue)
+                stamp(1);
                 if (have_prev) {
                     if constexpr (SCR) store_scr(pw, 1, f.res);
                     else {
-                        if (!(dbg & 3) && fast_failed(f, pw)) redo(1u, pw, 1, f.res); else merge_extremes(f, 1);
-                        put_samples(1, f.res);
+                        if (!(dbg & 3) && fast_failed(f, pw)) { int32_t o[NS]; redo_acc(accB, pw, 1, o); put_samples(1, o); } else merge_extremes(f, 1);
                     }
                 }
             }
             // ---- region B ----
+            stamp(2);
             wave_sync2();
             if (!(dbg & 4)) {
                 write_lds(C1{});
-                if (AF || more) issue_loads(nxt, C1{}, af);
+                if (AF || more) issue_loads(nxt, C0{}, af);
             }
             if constexpr (AF) { if (!SCR) store_tile(pw, true); }
             else if (have_prev && !SCR) store_tile(pw);
             wave_sync2();
+            stamp(0);
             {
                 Fast f;
                 fast_begin(f, wt, 0);
@@ -494,10 +531,10 @@ __global__ __launch_bounds__(D2D_MX_THREADS) void d2d_fir_mx_kernel(Mfma2Args m)
                 else if (dbg & 1) { static_for<0, NJ>([&](auto jc) { fast_job(f, accA, jc); }); for (int g = 0; g < G; ++g) accB[g] = cinit - (float)lane; }
                 else chain(1u, accB, [&](auto uc) { fast_hook(f, accA, uc); });
                 pin(accB);
+                stamp(1);
                 if constexpr (SCR) store_scr(wt, 0, f.res);
                 else {
-                    if (!(dbg & 3) && fast_failed(f, wt)) redo(0u, wt, 0, f.res); else merge_extremes(f, 0);
-                    put_samples(0, f.res);
+                    if (!(dbg & 3) && fast_failed(f, wt)) { int32_t o[NS]; redo_acc(accA, wt, 0, o); put_samples(0, o); } else merge_extremes(f, 0);
                 }
             }
             have_prev = true; pw = wt;
@@ -509,8 +546,7 @@ __global__ __launch_bounds__(D2D_MX_THREADS) void d2d_fir_mx_kernel(Mfma2Args m)
             static_for<0, NJ>([&](auto jc) { fast_job(f, accB, jc); });
             if constexpr (SCR) store_scr(pw, 1, f.res);
             else {
-                if (fast_failed(f, pw)) redo(1u, pw, 1, f.res); else merge_extremes(f, 1);
-                put_samples(1, f.res);
+                if (fast_failed(f, pw)) { int32_t o[NS]; redo_acc(accB, pw, 1, o); put_samples(1, o); } else merge_extremes(f, 1);
                 wave_sync2();
                 store_tile(pw);
                 wave_sync2();
@@ -522,8 +558,8 @@ __global__ __launch_bounds__(D2D_MX_THREADS) void d2d_fir_mx_kernel(Mfma2Args m)
     auto slow_tile = [&](uint32_t t) {
         wave_sync2();
         issue_loads(t, C0{}, std::false_type{});
-        issue_loads(t, C1{}, std::false_type{});
         write_lds(C0{});
+        issue_loads(t, C1{}, std::false_type{});
         write_lds(C1{});
         wave_sync2();
         int32_t o0[NS], o1[NS];
@@ -558,12 +594,20 @@ __global__ __launch_bounds__(D2D_MX_THREADS) void d2d_fir_mx_kernel(Mfma2Args m)
         run_loop(0u, nwt, std::false_type{});
     }
 
+#if D2D_MX_STAMPS
+    if (lane == 0) {
+        const unsigned long long dt = __builtin_amdgcn_s_memtime() - t_start;
+        atomicMin(&d2d_mx_stamps[0], dt); atomicMax(&d2d_mx_stamps[1], dt); atomicAdd(&d2d_mx_stamps[2], dt); atomicAdd(&d2d_mx_stamps[3], 1ull);
+        for (int i = 0; i < 3; ++i) atomicAdd(&d2d_mx_stamps[4 + i], st_sum[i]);
+        atomicAdd(&d2d_mx_stamps[7], __builtin_amdgcn_s_memrealtime() - rt_start);      // constant 100 MHz: sum[2] / sum[7] = core clock / 100 MHz
+    }
+#endif
     if constexpr (SCR) return;                              // (stage B / the noise shaper keep the peaks)
     // peak meter: |x| in LSB; undo the power-of-two part exactly
     const double unscale = 1.0 / (double)(1u << (a.epi.bits - 1));   // (float: fbits = S - 31, so dev * 2^-fbits * 2^-31 = dev * 2^-S)
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
-        const int32_t dev = max(vmx[c], -vmn[c]);
+        const int32_t dev = max(vmx[c] - kBias, kBias - vmn[c]);
         double p = fmax(pk[c], ldexp((double)dev, -m.fbits)) * unscale;
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) p = fmax(p, __shfl_xor(p, o));
@@ -573,16 +617,25 @@ __global__ __launch_bounds__(D2D_MX_THREADS) void d2d_fir_mx_kernel(Mfma2Args m)
 }
 
 // ---- host side -------------------------------------------------------------------------------
-// (MB, taps) of the filters this kernel serves: X_M32, C_M32, E_M32, A_M32, A_M64, C_M64, E_M64
+// (MB, taps) of the filters this kernel serves: X_M32, C_M32, E_M32, A_M32, A_M64, C_M64, E_M64.  The file is compiled in four parts
+// (Makefile: D2D_MX_PART), each with the kernels of some shapes; part 0 also holds the table builder and the dispatcher.
+#ifndef D2D_MX_PART
+#define D2D_MX_PART 0
+#endif
 #ifdef D2D_MX_DEV
-#define D2D_MX_SHAPES(X) X(4, 560)
+#define D2D_MX_SHAPES_0(X) X(4, 560)
+#define D2D_MX_SHAPES_1(X)
+#define D2D_MX_SHAPES_2(X)
+#define D2D_MX_SHAPES_3(X)
 #else
-#define D2D_MX_SHAPES(X) X(4, 384) X(4, 512) X(4, 560) X(4, 352) X(8, 688) X(8, 1024) X(8, 1104)
+#define D2D_MX_SHAPES_0(X) X(4, 560) X(4, 352)
+#define D2D_MX_SHAPES_1(X) X(4, 384) X(4, 512)
+#define D2D_MX_SHAPES_2(X) X(8, 688) X(8, 1024)
+#define D2D_MX_SHAPES_3(X) X(8, 1104)
 #endif
-#ifndef D2D_MX_G
-#define D2D_MX_G 2
-#endif
+#define D2D_MX_SHAPES(X) D2D_MX_SHAPES_0(X) D2D_MX_SHAPES_1(X) D2D_MX_SHAPES_2(X) D2D_MX_SHAPES_3(X)
 
+#if D2D_MX_PART == 0
 bool mx_supported(int MB, int NT) {
 #define X(mb, nt) if (MB == mb && NT == nt) return true;
     D2D_MX_SHAPES(X)
@@ -661,6 +714,8 @@ std::vector<int8_t> build_mx_tables(const d2d_filter_def& f, bool msb_first) {
     return t;
 }
 
+#endif   // part 0
+
 template <int MB, int NT, int G, int KIND, int SBY>
 static hipError_t launch_mx_t(Mfma2Args& m, uint32_t max_nout, uint32_t nrows, hipStream_t s) {
     static KernelPrep prep;
@@ -705,10 +760,9 @@ static hipError_t launch_mx_t(Mfma2Args& m, uint32_t max_nout, uint32_t nrows, h
     return hipGetLastError();
 }
 
-hipError_t launch_fir_mx(Mfma2Args& m, int MB, int NT, uint32_t max_nout, uint32_t nrows, hipStream_t s) {
-    constexpr int G = D2D_MX_G;
-#define X(mb, nt)                                                                                                  \
+#define D2D_MX_LAUNCH(mb, nt)                                                                                      \
     if (MB == mb && NT == nt) {                                                                                    \
+        constexpr int G = mx_g(mb);                                                                                \
         if (m.f.to_scratch) return launch_mx_t<mb, nt, G, 0, 0>(m, max_nout, nrows, s);                             \
         if (m.f.epi.sample_bytes == 4) return launch_mx_t<mb, nt, G, 0, 4>(m, max_nout, nrows, s);                  \
         if (m.f.epi.sample_bytes == 2) {                                                                           \
@@ -720,11 +774,49 @@ hipError_t launch_fir_mx(Mfma2Args& m, int MB, int NT, uint32_t max_nout, uint32
         if (m.dkind == 2) return launch_mx_t<mb, nt, G, 2, 3>(m, max_nout, nrows, s);                               \
         return launch_mx_t<mb, nt, G, 0, 3>(m, max_nout, nrows, s);                                                 \
     }
-    D2D_MX_SHAPES(X)
+#define D2D_MX_PART_FN(n, shapes)                                                                                  \
+    hipError_t launch_fir_mx_part##n(Mfma2Args& m, int MB, int NT, uint32_t max_nout, uint32_t nrows, hipStream_t s) { \
+        shapes(D2D_MX_LAUNCH)                                                                                      \
+        return hipErrorInvalidValue;                                                                               \
+    }
+#if D2D_MX_PART == 0
+D2D_MX_PART_FN(0, D2D_MX_SHAPES_0)
+hipError_t launch_fir_mx_part1(Mfma2Args& m, int MB, int NT, uint32_t max_nout, uint32_t nrows, hipStream_t s);
+hipError_t launch_fir_mx_part2(Mfma2Args& m, int MB, int NT, uint32_t max_nout, uint32_t nrows, hipStream_t s);
+hipError_t launch_fir_mx_part3(Mfma2Args& m, int MB, int NT, uint32_t max_nout, uint32_t nrows, hipStream_t s);
+hipError_t launch_fir_mx(Mfma2Args& m, int MB, int NT, uint32_t max_nout, uint32_t nrows, hipStream_t s) {
+#define X(mb, nt) if (MB == mb && NT == nt) return launch_fir_mx_part0(m, MB, NT, max_nout, nrows, s);
+    D2D_MX_SHAPES_0(X)
 #undef X
+#ifndef D2D_MX_DEV
+#define X(mb, nt) if (MB == mb && NT == nt) return launch_fir_mx_part1(m, MB, NT, max_nout, nrows, s);
+    D2D_MX_SHAPES_1(X)
+#undef X
+#define X(mb, nt) if (MB == mb && NT == nt) return launch_fir_mx_part2(m, MB, NT, max_nout, nrows, s);
+    D2D_MX_SHAPES_2(X)
+#undef X
+#define X(mb, nt) if (MB == mb && NT == nt) return launch_fir_mx_part3(m, MB, NT, max_nout, nrows, s);
+    D2D_MX_SHAPES_3(X)
+#undef X
+#endif
     return hipErrorInvalidValue;
 }
-
-int mx_groups() { return D2D_MX_G; }
+int mx_groups(int MB) { return mx_g(MB); }
+#if D2D_MX_STAMPS
+void mx_debug_stamps(unsigned long long out[8]) {
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(d2d_mx_stamps), sizeof(unsigned long long) * 8);
+    unsigned long long z[8] = {~0ull, 0, 0, 0, 0, 0, 0, 0};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(d2d_mx_stamps), z, sizeof(z));
+}
+#else
+void mx_debug_stamps(unsigned long long out[8]) { for (int i = 0; i < 8; ++i) out[i] = 0; }
+#endif
+#elif D2D_MX_PART == 1
+D2D_MX_PART_FN(1, D2D_MX_SHAPES_1)
+#elif D2D_MX_PART == 2
+D2D_MX_PART_FN(2, D2D_MX_SHAPES_2)
+#else
+D2D_MX_PART_FN(3, D2D_MX_SHAPES_3)
+#endif
 
 }  // namespace d2d

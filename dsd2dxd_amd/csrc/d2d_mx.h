@@ -25,10 +25,33 @@ __host__ __device__ constexpr int mx_stream_bytes(int MB, int NT, int G) {
     return (((dw + dw / mx_cs(MB, G) + 4) * 4 + 15) & ~15) + 16;   // + a dummy slot for the dwords in front of the window
 }
 
+// index of the MFMA (step u, group g) among the MFMAs of a chain, in issue order
+__host__ __device__ constexpr int mx_slot(int MB, int NT, int G, int u, int g) {
+    int k = 0;
+    for (int uu = 0; uu <= u; ++uu)
+        for (int gg = 0; gg < G; ++gg) {
+            const int f = uu - mx_dly(MB) * gg;
+            if (f < 0 || f >= mx_nf(MB, NT)) continue;
+            if (uu == u && gg == g) return k;
+            ++k;
+        }
+    return k;
+}
+
+// groups per column: three at M = 32; at M = 64 the tap fragments of three groups do not fit the register file next to two accumulator sets
+#ifndef D2D_MX_G4
+#define D2D_MX_G4 3
+#endif
+#ifndef D2D_MX_G8
+#define D2D_MX_G8 2
+#endif
+__host__ __device__ constexpr int mx_g(int MB) { return MB == 4 ? D2D_MX_G4 : D2D_MX_G8; }
+
 struct Mfma2Args;
 bool mx_supported(int MB, int NT);                 // is a kernel compiled for this shape?
 bool mx_exact(const d2d_filter_def& f);            // do the digit sums of this table recombine exactly in f32?
-int mx_groups();
+int mx_groups(int MB);
+void mx_debug_stamps(unsigned long long out[8]);   // diagnostic (-DD2D_MX_STAMPS=1 builds)
 std::vector<int8_t> build_mx_tables(const d2d_filter_def& f, bool msb_first);
 hipError_t launch_fir_mx(Mfma2Args& m, int MB, int NT, uint32_t max_nout, uint32_t nrows, hipStream_t s);
 
