@@ -82,6 +82,9 @@ __global__ __launch_bounds__(D2D_MX_THREADS) void d2d_fir_mx_kernel(Mfma2Args m)
     constexpr int OC = 6 * G, TILE = 32 * OC, NS = 3 * G;           // outputs per column / per tile; samples per lane and channel
     constexpr int NCHK = mx_chunks(MB, NT, G), PF = mx_pf(MB, NT, G);
     constexpr uint32_t SB = (uint32_t)mx_stream_bytes(MB, NT, G);
+    // FLAT: the column stride is 2 mod 4 dwords, so the 32 lanes of a half already read 16 different banks from an unpadded image: the
+    // chunks go to LDS as they come, one 16-byte write each, at their own 16-byte slots
+    constexpr bool FLAT = mx_flat(MB, G);
     constexpr uint32_t FB = 2u * (SBY ? SBY : 1);                   // bytes per stereo frame
     constexpr uint32_t TBL16 = (uint32_t)NF * (MX_FRAG_BYTES / 16); // 16-byte units of one table variant
     constexpr bool SCR = SBY == 0;
@@ -111,17 +114,20 @@ __global__ __launch_bounds__(D2D_MX_THREADS) void d2d_fir_mx_kernel(Mfma2Args m)
     const uint32_t r = lane & 31, h = lane >> 5;
 
     // ---- staging geometry: window dword L of a tile sits at LDS dword L + L / CS (one pad dword per column stride: CS is even, so the
-    // 32 lanes of a half read distinct banks); a chunk's four dwords each carry their own address (CS need not be a multiple of 4) ----
+    // 32 lanes of a half read distinct banks); a chunk's four dwords each carry their own address (CS need not be a multiple of 4).
+    // FLAT: chunk q at byte 16 q, window dword L at LDS dword L + X0 ----
     const uint32_t X0 = (uint32_t)(first0 >> 2) & 3u;
     constexpr uint32_t DUMMY = SB - 16u;
-    uint32_t wad[PF][4];
+    uint32_t wad[FLAT ? 1 : PF][4];
+    if constexpr (!FLAT) {
 #pragma unroll
-    for (int i = 0; i < PF; ++i)
+        for (int i = 0; i < PF; ++i)
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int32_t L = (int32_t)(4u * (lane + 64u * i)) - (int32_t)X0 + k;
-            wad[i][k] = L < 0 ? DUMMY + 4u * k : 4u * ((uint32_t)L + (uint32_t)L / (uint32_t)CS);
-        }
+            for (int k = 0; k < 4; ++k) {
+                const int32_t L = (int32_t)(4u * (lane + 64u * i)) - (int32_t)X0 + k;
+                wad[i][k] = L < 0 ? DUMMY + 4u * k : 4u * ((uint32_t)L + (uint32_t)L / (uint32_t)CS);
+            }
+    }
     const uint32_t Bsz = a.B, Lcall = (uint32_t)j0.L;
     const bool pow2B = Bsz >= 16 && (Bsz & (Bsz - 1)) == 0;
     const uint32_t bshift = pow2B ? 31 - __builtin_clz(Bsz) : 0;
@@ -162,9 +168,12 @@ __global__ __launch_bounds__(D2D_MX_THREADS) void d2d_fir_mx_kernel(Mfma2Args m)
 #pragma unroll
         for (int i = 0; i < PF; ++i)
             if (lane + 64u * i < (uint32_t)NCHK) {
-                const uint32_t v[4] = {pf[i].x, pf[i].y, pf[i].z, pf[i].w};
+                if constexpr (FLAT) *reinterpret_cast<u32x4*>(buf + 16u * lane + 1024u * i) = pf[i];
+                else {
+                    const uint32_t v[4] = {pf[i].x, pf[i].y, pf[i].z, pf[i].w};
 #pragma unroll
-                for (int k = 0; k < 4; ++k) *reinterpret_cast<uint32_t*>(buf + wad[i][k]) = v[k];
+                    for (int k = 0; k < 4; ++k) *reinterpret_cast<uint32_t*>(buf + wad[i][k]) = v[k];
+                }
             }
     };
 
@@ -188,10 +197,10 @@ __global__ __launch_bounds__(D2D_MX_THREADS) void d2d_fir_mx_kernel(Mfma2Args m)
     // One chain: TP steps of 64 stream bits; group g runs its NF MFMAs from step DLY g on, with the fragments group 0 read
     // DLY g steps earlier; LDS reads are issued AHEAD steps before their use; `hook(k)` is whatever else the wave does behind its k-th MFMA.
     auto chain = [&](uint32_t c, v16f (&acc)[G], auto&& hook) {
-        const uint8_t* rbc = wbase + c * SB + 4u * ((CS + 1) * r + h);
+        const uint8_t* rbc = wbase + c * SB + (FLAT ? 4u * (CS * r + h + X0) : 4u * ((CS + 1) * r + h));
         uint32_t W[TP];
         v4i F4[NF]; u32x2 F2[NF];
-        auto rdW = [&](auto uc) { constexpr int u = decltype(uc)::value; W[u] = *reinterpret_cast<const uint32_t*>(rbc + 4 * (2 * u + (2 * u) / CS)); };
+        auto rdW = [&](auto uc) { constexpr int u = decltype(uc)::value; W[u] = *reinterpret_cast<const uint32_t*>(rbc + 4 * (2 * u + (FLAT ? 0 : (2 * u) / CS))); };
         auto rdF = [&](auto fc) {
             constexpr int f = decltype(fc)::value;
             F4[f] = *reinterpret_cast<const v4i*>(tp16 + MX_FRAG_BYTES * f);

@@ -20,8 +20,13 @@ __host__ __device__ constexpr int mx_nstep(int MB, int NT, int G) { return mx_nf
 __host__ __device__ constexpr int mx_span_dw(int MB, int NT, int G) { return 31 * mx_cs(MB, G) + 2 * mx_nstep(MB, NT, G); }
 __host__ __device__ constexpr int mx_chunks(int MB, int NT, int G) { return (mx_span_dw(MB, NT, G) + 3 + 3) / 4; }   // + up to 3 dwords in front
 __host__ __device__ constexpr int mx_pf(int MB, int NT, int G) { return (mx_chunks(MB, NT, G) + 63) / 64; }
+#ifndef D2D_MX_NOFLAT
+#define D2D_MX_NOFLAT 0     // 1: the padded image for every shape (A/B builds)
+#endif
+__host__ __device__ constexpr bool mx_flat(int MB, int G) { return !D2D_MX_NOFLAT && mx_cs(MB, G) % 4 == 2; }        // unpadded LDS image (see the kernel)
 __host__ __device__ constexpr int mx_stream_bytes(int MB, int NT, int G) {
     const int dw = 4 * mx_chunks(MB, NT, G);
+    if (mx_flat(MB, G)) return 4 * dw + 16;
     return (((dw + dw / mx_cs(MB, G) + 4) * 4 + 15) & ~15) + 16;   // + a dummy slot for the dwords in front of the window
 }
 

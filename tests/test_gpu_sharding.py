@@ -40,7 +40,7 @@ def test_two_engine_processes_share_a_batch_by_files(engine_lib, oracle_mod, tmp
     import shard_worker as W
     from dsd2dxd_amd.shard import shard_range
     parts = _run_ranks("files", 2, tmp_path)
-    assert "mfma" in str(parts[0]["kernel"])
+    assert "mfma" in str(parts[0]["kernel"]) or "d2d_fir_mx" in str(parts[0]["kernel"])
     e1 = engine_lib.Engine(n_files=1, kernel=2, **W.KW_FILES)
     for rank, part in enumerate(parts):
         b, e = shard_range(W.N_FILES, 2, rank)
