@@ -31,6 +31,7 @@ CASES = [
     # name, engine kwargs, channels' content
     ("c2_dsd64_f32_352k8", dict(dsd_rate=1, output_rate=352800, channels=2, fmt="P", endianness="L", block_size=4096, filter="E", bit_depth=32, dither="X", seed=0)),
     ("c3_dsd128_s24_88k2_tpdf", dict(dsd_rate=2, output_rate=88200, channels=2, fmt="P", endianness="L", block_size=4096, filter="E", bit_depth=24, dither="T", seed=1)),
+    ("c3_dsd128_s24_88k2_ns", dict(dsd_rate=2, output_rate=88200, channels=2, fmt="P", endianness="L", block_size=4096, filter="E", bit_depth=24, dither="N", seed=1)),
     ("c4_dsd64_s24_88k2_tpdf", dict(dsd_rate=1, output_rate=88200, channels=2, fmt="P", endianness="L", block_size=4096, filter="E", bit_depth=24, dither="T", seed=206)),
     ("c5_dsd512_8ch_s24_96k", dict(dsd_rate=8, output_rate=96000, channels=8, fmt="I", endianness="M", block_size=1, filter="E", bit_depth=24, dither="T", seed=5)),
     ("dsd64_s16_176k4_rect_xld", dict(dsd_rate=1, output_rate=176400, channels=2, fmt="I", endianness="M", block_size=4096, filter="X", bit_depth=16, dither="R", seed=2, level_db=-4.0)),

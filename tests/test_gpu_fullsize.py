@@ -101,6 +101,27 @@ def test_c3_dsd128_shift_invariance(engine_lib):
     assert np.array_equal(fb[k:], fa[:-k])
 
 
+def test_c3_full_length_noise_shaped(engine_lib, oracle_mod):
+    """config 3 itself at full length: DSD128 stereo 60 s -> 24-bit 88.2 kHz with the noise-shaped dither 'N' at 0 dB (the FIR kernel's
+    scratch flavour + d2d_noise_shape_stereo_kernel's int32 recurrence over 646 segments per channel): one call == five calls (the
+    shaper's two carried errors and the segment restarts survive the call boundaries), and the first 1/16 equals the oracle."""
+    kw = dict(dsd_rate=2, output_rate=88200, channels=2, fmt="P", endianness="L", block_size=4096, filter="E",
+              bit_depth=24, dither="N", seed=3)
+    blocks = 2 * BLOCKS                                  # DSD128: twice the bytes per second
+    nbytes = blocks * 4096
+    files = [pack_layout([synth("sine", nbytes, seed=7, dsd_rate=2), synth("pink", nbytes, seed=8, amp=0.098, dsd_rate=2)], "P", 4096)]
+    one, e1 = _run_batch(engine_lib, files, kw, 2)
+    five, e5 = _run_batch(engine_lib, files, kw, 2, chunks=5)
+    frames = nbytes * 8 // 64
+    assert one[0].size == frames * 6
+    assert np.array_equal(one[0], five[0])
+    for c in range(2):
+        assert e1.peak(c) == e5.peak(c)
+    sl = (blocks // 16) * 4096 * 2
+    r, rf = oracle_mod.Oracle(**kw).translate(files[0][:sl])
+    assert np.array_equal(one[0][:rf * 6], r)
+
+
 def test_c5_full_length_channel_split_and_streaming(engine_lib, oracle_mod):
     """config 5 at its full size: ONE DSD512 8-channel byte-interleaved MSB-first stream of 30 s
     (84.7 MB per channel) -> 24-bit 96 kHz through the 48k cascade.  Properties: four engines that take

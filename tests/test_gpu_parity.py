@@ -216,10 +216,11 @@ def test_known_answers_on_device(engine_lib, kernel):
 
 
 @pytest.mark.parametrize("kernel", KERNELS)
-@pytest.mark.parametrize("dsd_rate,out_rate,bits,level", [(1, 88200, 16, 0.0), (2, 88200, 24, -2.0), (1, 176400, 20, 0.0), (1, 352800, 16, 30.0)])
+@pytest.mark.parametrize("dsd_rate,out_rate,bits,level", [(1, 88200, 16, 0.0), (2, 88200, 24, -2.0), (2, 88200, 24, 0.0), (1, 176400, 20, 0.0), (1, 352800, 16, 30.0)])
 def test_noise_shaped_dither_matches_the_oracle(engine_lib, oracle_mod, dsd_rate, out_rate, bits, level, kernel):
     """the 'N' extension (BASELINE config 3 names a noise-shaped variant): an error-feedback loop per
-    channel, carried across calls and files, identical to the oracle's sequential loop, clipping included"""
+    channel, carried across calls and files, identical to the oracle's sequential loop, clipping included.
+    (2, 88200, 24, 0 dB) is BASELINE config 3 itself: the FIR kernel's scratch flavour + the stereo shaper's int32 recurrence."""
     nbytes = 4096 * 4 + 90
     chans = [synth("sine", nbytes, seed=1, dsd_rate=dsd_rate, amp=0.5), synth("pink", nbytes, seed=2, amp=0.098, dsd_rate=dsd_rate)]
     cuts = [0, 4096, 4096 * 3, nbytes]
