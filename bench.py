@@ -73,25 +73,93 @@ def kernel_source_hash():
     return h.hexdigest()[:16]
 
 
-def spawn_ranks(n):
+def spawn_ranks(n, timeout_s=None):
     """--gpus N without a launcher: start N copies of this script, one per GPU, from a parent that never
     touches the GPU (a process that has initialised HIP must not be replaced or forked on this pool).  Rank 0's
-    JSON line is the parent's output; the parent exits with the worst child code."""
+    JSON line is the parent's output.  The parent watches ALL children: the first one that exits non-zero ends the
+    run -- the others are terminated (they are fresh child processes; nothing is re-executed) -- and its code is the
+    parent's; so does an overall timeout (D2D_BENCH_TIMEOUT seconds, default 1500).  The stderr tail of every failed
+    rank is repeated on the parent's stderr."""
+    import tempfile
+    if timeout_s is None:
+        timeout_s = float(os.environ.get("D2D_BENCH_TIMEOUT", "1500"))
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
-    procs = []
+    procs, logs = [], []
+    out0 = tempfile.TemporaryFile()
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        log = tempfile.TemporaryFile()
+        logs.append(log)
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out0, _ = procs[0].communicate()
-    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
-    for line in out0.decode().splitlines():            # rank 0's JSON line only (gloo chats on stdout)
-        if line.startswith("{"):
+                                      stdout=out0 if r == 0 else subprocess.DEVNULL, stderr=log))
+    t0 = time.monotonic()
+    rc = 0
+    while True:
+        codes = [p.poll() for p in procs]
+        bad = [c for c in codes if c not in (None, 0)]
+        if bad:
+            rc = max(abs(c) for c in bad)
+            break
+        if all(c == 0 for c in codes):
+            break
+        if time.monotonic() - t0 > timeout_s:
+            sys.stderr.write(f"bench.py: ranks still running after {timeout_s:.0f} s, giving up\n")
+            rc = 124
+            break
+        time.sleep(0.05)
+    if rc:
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        for p in procs:
+            try:
+                p.wait(timeout=10)
+            except subprocess.TimeoutExpired:
+                p.kill()
+                p.wait()
+    for r, (p, log) in enumerate(zip(procs, logs)):
+        log.seek(0)
+        text = log.read().decode(errors="replace")
+        if p.returncode not in (0, None) or (rc and r == 0):
+            sys.stderr.write(f"---- rank {r} (exit {p.returncode}) stderr tail ----\n" + "\n".join(text.splitlines()[-15:]) + "\n")
+        elif r == 0:
+            sys.stderr.write(text)
+    out0.seek(0)
+    for line in out0.read().decode(errors="replace").splitlines():      # rank 0's JSON line only (gloo chats on stdout)
+        if line.startswith("{") and not rc:
             print(line)
     sys.stdout.flush()
-    return max(abs(rc) for rc in rcs)
+    return rc
+
+
+def stub_rank(args):
+    """D2D_BENCH_STUB=1: the rank protocol without a GPU (tests/test_sharding_gloo.py drives spawn_ranks with it): rendezvous over gloo,
+    a sleep as the step, MAX over ranks, one JSON line from rank 0.  D2D_BENCH_STUB_FAIL_RANK=r makes rank r die before the rendezvous."""
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    if os.environ.get("D2D_BENCH_STUB_FAIL_RANK", "") == str(rank):
+        sys.stderr.write(f"stub rank {rank}: failing on request\n")
+        sys.exit(7)
+    if world > 1:
+        dist.init_process_group("gloo")
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        time.sleep(0.001 * (rank + 1))
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    if rank == 0:
+        print("gloo-like chatter that is not JSON")
+        print(json.dumps({"metric": "stub", "value": args.steps / dt, "n_gpus": world, "steps": args.steps, "ms_per_step": dt / args.steps * 1e3}))
+    if world > 1:
+        dist.destroy_process_group()
 
 
 def usable_cpus():
@@ -179,6 +247,11 @@ def main():
     ap.add_argument("--shard", default="files", choices=["files", "channels"],
                     help="files: every rank converts its own files (weak scaling, the default).  channels: every rank holds the SAME "
                          "multichannel files and converts its channel range (BASELINE config 5: one stream split by channel; strong scaling)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="--shard files only.  weak (default): --files files on EVERY rank.  strong: --files-total files split over the ranks "
+                         "(SURVEY.md 8d S3: the 512-file batch on 1/2/4/8 GPUs with the same total)")
+    ap.add_argument("--files-total", type=int, default=512, help="--scaling strong: files of the whole job")
+    ap.add_argument("--sustain", type=float, default=2.0, help="seconds of back-to-back steps timed once more after the repetitions (0 = skip)")
     ap.add_argument("--reps", type=int, default=5, help="repetitions of the timed K-step loop (median reported)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pcie", action="store_true", help="skip the host-resident batch (pinned host in/out, upload/convert/download overlapped) that is reported as the extra pcie_inclusive object, never as value")
@@ -187,6 +260,8 @@ def main():
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(args.gpus))
+    if os.environ.get("D2D_BENCH_STUB"):
+        return stub_rank(args)
 
     import torch
     import torch.distributed as dist
@@ -225,6 +300,14 @@ def main():
     ncpu = usable_cpus()
     gen_threads = max(1, min(32, ncpu // max(1, min(world, 8))))
 
+    if args.scaling == "strong":
+        if args.shard != "files":
+            raise SystemExit("--scaling strong goes with --shard files (a channel shard is strong scaling already)")
+        from dsd2dxd_amd.shard import shard_range
+        lo, hi = shard_range(args.files_total, world, rank)
+        args.files = hi - lo
+        if args.files < 1:
+            raise SystemExit(f"--scaling strong: rank {rank} of {world} gets no file of {args.files_total}")
     if args.distinct <= 0:
         args.distinct = args.files
     ch_first, ch_count = 0, channels
@@ -241,7 +324,9 @@ def main():
 
     # the shared filter tables: rank 0's copy is broadcast over RCCL and adopted by the others
     if world > 1:
-        nb = eng.tables_bytes()
+        nb_t = torch.tensor([eng.tables_bytes()], dtype=torch.int64, device=cdev)      # rank 0's size (another variant may differ)
+        dist.broadcast(nb_t, src=0)
+        nb = int(nb_t.item())
         blob = torch.empty(nb, dtype=torch.uint8, device=dev)
         if rank == 0:
             eng.tables_export_device(blob.data_ptr(), nb, stream)
@@ -251,7 +336,12 @@ def main():
         blob.copy_(wire)
         torch.cuda.synchronize()
         if rank != 0:
-            eng.tables_import_device(blob.data_ptr(), nb, stream)
+            # a rank whose conversion differs from rank 0's (an uneven channel shard: other channel count, hence another kernel and
+            # table variant) is refused by the blob's header and keeps the tables it built itself
+            try:
+                eng.tables_import_device(blob.data_ptr(), nb, stream)
+            except d.D2DError as ex:
+                sys.stderr.write(f"rank {rank}: keeping its own filter tables ({ex})\n")
 
     # device-resident inputs and outputs (distinct files uploaded once, tiled by pointer)
     uniq = {}
@@ -298,11 +388,28 @@ def main():
         dts.append(dt)
     fir_ms, step_ms, launches = eng.profile_read_all()
     eng.profile_enable(False)
+    # does the rate hold for seconds (the chip sets its clock by the load)?  One more timed stretch of back-to-back steps
+    sustained = None
+    if args.sustain > 0:
+        n_sus = max(args.steps, int(args.sustain / max(min(dts) / args.steps, 1e-6)) + 1)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n_sus):
+            step()
+        torch.cuda.synchronize()
+        dts_ = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dts_], dtype=torch.float64, device=cdev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dts_ = float(t.item())
+        sustained = {"steps": n_sus, "seconds": round(dts_, 3), "ms_per_step": round(dts_ / n_sus * 1e3, 4)}
     dts_sorted = sorted(dts)
     dt = dts_sorted[len(dts_sorted) // 2]                 # the median repetition is the reported one
 
     samples_per_step_rank = frames * ch_count * args.files
-    if world > 1 and args.shard == "channels":
+    if world > 1 and (args.shard == "channels" or args.scaling == "strong"):
         tot = torch.tensor([samples_per_step_rank], dtype=torch.int64, device=cdev)
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
         total_samples = int(tot.item()) * args.steps
@@ -323,7 +430,7 @@ def main():
         "value": round(value, 3), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True,
         "repetitions": {"n": len(dts), "ms_per_step_min": round(dts_sorted[0] / args.steps * 1e3, 4), "ms_per_step_max": round(dts_sorted[-1] / args.steps * 1e3, 4),
-                        "ms_per_step_all": [round(x / args.steps * 1e3, 4) for x in dts]}, "scaling": "weak" if args.shard == "files" else "strong",
+                        "ms_per_step_all": [round(x / args.steps * 1e3, 4) for x in dts]}, "scaling": "weak" if args.shard == "files" and args.scaling == "weak" else "strong",
         "vs_baseline": None, "dtype": "f64", "data": "synthetic (2nd-order 1-bit modulator: 1 kHz-family sines at 0.352 FS and pink noise at ~0.1 RMS; %d distinct files per rank%s)" % (min(args.distinct, args.files), "" if args.distinct >= args.files else " tiled to %d" % args.files),
         "config": {"workload": f"{args.workload}: {args.files} files/GPU x {blocks * 4096 * 8 / (DSD64 * dsd_rate):.1f} s, {'planar 4096-B LSB-first' if fmt == 'P' else 'byte-interleaved MSB-first'} {channels} ch -> {bits}-bit {out_rate} Hz, dither {dither}, filter E ({eng.info()['ntaps']} taps, M={M:g})",
                    "files_per_gpu": args.files, "seconds_per_file": round(blocks * 4096 * 8 / (DSD64 * dsd_rate), 3),
@@ -335,14 +442,22 @@ def main():
                      "kernel_ms": round(roof_s * 1e3, 4), "fir_kernel_ms": round(fir_s * 1e3, 4), "step_kernels_ms": round(step_s * 1e3, 4),
                      "algorithmic_bytes_per_launch": int(alg_bytes), "bytes_per_output_sample": bytes_per_sample},
     }
+    if sustained:
+        sustained["value"] = round(total_samples / args.steps * sustained["steps"] / sustained["seconds"] / 1e6, 3)
+        out["sustained"] = sustained
+    # a development library (D2D_AMD_LIB, tools/ab_*.sh) is named in the line, and no counter traffic is cited for it
+    alt_lib = os.environ.get("D2D_AMD_LIB")
+    if alt_lib:
+        with open(alt_lib, "rb") as fl:
+            out["config"]["library"] = {"path": alt_lib, "sha16": hashlib.sha256(fl.read()).hexdigest()[:16]}
     # PMC traffic is collected in separate rocprofv3 --pmc passes (tools/prof.sh -> profiles/); bench.py only cites an
     # entry taken on exactly these kernel sources and this workload size, otherwise traffic stays null
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as fjs:
             pmc = json.load(fjs)
-        ent = pmc.get(eng.kernel_name(), {}).get(args.workload)
-        if (ent and ent.get("kernel_src_sha16") == kernel_source_hash() and ent.get("files_per_gpu") == args.files
-                and abs(ent.get("seconds_per_file", 0) - out["config"]["seconds_per_file"]) < 1e-3 and scope == "kernel"):
+        ent = pmc.get(eng.kernel_name() if scope == "kernel" else "step", {}).get(args.workload)      # "step": every kernel of the step, summed
+        if (ent and not alt_lib and ent.get("kernel_src_sha16") == kernel_source_hash() and ent.get("files_per_gpu") == args.files
+                and abs(ent.get("seconds_per_file", 0) - out["config"]["seconds_per_file"]) < 1e-3):
             out["roofline"]["traffic"] = ent["hbm_bytes_per_launch"]
     except Exception:
         pass

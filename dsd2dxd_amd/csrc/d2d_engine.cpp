@@ -53,6 +53,7 @@ struct d2d_engine {
     bool mfma_v2 = false;      // the two-group matrix-core kernel (d2d_kernels_mfma2.hip) serves this shape
     int mfma_pipe = 0;         // ... through its software-pipelined variant (d2d_kernels_mfma3.hip; stereo 24-bit at 0 dB): 3 dense chain, 4 sparse chain
     std::string kname;
+    std::string launched;      // the FIR kernel the last call really enqueued (d2d_last_launched_kernel)
     Epilogue epi{};
     std::string err;
     std::vector<FileState> files;
@@ -191,6 +192,8 @@ static void fir_args_static(const d2d_engine* e, FirArgs& a) {
     a.pipelined = (uint32_t)e->mfma_pipe;
     a.mx_exact = mx_exact(*e->fc.fir) ? 1u : 0u;
 }
+
+namespace d2d { thread_local const char* d2d_last_launched_kernel = nullptr; }
 
 extern "C" {
 
@@ -476,6 +479,7 @@ int d2d_translate_batch_device(d2d_engine* e, d2d_file_io* io, uint32_t n_files,
         }
     }
     if (pe) HIPCHK(e, hipEventRecord(pe->second, s));
+    if (max_nx && d2d_last_launched_kernel) e->launched = d2d_last_launched_kernel;
     if (e->noise_shape) {
         NoiseShapeArgs ns{};
         ns.jobs = e->d_jobs; ns.state = e->d_ns[e->ns_cur]; ns.state_next = e->d_ns[e->ns_cur ^ 1]; ns.dump = e->d_ns_dump;
@@ -825,6 +829,7 @@ void d2d_debug_stamps3(unsigned long long* out8) { hipDeviceSynchronize(); mfma3
 
 const char* d2d_kernel_name(const d2d_engine* e) {
     if (!e) return "";
+    if (!e->launched.empty()) return e->launched.c_str();      // what the last call launched; before the first call: what the dispatch will choose
     if (e->kernel == D2D_KERNEL_MFMA && e->mfma_v2) {
         d2d_engine* m = const_cast<d2d_engine*>(e);
         if (e->mfma_pipe == 5) {

@@ -454,9 +454,10 @@ __global__ __launch_bounds__(256) void d2d_noise_shape_kernel(NoiseShapeArgs a) 
             const uint32_t nb = nfr * fb;
             if (dw_ok && nfr == NS_FRAMES) {
                 uint32_t o = 0;
+                typedef uint32_t u32x4_dw __attribute__((ext_vector_type(4), aligned(4)));      // dw_ok: dword-aligned, no more
                 for (; o + 16 <= nb; o += 16)
-                    *reinterpret_cast<D2D_GLOBAL u32x4*>(as_global(g + o)) =
-                        u32x4{*reinterpret_cast<uint32_t*>(row + o), *reinterpret_cast<uint32_t*>(row + o + 4),
+                    *reinterpret_cast<D2D_GLOBAL u32x4_dw*>(as_global(g + o)) =
+                        u32x4_dw{*reinterpret_cast<uint32_t*>(row + o), *reinterpret_cast<uint32_t*>(row + o + 4),
                               *reinterpret_cast<uint32_t*>(row + o + 8), *reinterpret_cast<uint32_t*>(row + o + 12)};
                 for (; o < nb; o += 4) *reinterpret_cast<D2D_GLOBAL uint32_t*>(as_global(g + o)) = *reinterpret_cast<uint32_t*>(row + o);
             } else {
@@ -571,7 +572,8 @@ __global__ __launch_bounds__(256) void d2d_noise_shape_stereo_kernel(NoiseShapeA
     };
 
     typedef int32_t i32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
-    typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
+    // (the frames' byte offset inside a file is a multiple of the frame size only: 2-byte alignment is all these 16-byte stores may claim)
+    typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(2)));
     typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
     constexpr int NH = NW / 2;                                             // each lane of the pair packs half of the group: frames 0-3 (left lane) or 4-7
     // Rounds of four groups = one 128-byte line of a lane's integers, requested a round ahead and consumed from registers (a line is
@@ -738,6 +740,7 @@ static hipError_t launch_lut_t(const FirArgs& a, dim3 grid, hipStream_t s) {
     hipError_t e = prep.max_dynamic_lds(reinterpret_cast<const void*>(&d2d_fir_lut_kernel<MB>), 160 * 1024);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(d2d_fir_lut_kernel<MB>, grid, dim3(LUT_THREADS), smem, s, a);
+    d2d_last_launched_kernel = launched_name<MB>("d2d_fir_lut_kernel");
     return hipGetLastError();
 }
 

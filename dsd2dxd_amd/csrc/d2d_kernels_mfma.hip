@@ -771,6 +771,7 @@ static hipError_t launch_mfma_t(const MfmaArgs& m, size_t smem, uint32_t nwt_max
     const uint32_t need = (nwt_max + m.nwaves - 1) / m.nwaves;
     if (gx > need) gx = need;
     hipLaunchKernelGGL((d2d_fir_mfma_kernel<MB>), dim3(gx, nfiles), dim3(64 * m.nwaves), smem, s, m);
+    d2d_last_launched_kernel = launched_name<MB>("d2d_fir_mfma_kernel");
     return hipGetLastError();
 }
 

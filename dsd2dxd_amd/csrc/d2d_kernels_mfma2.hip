@@ -796,9 +796,11 @@ static hipError_t launch_mfma2_t(Mfma2Args& m, size_t smem, uint32_t nwt_max, ui
     int blocks_per_cu, ncu;
     {
         std::lock_guard<std::mutex> g(prep.mu);
+        // the cache is keyed on what the caller ASKED for (LDS bytes, waves); what the register file then admitted is kept next to it
         if (prep.blocks_per_cu[dev] == 0 || smem != prep.smem_seen[dev] || m.nwaves != prep.nwaves_seen[dev]) {
             hipDeviceProp_t prop;
             if ((e = hipGetDeviceProperties(&prop, dev)) != hipSuccess) return e;
+            const size_t smem_req = smem; const uint32_t nwaves_req = m.nwaves;
             // the register file may admit fewer waves than LDS does: shrink the block until one fits
             int nb = 0;
             for (;;) {
@@ -810,11 +812,11 @@ static hipError_t launch_mfma2_t(Mfma2Args& m, size_t smem, uint32_t nwt_max, ui
             }
             prep.ncu[dev] = prop.multiProcessorCount;
             prep.blocks_per_cu[dev] = nb < 1 ? 1 : nb;
-            prep.smem_seen[dev] = smem; prep.nwaves_seen[dev] = m.nwaves;
-            prep.smem_used[dev] = smem;
+            prep.smem_seen[dev] = smem_req; prep.nwaves_seen[dev] = nwaves_req;
+            prep.smem_used[dev] = smem; prep.nwaves_used[dev] = m.nwaves;
         }
         blocks_per_cu = prep.blocks_per_cu[dev]; ncu = prep.ncu[dev];
-        m.nwaves = prep.nwaves_seen[dev]; smem = prep.smem_used[dev];
+        m.nwaves = prep.nwaves_used[dev]; smem = prep.smem_used[dev];
     }
     // every wave loops over its share of the wave-tiles: launch what is resident at once
     uint32_t gx = (uint32_t)(ncu * blocks_per_cu) / nrows;
@@ -822,6 +824,7 @@ static hipError_t launch_mfma2_t(Mfma2Args& m, size_t smem, uint32_t nwt_max, ui
     const uint32_t need = (nwt_max + m.nwaves - 1) / m.nwaves;
     if (gx > need) gx = need;
     hipLaunchKernelGGL((d2d_fir_mfma2_kernel<MB, NPG, CH, EPI>), dim3(gx, nrows), dim3(64 * m.nwaves), smem, s, m);
+    d2d_last_launched_kernel = launched_name<MB, NPG, CH, EPI>("d2d_fir_mfma2_kernel");
     return hipGetLastError();
 }
 

@@ -824,6 +824,7 @@ static hipError_t launch_mfma3_t(Mfma2Args& m, uint32_t nwt_max, uint32_t nrows,
     const uint32_t need = (nwt_max + m.nwaves - 1) / m.nwaves;
     if (gx > need) gx = need;
     hipLaunchKernelGGL((d2d_fir_mfma3_kernel<MB, NPG, NT, KIND, SBY>), dim3(gx, nrows), dim3(64 * m.nwaves), smem, s, m);
+    d2d_last_launched_kernel = launched_name<MB, NPG, NT, KIND, SBY>("d2d_fir_mfma3_kernel");
     return hipGetLastError();
 }
 

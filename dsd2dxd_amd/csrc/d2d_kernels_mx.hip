@@ -766,6 +766,7 @@ static hipError_t launch_mx_t(Mfma2Args& m, uint32_t max_nout, uint32_t nrows, h
     const uint32_t need = (nwt_max + m.nwaves - 1) / m.nwaves;
     if (gx > need) gx = need;
     hipLaunchKernelGGL((d2d_fir_mx_kernel<MB, NT, G, KIND, SBY>), dim3(gx, nrows), dim3(64 * m.nwaves), smem, s, m);
+    d2d_last_launched_kernel = launched_name<MB, NT, G, KIND, SBY>("d2d_fir_mx_kernel");
     return hipGetLastError();
 }
 

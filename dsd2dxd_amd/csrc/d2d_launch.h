@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include <mutex>
+#include <string>
 
 #include "d2d_internal.h"
 
@@ -20,6 +21,7 @@ struct KernelPrep {
     size_t smem_seen[MAX_DEV] = {};
     size_t smem_used[MAX_DEV] = {};
     uint32_t nwaves_seen[MAX_DEV] = {};
+    uint32_t nwaves_used[MAX_DEV] = {};
 
     hipError_t max_dynamic_lds(const void* fn, int bytes, int* dev_out = nullptr) {
         int dev = 0;
@@ -34,6 +36,21 @@ struct KernelPrep {
         return e;
     }
 };
+
+// The FIR kernel a launcher has just enqueued, spelled the way rocprofv3 prints it: set by every launch_fir_* at the point of the launch
+// (per thread: engines are driven from one thread each), copied into the engine by d2d_translate_batch_device, so that
+// d2d_kernel_name() reports what ran and not what the dispatch logic predicts.
+extern thread_local const char* d2d_last_launched_kernel;
+template <int... V>
+inline const char* launched_name(const char* base) {
+    static const std::string n = [&] {
+        std::string s = std::string(base) + "<";
+        const int v[] = {V...};
+        for (size_t i = 0; i < sizeof...(V); ++i) s += (i ? ", " : "") + std::to_string(v[i]);
+        return s + ">";
+    }();
+    return n.c_str();
+}
 
 size_t lut_smem_bytes(const FirArgs& a, int MB);
 uint32_t lut_outputs_per_tile(int MB);

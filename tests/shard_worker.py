@@ -44,17 +44,26 @@ def main():
         bufs = [stream_bytes()]
     eng = d.Engine(n_files=max(nf, 1), kernel=d.KERNEL_MFMA, device=0, **kw)
     # rank 0's tables, broadcast and adopted: what bench.py does before its timed region
-    nb = eng.tables_bytes()
+    # (a rank whose conversion differs from rank 0's -- an uneven channel shard: another channel count, hence another kernel and table
+    # variant -- is refused by the blob's header and keeps the tables it built itself)
+    nb_t = torch.tensor([eng.tables_bytes()], dtype=torch.int64)
+    dist.broadcast(nb_t, src=0)
+    nb = int(nb_t.item())
     blob = torch.zeros(nb, dtype=torch.uint8, device=dev)
     if rank == 0:
         eng.tables_export_device(blob.data_ptr(), nb)
     torch.cuda.synchronize()
     wire = blob.cpu()
     dist.broadcast(wire, src=0)
+    adopted = rank == 0
     if rank != 0:
         blob.copy_(wire)
         torch.cuda.synchronize()
-        eng.tables_import_device(blob.data_ptr(), nb)
+        try:
+            eng.tables_import_device(blob.data_ptr(), nb)
+            adopted = True
+        except d.D2DError:
+            adopted = False
     # the conversion: device-resident batch in two calls (state carried), like the bench's step
     res = {}
     if nf:
@@ -85,6 +94,7 @@ def main():
             res["pcm%d" % i] = np.concatenate(outs[i])
         res["peaks"] = np.array([[eng.peak(c, file=i) for c in range(eng.out_channels)] for i in range(len(bufs))])
     res["kernel"] = np.array(eng.kernel_name())
+    res["adopted"] = np.array(adopted)
     np.savez(out, **res)
     dist.barrier()
     dist.destroy_process_group()

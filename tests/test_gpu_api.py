@@ -59,6 +59,18 @@ def test_table_blob_roundtrip(engine_lib, oracle_mod, kernel, out_rate):
     with pytest.raises(engine_lib.D2DError) as ei:
         other.tables_import_device(blob.data_ptr(), nb)
     assert ei.value.code == -1
+    # the same filter under another conversion can mean another table variant of the SAME size (one channel: the two-group kernel, plane 0
+    # unmasked; stereo at 0 dB: a pipelined kernel, every plane masked or fp6 digits): the header names the variant and the import is refused
+    if kernel == 2 and out_rate == 88200:
+        mono = engine_lib.Engine(kernel=kernel, **dict(kw, channels=1))
+        with pytest.raises(engine_lib.D2DError):
+            mono.tables_import_device(blob.data_ptr(), nb)
+        lvl = engine_lib.Engine(kernel=kernel, **dict(kw, level_db=-3.0))
+        with pytest.raises(engine_lib.D2DError):
+            lvl.tables_import_device(blob.data_ptr(), nb)
+        g3, f3 = lvl.translate(buf)                       # ... and the refused engine still converts with its own tables
+        r3, rf3 = oracle_mod.Oracle(**dict(kw, level_db=-3.0)).translate(buf)
+        assert f3 == rf3 and np.array_equal(g3, r3[:rf3 * 6])
     # a corrupted table must change the output (i.e. the imported bytes are really what runs)
     blob[256:(3 * nb) // 4] = 0      # (the MFMA table holds four byte-shift variants; wipe most of them)
     b2 = engine_lib.Engine(kernel=kernel, **kw)

@@ -70,3 +70,20 @@ def test_two_engine_processes_split_one_stream_by_channel(engine_lib, oracle_mod
     for r in range(2):
         first, count = shard_channels(W.CHN, 2, r)
         assert list(parts[r]["peaks"][0]) == [full.peak(first + c) for c in range(count)] == [o.peak(first + c) for c in range(count)]
+
+
+def test_uneven_channel_shards_keep_their_own_tables(engine_lib, oracle_mod, tmp_path):
+    """six channels over four ranks = 2, 2, 1, 1: the two-channel ranks run a pipelined stereo kernel, the one-channel ranks the
+    two-group kernel with ANOTHER tap-table variant of the same size: the blob's header names the variant, the import
+    is refused, the rank keeps the tables it built -- and the union is still the oracle's conversion"""
+    import shard_worker as W
+    from dsd2dxd_amd.shard import merge_channel_frames, shard_channels
+    parts = _run_ranks("channels", 4, tmp_path)
+    counts = [shard_channels(W.CHN, 4, r)[1] for r in range(4)]
+    assert counts == [2, 2, 1, 1]
+    assert [bool(p["adopted"]) for p in parts] == [True, True, False, False]
+    assert str(parts[0]["kernel"]) != str(parts[2]["kernel"])
+    buf = W.stream_bytes()
+    want, fr = oracle_mod.Oracle(**W.KW_CHANNELS).translate(buf)
+    merged = merge_channel_frames([(*shard_channels(W.CHN, 4, r), parts[r]["pcm0"]) for r in range(4)], 3)
+    assert np.array_equal(merged, want[:fr * W.CHN * 3])

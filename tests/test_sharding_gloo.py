@@ -160,3 +160,34 @@ def test_two_ranks_split_one_stream_by_channel():
         p.join(30)
         assert p.exitcode == 0
     assert same and ranges == [(0, 3), (3, 2)]
+
+
+def _bench(*args, **env):
+    import subprocess
+    e = dict(os.environ, D2D_BENCH_STUB="1", D2D_BENCH_TIMEOUT="120", **env)
+    e.pop("WORLD_SIZE", None); e.pop("RANK", None)
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], env=e, capture_output=True, text=True, timeout=300)
+
+
+def test_bench_starts_its_ranks_and_prints_rank0s_line():
+    """bench.py --gpus 2 with no launcher: the parent starts two ranks (here the stub step over gloo: no GPU), prints rank 0's JSON
+    line and nothing else, exits 0"""
+    import json
+    r = _bench("--gpus", "2", "--steps", "3")
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["steps"] == 3 and j["ms_per_step"] >= 2.0      # MAX over ranks: rank 1 sleeps 2 ms per step
+
+
+def test_bench_ends_the_run_when_a_rank_dies_early():
+    """a rank that dies before the rendezvous (bad device ordinal, refused table import ...) must not leave rank 0 waiting in
+    init_process_group: the parent terminates the others, repeats the failed rank's stderr and exits with its code"""
+    import time
+    t0 = time.monotonic()
+    r = _bench("--gpus", "2", "--steps", "3", D2D_BENCH_STUB_FAIL_RANK="1")
+    assert r.returncode == 7
+    assert time.monotonic() - t0 < 60
+    assert "rank 1" in r.stderr and "failing on request" in r.stderr
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]

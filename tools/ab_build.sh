@@ -1,25 +1,26 @@
 #!/bin/bash
-# A/B helper: build a variant library ab/<name>/libdsd2dxd_amd.so: the tree's pipelined kernel (d2d_kernels_mfma3.hip) compiled with
-# extra hipcc flags (e.g. -DD2D_M3_ABL=2 -DD2D_M3_STAMPS=1), linked with the tree's other objects (make first).
-# Select it at run time with D2D_AMD_LIB=$PWD/ab/<name>/libdsd2dxd_amd.so (dsd2dxd_amd/_capi.py, development only).
+# A/B helper: ab/<name>/libdsd2dxd_amd.so = the tree's library with ONE translation unit recompiled with extra hipcc flags
+# (make the tree first).  Select it at run time with D2D_AMD_LIB=$PWD/ab/<name>/libdsd2dxd_amd.so (dsd2dxd_amd/_capi.py,
+# development only; bench.py names such a library in its line and cites no counter traffic for it).
+#   tools/ab_build.sh <name> <unit> [flags...]     unit: mx | mfma3 | kernels
+#     mx       d2d_kernels_mx.hip, E_M32 shape only (-DD2D_MX_DEV): -DD2D_MX_ABL=<mask> -DD2D_MX_STAMPS=1 -DD2D_MX_G4=<groups> -DD2D_MX_NOFLAT=1
+#     mfma3    d2d_kernels_mfma3.hip (both parts):                   -DD2D_M3_ABL=<mask> -DD2D_M3_STAMPS=1
+#     kernels  d2d_kernels.hip (LUT, resampler, de-interleave, noise shaping)
 set -e
-NAME=$1; shift
-ROOT=$(cd "$(dirname "$0")/.." && pwd); CS=$ROOT/dsd2dxd_amd/csrc
-mkdir -p $ROOT/ab/$NAME
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wall -Wno-unused-function -Wno-unused-value -Wno-unused-result \
-    -I$CS -I$ROOT/filters "$@" -c $CS/d2d_kernels_mfma3.hip -o $ROOT/ab/$NAME/d2d_kernels_mfma3.o
-M2O=$CS/d2d_kernels_mfma2.o
-if [ -n "$AB_M2" ]; then    # AB_M2=1: the two-group kernel's file too (it builds the tap tables both kernels read)
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wall -Wno-unused-function -Wno-unused-value -Wno-unused-result \
-    -I$CS -I$ROOT/filters -DD2D_M2_DEV "$@" -c $CS/d2d_kernels_mfma2.hip -o $ROOT/ab/$NAME/d2d_kernels_mfma2.o
-  M2O=$ROOT/ab/$NAME/d2d_kernels_mfma2.o
-fi
-P1O=$CS/d2d_kernels_mfma3b.o
-if [ -n "$AB_P1" ]; then    # AB_P1=1: the second half of the pipelined kernel's instantiations too (16-bit, float, scratch)
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wall -Wno-unused-function -Wno-unused-value -Wno-unused-result \
-    -I$CS -I$ROOT/filters -DD2D_M3_PART=1 "$@" -c $CS/d2d_kernels_mfma3.hip -o $ROOT/ab/$NAME/d2d_kernels_mfma3b.o
-  P1O=$ROOT/ab/$NAME/d2d_kernels_mfma3b.o
-fi
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $ROOT/ab/$NAME/libdsd2dxd_amd.so $CS/d2d_kernels.o $CS/d2d_kernels_mfma.o $M2O $ROOT/ab/$NAME/d2d_kernels_mfma3.o $P1O \
-  $CS/d2d_engine.o $CS/host/dsd_reader.o $CS/host/pcm_sink.o $CS/host/id3_tag.o $CS/host/rdsd2pcm.o $CS/host/rdsd2pcm_c.o -lpthread
+NAME=$1; UNIT=$2; shift; shift
+ROOT=$(cd "$(dirname "$0")/.." && pwd); CS=$ROOT/dsd2dxd_amd/csrc; O=$ROOT/ab/$NAME
+mkdir -p $O
+FL="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wall -Wno-unused-function -Wno-unused-value -Wno-unused-result -I$CS -I$ROOT/filters"
+K=$CS/d2d_kernels.o; M3=$CS/d2d_kernels_mfma3.o; M3B=$CS/d2d_kernels_mfma3b.o; MX="$CS/d2d_kernels_mx.o $CS/d2d_kernels_mx1.o $CS/d2d_kernels_mx2.o $CS/d2d_kernels_mx3.o"
+case $UNIT in
+  mx)      /opt/rocm/bin/hipcc $FL -DD2D_MX_DEV=1 "$@" -c $CS/d2d_kernels_mx.hip -o $O/d2d_kernels_mx.o; MX=$O/d2d_kernels_mx.o ;;
+  mfma3)   /opt/rocm/bin/hipcc $FL "$@" -c $CS/d2d_kernels_mfma3.hip -o $O/d2d_kernels_mfma3.o & /opt/rocm/bin/hipcc $FL -DD2D_M3_PART=1 "$@" -c $CS/d2d_kernels_mfma3.hip -o $O/d2d_kernels_mfma3b.o; wait
+           M3=$O/d2d_kernels_mfma3.o; M3B=$O/d2d_kernels_mfma3b.o ;;
+  kernels) /opt/rocm/bin/hipcc $FL "$@" -c $CS/d2d_kernels.hip -o $O/d2d_kernels.o; K=$O/d2d_kernels.o ;;
+  *) echo "unit: mx | mfma3 | kernels"; exit 2 ;;
+esac
+# (the engine sees the geometry macros too: groups per column name the kernel)
+/opt/rocm/bin/hipcc $FL -x hip "$@" -c $CS/d2d_engine.cpp -o $O/d2d_engine.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $O/libdsd2dxd_amd.so $K $CS/d2d_kernels_mfma.o $CS/d2d_kernels_mfma2.o $M3 $M3B $MX $O/d2d_engine.o \
+  $CS/host/dsd_reader.o $CS/host/pcm_sink.o $CS/host/id3_tag.o $CS/host/rdsd2pcm.o $CS/host/rdsd2pcm_c.o -lpthread
 echo built ab/$NAME
