@@ -296,8 +296,8 @@ int d2d_create(const d2d_params* params, uint32_t n_files, d2d_engine** out) {
         CK(hipMemcpy(e->d_fir_tables, t.data(), e->fir_table_bytes, hipMemcpyHostToDevice));
     }
     if (e->fc.resamp) {
-        const std::vector<double> rt = build_resamp_table(*e->fc.resamp, e->S);
-        e->resamp_bytes = sizeof(double) * rt.size();
+        const std::vector<int8_t> rt = build_resamp2_table(*e->fc.resamp);
+        e->resamp_bytes = rt.size();
         CK(hipMalloc((void**)&e->d_resamp, e->resamp_bytes));
         CK(hipMemcpy(e->d_resamp, rt.data(), e->resamp_bytes, hipMemcpyHostToDevice));
         e->xs_hist = (uint32_t)e->fc.resamp->P;
@@ -491,13 +491,11 @@ int d2d_translate_batch_device(d2d_engine* e, d2d_file_io* io, uint32_t n_files,
         e->ns_cur ^= 1;
     }
     if (e->fc.resamp) {
-        ResampArgs r{};
-        r.jobs = e->d_jobs; r.coef = e->d_resamp;
-        r.L = (uint32_t)e->fc.resamp->L; r.Mdn = (uint32_t)e->fc.resamp->Mdn; r.P = (uint32_t)e->fc.resamp->P;
-        r.nsteps = resamp_nsteps(*e->fc.resamp);
-        r.epi = e->epi;
-        HIPCHK(e, launch_resample(r, max_frames, e->nstreams, s));
-        HIPCHK(e, launch_xhist(e->d_jobs, e->nstreams, r.P, s));
+        Rs2Args r{};
+        r.jobs = e->d_jobs; r.tables = reinterpret_cast<const uint8_t*>(e->d_resamp);
+        r.S = e->S; r.epi = e->epi;
+        HIPCHK(e, launch_resample2(r, *e->fc.resamp, max_frames, n_files, s));
+        HIPCHK(e, launch_xhist(e->d_jobs, e->nstreams, (uint32_t)e->fc.resamp->P, s));
     }
     HIPCHK(e, launch_history(e->d_jobs, e->nstreams, e->Cin, e->B, e->keep, s));
     if (ps) HIPCHK(e, hipEventRecord(ps->second, s));

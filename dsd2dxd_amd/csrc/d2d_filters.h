@@ -81,34 +81,6 @@ inline LutLayout lut_layout(int MB, int Wb) {
     return g;
 }
 
-// Stage-B coefficients packed for d2d_resample_kernel: task w serves the four residues r = 4w..4w+3 of
-// m = L*c + r; output r reads x[Mdn*c + b_r - k] with b_r = Mdn*r div L and phase Mdn*r mod L.  At step
-// s every output of the task is fed the same sample x[Mdn*c + b_max - s], so its coefficient is
-// g[phase_r][s - (b_max - b_r)], zero outside [0, P).  The stage-A samples arrive as the integers
-// X = x * 2^S, so the table holds g * 2^-S: (g * 2^-S) * X is the same real number as g * x, and the
-// fma that follows rounds it identically.  Layout [L/4][nsteps][4] (+ 16 zeros),
-// nsteps a multiple of 4.
-inline uint32_t resamp_nsteps(const d2d_resamp_def& r) {
-    int dmax = 0;
-    for (int w = 0; w < r.L / 4; ++w) dmax = std::max(dmax, (r.Mdn * (4 * w + 3)) / r.L - (r.Mdn * 4 * w) / r.L);
-    return (uint32_t)((r.P + dmax + 3) & ~3);   // the kernel walks four steps per trip
-}
-inline std::vector<double> build_resamp_table(const d2d_resamp_def& r, int S) {
-    const uint32_t nsteps = resamp_nsteps(r);
-    std::vector<double> t((size_t)(r.L / 4) * nsteps * 4 + 16, 0.0);   // + one look-ahead trip
-    for (int w = 0; w < r.L / 4; ++w) {
-        const int bmax = (r.Mdn * (4 * w + 3)) / r.L;
-        for (int j = 0; j < 4; ++j) {
-            const int res = 4 * w + j, b = (r.Mdn * res) / r.L, phase = (r.Mdn * res) % r.L;
-            for (uint32_t s = 0; s < nsteps; ++s) {
-                const int k = (int)s - (bmax - b);
-                if (k >= 0 && k < r.P) t[((size_t)w * nsteps + s) * 4 + j] = std::ldexp(r.coef[(size_t)phase * r.P + k], -S);
-            }
-        }
-    }
-    return t;
-}
-
 // Nibble tables [ntab][16] of f64.  Table pad+2w serves the HIGH nibble of window byte w, table
 // pad+2w+1 its LOW nibble, whatever the stream's bit order: for MSB-first streams the high nibble
 // holds the four EARLIER samples (bit 7 first), for LSB-first streams the LATER four (bit 4 first).

@@ -80,19 +80,19 @@ struct NoiseShapeArgs {
     Epilogue epi;
 };
 
-struct ResampArgs {
+// stage B of the 48k cascade (d2d_kernels_rs.hip): launch_resample2 fills everything but jobs, tables, S and epi
+struct Rs2Args {
     const StreamJob* jobs;
-    const double*    coef;     // packed per task: [L/4][nsteps][4] and pre-scaled by 2^-S, see build_resamp_table()
-    uint32_t L, Mdn, P;
-    uint32_t nsteps;           // P + widest spread of window starts inside a task
+    const uint8_t* tables;     // [L/4 blocks][NSTEP][64 lanes][16 bytes] coefficient fragments, then the blocks' row offsets (uint32)
+    uint32_t L, Mdn, P, NB, NSTEP;
+    int32_t  S, T;             // x = X * 2^-S (stage A's table), g = G * 2^-T (filters/filter_tables.inc)
+    uint32_t cw;               // channels a wave converts one after the other: 2 for an even channel count, else 1
+    uint32_t nwaves;
+    uint32_t off_waves, wave_lds, off_out;   // LDS: start of the per-wave regions, bytes per wave, the wave's output slice inside its region
+    uint32_t fast;             // 1: unit gain at 24 or 16 bits, dither T / R / X: the all-integer requantiser (with its guard band)
+    uint32_t dkind;            // 0 none, 1 triangular, 2 rectangular
+    int32_t  fbits;            // F = S + T - (bits - 1): y in LSB is v * 2^-F
     Epilogue epi;
-    // integer-depth epilogue as data (filled by launch_resample): d = fma(term, dmul, dadd), clamp, shift
-    double   dmul, dadd;
-    uint32_t dsel;             // 1: triangular term, 0: rectangular term (dmul = 0: no dither)
-    uint32_t kind;             // requantiser instantiation: 0 int/none, 1 triangular, 2 rectangular, 3 float FPD, 4 float cast
-    uint32_t reserved2;
-    uint32_t qsh;              // 4 for 20-bit samples in a 24-bit container, else 0
-    int32_t  qmin_i, qmax_i;
 };
 
 // blob header for d2d_tables_export/import

@@ -3,8 +3,7 @@
 //   d2d_fir_lut_kernel<MB>   1-bit FIR decimator by M = 8*MB through per-nibble lookup tables in LDS
 //                            (the per-bit-pattern LUT path; 16-entry f64 tables are bank-conflict free:
 //                            16 entries x 8 B = 32 banks, equal indices broadcast)
-//   d2d_resample_kernel<NT>  stage B of the 48k cascade: polyphase L/147 on f64, one fma per tap; lanes run along
-//                            cycles of L outputs so that coefficients are wave-uniform scalar operands
+//   (stage B of the 48k cascade lives in d2d_kernels_rs.hip: int8 matrix cores)
 //   d2d_deinterleave_kernel  byte-interleaved multichannel input -> the planar 4096-byte-block layout (one LDS pass)
 //   d2d_noise_shape_kernel   the 'N' dither extension: error-feedback requantiser, one lane per (8192-output segment, channel)
 //   d2d_history_kernel       carries the last `keep` bytes per channel to the next call
@@ -100,204 +99,6 @@ __global__ __launch_bounds__(LUT_THREADS) void d2d_fir_lut_kernel(FirArgs a) {
     }
     if (!a.to_scratch) block_peak_max(pk, job.peak, red);
 }
-
-// Stage B of the 48k cascade: y[m] = sum_k g[phi][k] * x[i_m - k],
-// t = Mdn*m, i_m = t div L, phi = t mod L; acc = fma(g, x, acc) for k ascending (the oracle's order,
-// so the f64 result is bit-identical).
-//
-// Write m = L*c + r ("cycle" c, "residue" r).  Then i_m = Mdn*c + (Mdn*r div L) and phi = Mdn*r mod L:
-// the phase depends on r only and the window moves by exactly Mdn samples per cycle.  So
-//   * a wave takes RS_R consecutive residues and its 64 lanes take 64 consecutive cycles: every
-//     coefficient is wave-uniform (scalar loads from a table packed per task, no LDS traffic), and
-//     the lanes' x reads are Mdn doubles apart -- Mdn = 147 is odd, so the 64-bit LDS reads are
-//     bank-conflict free;
-//   * the RS_R outputs of a lane have windows that start within a few samples of each other, so one
-//     x read per step feeds all RS_R fma chains; an output whose window has not started / has ended
-//     gets a zero coefficient (fma(0, x, acc) == acc exactly: acc is never -0 and x is finite), each
-//     chain still sees its own taps in ascending k.
-// A tile = 64 cycles of one stream: its Mdn*64 + nsteps stage-A samples are staged in LDS, the
-// results go back through LDS so that the PCM stores run along consecutive frames.
-#ifndef D2D_DIAG
-#define D2D_DIAG 0
-#endif
-constexpr int RS_R = 4;
-constexpr int RS_WAVES = 10;                         // L/RS_R tasks per tile = RS_WAVES * NT
-constexpr int RS_THREADS = RS_WAVES * 64;
-constexpr int RS_LD = 4;                             // a tile's samples: RS_LD 16-byte loads per thread
-typedef double rs_d8 __attribute__((ext_vector_type(8)));
-typedef const __attribute__((address_space(4))) rs_d8* rs_const8;
-constexpr int RS_XPAD = 4;                           // doubles in front of the x tile (look-ahead reads)
-
-// rng32() for an output `o` of this call (index m0 + o; lo32 arithmetic wraps like the counter does)
-// Integer depths track the peak in the scaled domain (|y*scale|, scale = gain*2^(bits-1): an exact
-// power-of-two multiple of |y*gain|, undone once at the end) and run the branch-free form of
-// quantise_int() that the MFMA kernel uses; float output takes quantise_f32().
-// KIND (fixed per launch, dispatched once per tile so that a lane's outputs share a basic block):
-// 0 integer, no dither; 1 triangular; 2 rectangular; 3 float with FPD; 4 float, plain cast.
-template <int KIND>
-__device__ __forceinline__ uint32_t quantise_bits(const ResampArgs& a, const StreamJob& job, double y, uint32_t o, double& pk) {
-    if constexpr (KIND >= 3) {
-        pk = fmax(pk, fabs(y * a.epi.gain));
-        if constexpr (KIND == 3) return __float_as_uint(quantise_f32(a.epi, y, rng32(job, (uint64_t)(job.rng_lo0 + o))));
-        return __float_as_uint((float)(y * a.epi.gain));              // quantise_f32() without FPD
-    }
-    const double x = y * a.epi.scale;
-    asm("v_max_f64 %0, %1, |%2|" : "=v"(pk) : "v"(pk), "v"(x));      // plain max with the |.| source modifier
-    double q = x + 0.0;                                               // "none": what quantise_int() does
-    if constexpr (KIND == 1 || KIND == 2) {
-        const uint32_t z = rng32(job, (uint64_t)(job.rng_lo0 + o));
-        const uint32_t term = KIND == 1 ? (z & 0xFFFFu) + (z >> 16) + 1u : 2u * (z >> 16) + 1u;
-        q = x + fma((double)term, a.dmul, a.dadd);
-    }
-    int32_t ri;
-    const double t = q + copysign(0.5, q);
-    asm("v_cvt_i32_f64 %0, %1" : "=v"(ri) : "v"(t));            // truncates toward zero and saturates
-    return (uint32_t)(min(max(ri, a.qmin_i), a.qmax_i) << a.qsh);
-}
-
-// One trip = four steps of the four fma chains.  The coefficients (two scalar 64-byte loads) and the
-// samples (LDS) of the NEXT trip are requested first and consumed by an empty asm after the fmas: the
-// only wait of the trip then sits behind the arithmetic.  (Scalar loads return out of order, so any
-// wait placed while one is in flight is a wait for everything: it must not precede the fmas.)
-#define RS_TRIP(Q, CA, CB, X0, X1, X2, X3, NA, NB, Y0, Y1, Y2, Y3)                                   \
-    {                                                                                                 \
-        NA = t8[2 * (Q) + 2]; NB = t8[2 * (Q) + 3];                 /* past the end: table padding */ \
-        const double* xn = xp - 4 * (int32_t)((Q) + 1);             /* below the tile: RS_XPAD */     \
-        Y0 = xn[0]; Y1 = xn[-1]; Y2 = xn[-2]; Y3 = xn[-3];                                            \
-        __builtin_amdgcn_sched_barrier(0);                                                            \
-        _Pragma("unroll") for (int j = 0; j < RS_R; ++j) acc[j] = fma(CA[j], X0, acc[j]);             \
-        _Pragma("unroll") for (int j = 0; j < RS_R; ++j) acc[j] = fma(CA[4 + j], X1, acc[j]);         \
-        _Pragma("unroll") for (int j = 0; j < RS_R; ++j) acc[j] = fma(CB[j], X2, acc[j]);             \
-        _Pragma("unroll") for (int j = 0; j < RS_R; ++j) acc[j] = fma(CB[4 + j], X3, acc[j]);         \
-        __builtin_amdgcn_sched_barrier(0);                                                            \
-        asm volatile("" :: "s"(NA), "s"(NB), "v"(Y0), "v"(Y1), "v"(Y2), "v"(Y3));                     \
-    }
-
-template <int NT>
-__global__ __launch_bounds__(RS_THREADS, 6) void d2d_resample_kernel(ResampArgs a, uint32_t dbg_arg) {
-    const uint32_t dbg = D2D_DIAG ? dbg_arg : 0u;            // ablation switches exist in a -DD2D_DIAG=1 build only
-    extern __shared__ __align__(16) unsigned char smem[];
-    double* xt = reinterpret_cast<double*>(smem);              // [RS_XPAD + Mdn*64 + nsteps], later the output tile
-    uint32_t* ot = reinterpret_cast<uint32_t*>(smem);          // [64][L + 1]: the odd row stride keeps the lanes' writes on distinct banks
-    __shared__ double red[RS_WAVES];
-    const StreamJob& job = a.jobs[blockIdx.y];
-    const uint32_t tid = threadIdx.x, lane = tid & 63;
-    const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const uint32_t L = a.L, Mdn = a.Mdn, nsteps = a.nsteps;
-    const uint64_t m0 = job.m0;
-    const uint32_t nres = job.nres;
-    const uint64_t c_first = m0 / L;
-    const uint32_t ntiles = nres ? (uint32_t)(((m0 + nres - 1) / L - c_first) / 64 + 1) : 0;
-    // everything below is 32-bit and relative to this call: stage-A indices to job.n0, outputs to m0
-    const int32_t rel_c0 = (int32_t)((int64_t)(Mdn * c_first) - (int64_t)job.n0) - (int32_t)nsteps + 1;
-    const int32_t o_c0 = (int32_t)((int64_t)(c_first * L) - (int64_t)m0);        // in (-L, 0]
-    const int32_t jlo = -(int32_t)a.P, jhi = (int32_t)job.nout - 1;
-    const D2D_GLOBAL int32_t* xs = as_global(job.xs);
-    const uint32_t inv_L = (uint32_t)(((1ull << 32) + L - 1) / L);   // i / L == umulhi(i, inv_L) for i < 64 * L
-    const uint32_t nxa = (Mdn * 64 + nsteps + 3 + 3) & ~3u;     // tile samples incl. up to 3 of alignment slack
-    double pk = 0.0;
-    // The tile's stage-A integers start at rel0 (relative to job.n0); they are fetched from rel0a =
-    // rel0 rounded down to a multiple of 4 so that a thread moves 16 aligned bytes per load, and land
-    // converted to f64 (exact) at xt[RS_XPAD + i] for sample rel0a + i.  Samples that do not exist are
-    // 0: they only ever meet a zero coefficient or an output that is not stored.  The NEXT tile is
-    // fetched into registers before this tile's fma loop starts, so the HBM reads run under the
-    // arithmetic instead of in a phase of their own.
-    typedef int32_t i32x4 __attribute__((ext_vector_type(4)));
-    i32x4 v[RS_LD];
-    auto prefetch = [&](uint32_t tile) {
-        const int32_t rel0a = (rel_c0 + (int32_t)(tile * 64 * Mdn)) & ~3;
-        if (rel0a >= jlo && rel0a + (int32_t)(4 * RS_LD * RS_THREADS) - 1 <= jhi) {       // interior tile
-#pragma unroll
-            for (int u = 0; u < RS_LD; ++u)
-                v[u] = *reinterpret_cast<const D2D_GLOBAL i32x4*>(xs + (rel0a + (int32_t)(4 * (u * RS_THREADS + tid))));
-        } else {
-#pragma unroll
-            for (int u = 0; u < RS_LD; ++u)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int32_t j = rel0a + (int32_t)(4 * (u * RS_THREADS + tid) + e);
-                    const int32_t x = xs[min(max(j, jlo), jhi)];                          // always a valid address
-                    v[u][e] = (j >= jlo && j <= jhi) ? x : 0;
-                }
-        }
-    };
-    if (blockIdx.x < ntiles && !(dbg & 256)) prefetch(blockIdx.x);
-    for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const int32_t rel0 = rel_c0 + (int32_t)(tile * 64 * Mdn);
-        __syncthreads();
-#pragma unroll
-        for (int u = 0; u < RS_LD; ++u) {
-            const uint32_t i = 4 * (u * RS_THREADS + tid);
-            if (i < nxa) {
-                typedef double f64x2 __attribute__((ext_vector_type(2)));
-                f64x2* dst = reinterpret_cast<f64x2*>(xt + RS_XPAD + i);
-                dst[0] = f64x2{(double)v[u][0], (double)v[u][1]};
-                dst[1] = f64x2{(double)v[u][2], (double)v[u][3]};
-            }
-        }
-        __syncthreads();
-        if (tile + gridDim.x < ntiles && !(dbg & 256)) prefetch(tile + gridDim.x);
-
-        const int32_t o_lane = o_c0 + (int32_t)((tile * 64 + lane) * L);         // output of residue 0 in this lane's cycle
-        uint32_t bits[NT][RS_R];
-#pragma unroll
-        for (int tix = 0; tix < NT; ++tix) {
-            const uint32_t task = wave + RS_WAVES * tix;
-            const uint32_t bmax = (Mdn * (RS_R * task + RS_R - 1)) / L;
-            rs_const8 t8 = (rs_const8)(a.coef) + (size_t)task * (nsteps / 2);     // 2 steps per rs_d8
-            const double* xp = xt + RS_XPAD + (rel0 & 3) + (Mdn * lane + bmax + nsteps - 1);
-            double acc[RS_R];
-#pragma unroll
-            for (int j = 0; j < RS_R; ++j) acc[j] = 0.0;
-            rs_d8 ca = t8[0], cb = t8[1], da, db;
-            double x0 = xp[0], x1 = xp[-1], x2 = xp[-2], x3 = xp[-3], y0, y1, y2, y3;
-            asm volatile("" :: "s"(ca), "s"(cb), "v"(x0), "v"(x1), "v"(x2), "v"(x3));   // enter the loop with nothing in flight
-            const uint32_t ntrips = (dbg & 512) ? 2u : nsteps / 4;
-            uint32_t q = 0;
-            for (; q + 2 <= ntrips; q += 2) {
-                RS_TRIP(q, ca, cb, x0, x1, x2, x3, da, db, y0, y1, y2, y3)
-                RS_TRIP(q + 1, da, db, y0, y1, y2, y3, ca, cb, x0, x1, x2, x3)
-            }
-            if (q < ntrips) RS_TRIP(q, ca, cb, x0, x1, x2, x3, da, db, y0, y1, y2, y3)
-            auto requantise = [&](auto kind_tag) {
-#pragma unroll
-                for (int j = 0; j < RS_R; ++j) {
-                    const int32_t o = o_lane + (int32_t)(RS_R * task + j);
-                    bits[tix][j] = ((uint32_t)o < nres && !(dbg & 1024)) ? quantise_bits<decltype(kind_tag)::value>(a, job, acc[j], (uint32_t)o, pk) : 0u;
-                }
-            };
-            switch (a.kind) {
-                case 1: requantise(std::integral_constant<int, 1>{}); break;
-                case 2: requantise(std::integral_constant<int, 2>{}); break;
-                case 3: requantise(std::integral_constant<int, 3>{}); break;
-                case 4: requantise(std::integral_constant<int, 4>{}); break;
-                default: requantise(std::integral_constant<int, 0>{}); break;
-            }
-        }
-        __syncthreads();                                       // all x reads done: reuse the tile for output
-#pragma unroll
-        for (int tix = 0; tix < NT; ++tix)
-#pragma unroll
-            for (int j = 0; j < RS_R; ++j) ot[lane * (L + 1) + RS_R * (wave + RS_WAVES * tix) + j] = bits[tix][j];
-        __syncthreads();
-        const uint32_t sample_bytes = a.epi.sample_bytes;
-        const uint32_t frame_bytes = sample_bytes * a.epi.channels;
-        uint8_t* pcm = reinterpret_cast<uint8_t*>(job.out) + job.och * sample_bytes;
-        const int32_t o_tile = o_c0 + (int32_t)(tile * 64 * L);
-        for (uint32_t i = tid; i < 64 * L; i += RS_THREADS) {
-            const int32_t o = o_tile + (int32_t)i;
-            if ((uint32_t)o >= nres || (dbg & 2048)) continue;
-            const uint32_t w = ot[i + __umulhi(i, inv_L)];      // row i / L, one pad word per row
-            uint8_t* dst = pcm + (size_t)(uint32_t)o * frame_bytes;
-            if (sample_bytes == 4) *reinterpret_cast<uint32_t*>(dst) = w;
-            else if (sample_bytes == 2) *reinterpret_cast<uint16_t*>(dst) = (uint16_t)w;
-            else { dst[0] = (uint8_t)w; dst[1] = (uint8_t)(w >> 8); dst[2] = (uint8_t)(w >> 16); }
-        }
-    }
-    if (a.epi.bits != 32) pk *= 1.0 / (double)(1u << (a.epi.bits - 1));   // exact: back to |y*gain|
-    block_peak_max(pk, job.peak, red);
-}
-#undef RS_TRIP
 
 // Byte-interleaved input (DFF, `-f I`: c0 c1 c0 c1 ...) -> the planar 4096-byte-block layout the FIR
 // kernels stream with 16-byte loads.  A block moves DI_TILE bytes per channel: the source range is
@@ -770,42 +571,6 @@ const char* lut_kernel_name(int MB) {
         case 4: return "d2d_fir_lut_kernel<4>";
         case 8: return "d2d_fir_lut_kernel<8>";
         default: return "d2d_fir_lut_kernel<16>";
-    }
-}
-
-template <int NT>
-static hipError_t launch_resample_nt(const ResampArgs& a, uint32_t gx, uint32_t nstreams, size_t smem, hipStream_t s) {
-    static const char* env = getenv("D2D_DBG");
-    const uint32_t dbg = env ? (uint32_t)atoi(env) : 0u;   // diagnostic ablation mask, 0 in production
-    static KernelPrep prep;
-    hipError_t e = prep.max_dynamic_lds(reinterpret_cast<const void*>(&d2d_resample_kernel<NT>), 80 * 1024 - 256);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(d2d_resample_kernel<NT>, dim3(gx, nstreams), dim3(RS_THREADS), smem, s, a, dbg);
-    return hipGetLastError();
-}
-
-hipError_t launch_resample(const ResampArgs& a_in, uint32_t max_out, uint32_t nstreams, hipStream_t s) {
-    if (nstreams == 0 || max_out == 0) return hipSuccess;
-    ResampArgs a = a_in;
-    a.dsel = a.epi.dither == 'T' ? 1u : 0u;
-    a.kind = a.epi.bits == 32 ? (a.epi.dither == 'F' ? 3u : 4u) : (a.epi.dither == 'T' ? 1u : (a.epi.dither == 'R' ? 2u : 0u));
-    a.dmul = a.epi.dither == 'T' ? 0x1p-16 : (a.epi.dither == 'R' ? 0x1p-17 : 0.0);
-    a.dadd = a.epi.dither == 'T' ? -1.0 : (a.epi.dither == 'R' ? -0.5 : 0.0);
-    a.qsh = a.epi.bits == 20 ? 4u : 0u;
-    a.qmin_i = a.epi.bits == 32 ? 0 : -(1 << (a.epi.bits - 1));
-    a.qmax_i = a.epi.bits == 32 ? 0 : (1 << (a.epi.bits - 1)) - 1;
-    const uint32_t ntask = a.L / RS_R;
-    if (a.L % RS_R || ntask % RS_WAVES || a.nsteps % 4) return hipErrorInvalidValue;
-    const size_t smem = std::max((size_t)(RS_XPAD + ((a.Mdn * 64 + a.nsteps + 6) & ~3u)) * sizeof(double), (size_t)64 * (a.L + 1) * 4);
-    if (smem > 80 * 1024 - 256 || a.Mdn * 64 + a.nsteps + 6 > 4 * RS_LD * RS_THREADS) return hipErrorInvalidValue;
-    uint32_t gx = max_out / (64 * a.L) + 2;                    // tiles follow absolute cycles: up to one extra
-    const uint32_t cap = (4096 + nstreams - 1) / nstreams;
-    if (gx > cap) gx = cap;
-    switch (ntask / RS_WAVES) {
-        case 1: return launch_resample_nt<1>(a, gx, nstreams, smem, s);
-        case 2: return launch_resample_nt<2>(a, gx, nstreams, smem, s);
-        case 4: return launch_resample_nt<4>(a, gx, nstreams, smem, s);
-        default: return hipErrorInvalidValue;
     }
 }
 

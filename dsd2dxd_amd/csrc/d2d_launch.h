@@ -5,6 +5,9 @@
 #include <mutex>
 #include <string>
 
+#include <vector>
+
+#include "../../filters/filter_tables.inc"
 #include "d2d_internal.h"
 
 namespace d2d {
@@ -56,7 +59,8 @@ size_t lut_smem_bytes(const FirArgs& a, int MB);
 uint32_t lut_outputs_per_tile(int MB);
 const char* lut_kernel_name(int MB);
 hipError_t launch_fir_lut(const FirArgs& a, int MB, uint32_t max_tiles, uint32_t nstreams, hipStream_t s);
-hipError_t launch_resample(const ResampArgs& a, uint32_t max_out, uint32_t nstreams, hipStream_t s);
+hipError_t launch_resample2(Rs2Args& a, const d2d_resamp_def& r, uint32_t max_out, uint32_t nfiles, hipStream_t s);
+std::vector<int8_t> build_resamp2_table(const d2d_resamp_def& r);
 hipError_t launch_deinterleave(const StreamJob* jobs, uint32_t nfiles, uint32_t C, uint32_t streams_per_file, uint32_t max_L, hipStream_t s);
 hipError_t launch_noise_shape(const NoiseShapeArgs& a, hipStream_t s);
 hipError_t launch_history(const StreamJob* jobs, uint32_t nstreams, uint32_t C, uint32_t B, uint32_t keep, hipStream_t s);

@@ -321,19 +321,24 @@ int orc_translate_f64(orc_ctx* c, const uint8_t* dsd, size_t L, void* pcm_out, s
                 if (pcm_out) emit_sample(c, xs[i], ch, c->nfir + i, (uint8_t*)pcm_out + i * fb + ch * sb);
             }
         } else {
-            /* a4: stage B, polyphase L/147: y[m] = sum_k g[phi][k] * x[i_m - k], t = 147 m,
-             * i_m = t div L, phi = t mod L; one fma per tap, k ascending [own: fixed order] */
+            /* a4: stage B, polyphase L/147: y[m] = sum_k g[phi][k] * x[i_m - k], t = 147 m, i_m = t div L, phi = t mod L.
+             * [own] Both factors are dyadic: x = X * 2^-S with the exact stage-A integers X = sum q s, g = G * 2^-T with the 2^-T grid of
+             * filters/filter_tables.inc (every phase sums to 1 exactly), so the sum is the exact integer sum G X (|.| < 2^61); it is
+             * converted to f64 once (round to nearest even) and scaled by the power of two.  Any order of summation gives this number:
+             * the GPU forms it from int8 limbs on the matrix cores. */
             int P = c->r->P, Lr = c->r->L, Md = c->r->Mdn;
             memcpy(x, c->xhist + (size_t)ch * P, sizeof(double) * (size_t)P); /* x[-P..-1] relative to nfir */
+            const double xscale = ldexp(1.0, c->S), yscale = ldexp(1.0, -(c->S + c->r->T));
             for (size_t o = 0; o < nframes; ++o) {
                 uint64_t m = c->nres + o;
                 uint64_t t = m * (uint64_t)Md;
                 uint64_t im = t / (uint64_t)Lr; int phi = (int)(t % (uint64_t)Lr);
-                const double* g = c->r->coef + (size_t)phi * P;
+                const int32_t* g = c->r->q + (size_t)phi * P;
                 /* absolute index im -> xs[im - nfir]; history below */
                 const double* xp = xs + (ptrdiff_t)(im - c->nfir);
-                double acc = 0.0;
-                for (int k = 0; k < P; ++k) acc = fma(g[k], xp[-k], acc);
+                int64_t isum = 0;
+                for (int k = 0; k < P; ++k) isum += (int64_t)g[k] * (int64_t)(xp[-k] * xscale);   /* x * 2^S is an integer, exactly */
+                double acc = (double)isum * yscale;
                 double v = acc * c->gain;
                 double a = fabs(v); if (a > c->peak[ch]) c->peak[ch] = a;
                 if (f64_out) f64_out[o * C + ch] = v;
@@ -453,6 +458,7 @@ static void build_byte_tables(orc_ctx* c) {
 
 int orc_set_half_taps(orc_ctx* c, const double* half, int n_half) {
     if (!c || !half || n_half != c->N / 2) return -1;
+    if (c->r) return -2;   /* stage B sums the exact stage-A integers: the f64-tap study mode is for the integer decimators only */
     for (int k = 0; k < n_half; ++k) {
         c->taps[c->N / 2 + k] = half[k];
         c->taps[c->N / 2 - 1 - k] = half[k];

@@ -116,11 +116,45 @@ def quantise(h):
     return S, q
 
 
+RESAMP_T = 28      # stage-B coefficient grid: G = round(g * 2^28), four balanced int8 limbs in the matrix-core kernel
+
+
+def quantise_polyphase(poly):
+    """Stage-B coefficients on the dyadic grid 2^-RESAMP_T: every phase sums to 2^RESAMP_T EXACTLY (unity DC gain per phase: the
+    f64 design's branches sum to 1 +- 7e-7, which is a signal-independent ripple at the output rate's sub-multiples), the residual
+    spread one unit at a time over the taps whose rounding lost most, as quantise() does for the decimators."""
+    poly = np.asarray(poly, dtype=np.float64)
+    out = np.zeros(poly.shape, dtype=np.int64)
+    for ph in range(poly.shape[0]):
+        g = poly[ph] / poly[ph].sum()
+        q = np.rint(g * 2.0 ** RESAMP_T).astype(np.int64)
+        resid = (1 << RESAMP_T) - int(q.sum())
+        frac = g * 2.0 ** RESAMP_T - q
+        order = np.argsort(-frac, kind="stable") if resid > 0 else np.argsort(frac, kind="stable")
+        for i in range(abs(resid)):
+            q[order[i]] += 1 if resid > 0 else -1
+        assert int(q.sum()) == 1 << RESAMP_T and abs(resid) < 4 * len(q)
+        out[ph] = q
+    assert np.abs(out).max() < 2 ** 31 - 2 ** 24          # four balanced int8 limbs
+    assert int(np.abs(out).sum(1).max()) < 2 ** (RESAMP_T + 1)
+    return out
+
+
 def fmt_i32(q):
     return ", ".join(str(int(v)) for v in q)
 
 
 def main():
+    if "--regrid" in sys.argv:
+        # keep every frozen design (filters/filter_tables.json) and only (re)derive what is computed FROM them: the stage-B integer grid
+        with open(os.path.join(ROOT, "filters", "filter_tables.json")) as f:
+            frozen = json.load(f)
+        filters = frozen["filters"]
+        resamplers = [dict(r, coef=[float.fromhex(x) for x in r["coef"]]) for r in frozen["resamplers"]]
+        for r in resamplers:
+            r["q"] = [int(v) for v in quantise_polyphase(np.array(r["coef"]).reshape(r["L"], r["P"])).reshape(-1)]
+        write_tables(filters, resamplers, None)
+        return
     filters = []   # dicts: name, type, M, N, S, q(list), method
 
     unquantised = {}   # name -> the design's own f64 half taps (symmetrised, unity DC gain), before the 24-bit grid
@@ -175,14 +209,19 @@ def main():
         # phase-major layout: coef[phase][k] = g[k*L + phase]
         poly = g.reshape(P, L).T.copy()
         resamplers.append(dict(name=f"B_{out_rate}", out_rate=out_rate, L=L, Mdn=147, P=P,
-                               coef=[float(v) for v in poly.reshape(-1)],
+                               coef=[float(v) for v in poly.reshape(-1)], q=[int(v) for v in quantise_polyphase(poly).reshape(-1)],
                                method=f"kaiser 120dB pass {fp:.0f} stop {fst:.0f} Hz"))
         print(f"B_{out_rate} L={L} P={P} N={N}", file=sys.stderr)
 
+    write_tables(filters, resamplers, unquantised)
+
+
+def write_tables(filters, resamplers, unquantised):
     os.makedirs(os.path.join(ROOT, "filters"), exist_ok=True)
     # test data only (oracle/, tests/): what the 24-bit tap grid costs against the designs' f64 taps
-    with open(os.path.join(ROOT, "filters", "filter_taps_f64.json"), "w") as f:
-        json.dump(unquantised, f, indent=0)
+    if unquantised is not None:
+        with open(os.path.join(ROOT, "filters", "filter_taps_f64.json"), "w") as f:
+            json.dump(unquantised, f, indent=0)
     with open(os.path.join(ROOT, "filters", "filter_tables.json"), "w") as f:
         json.dump(dict(filters=filters,
                        resamplers=[{k: (v if k != "coef" else [x.hex() for x in v])
@@ -193,10 +232,12 @@ def main():
                " * This build's own filter designs (the reference's tables live in the absent rdsd2pcm\n"
                " * crate).  Integer decimators: taps = q * 2^-S, 2nd half stored centre-outward\n"
                " * (as /root/reference/README.md:252 describes), sum(all taps) == 1 exactly.\n"
+               " * Stage B of the 48k cascade: coefficient [phase][k] = q * 2^-T, every phase sums to 1 exactly\n"
+               " * (coef = the f64 design they were rounded from, kept for tests).\n"
                " * Shared DATA for the engine (dsd2dxd_amd/csrc) and the oracle (oracle/). */\n")
     out.append("#ifndef D2D_FILTER_TABLES_INC\n#define D2D_FILTER_TABLES_INC\n#include <stdint.h>\n")
     out.append("typedef struct { const char* name; char type; int M; int ntaps; int S; const int32_t* half; } d2d_filter_def;\n")
-    out.append("typedef struct { const char* name; int out_rate; int L; int Mdn; int P; const double* coef; } d2d_resamp_def;\n")
+    out.append("typedef struct { const char* name; int out_rate; int L; int Mdn; int P; const double* coef; int T; const int32_t* q; } d2d_resamp_def;\n")
     for i, fl in enumerate(filters):
         out.append(f"static const int32_t d2d_ftab_{i}[{len(fl['q'])}] = {{ {fmt_i32(fl['q'])} }};\n")
     out.append(f"static const d2d_filter_def D2D_FILTERS[{len(filters)}] = {{\n")
@@ -207,9 +248,10 @@ def main():
     for i, r in enumerate(resamplers):
         body = ", ".join(float(v).hex() for v in r["coef"])
         out.append(f"static const double d2d_rtab_{i}[{len(r['coef'])}] = {{ {body} }};\n")
+        out.append(f"static const int32_t d2d_rqtab_{i}[{len(r['q'])}] = {{ {fmt_i32(r['q'])} }};\n")
     out.append(f"static const d2d_resamp_def D2D_RESAMPLERS[{len(resamplers)}] = {{\n")
     for i, r in enumerate(resamplers):
-        out.append(f"  {{ \"{r['name']}\", {r['out_rate']}, {r['L']}, {r['Mdn']}, {r['P']}, d2d_rtab_{i} }},\n")
+        out.append(f"  {{ \"{r['name']}\", {r['out_rate']}, {r['L']}, {r['Mdn']}, {r['P']}, d2d_rtab_{i}, {RESAMP_T}, d2d_rqtab_{i} }},\n")
     out.append("};\n")
     out.append(f"enum {{ D2D_NUM_RESAMPLERS = {len(resamplers)} }};\n#endif\n")
     with open(os.path.join(ROOT, "filters", "filter_tables.inc"), "w") as f:
