@@ -35,7 +35,9 @@
 
 namespace d2d {
 
-#define D2D_MX_THREADS 512
+#ifndef D2D_MX_THREADS
+#define D2D_MX_THREADS 512     // waves per block x 64: 512 = two waves per SIMD (256 registers each); 768 = three (168), an A/B build
+#endif
 #ifndef D2D_MX_ABL
 #define D2D_MX_ABL 0
 #endif
@@ -206,7 +208,10 @@ __global__ __launch_bounds__(D2D_MX_THREADS) void d2d_fir_mx_kernel(Mfma2Args m)
             F4[f] = *reinterpret_cast<const v4i*>(tp16 + MX_FRAG_BYTES * f);
             F2[f] = *reinterpret_cast<const u32x2*>(tp8 + MX_FRAG_BYTES * f);
         };
-        constexpr int AHEAD = 2;
+#ifndef D2D_MX_AHEAD
+#define D2D_MX_AHEAD 2
+#endif
+        constexpr int AHEAD = D2D_MX_AHEAD;
         static_for<0, AHEAD>([&](auto uc) { rdW(uc); rdF(uc); });
         static_for<0, TP>([&](auto uc) {
             constexpr int u = decltype(uc)::value;
@@ -738,8 +743,8 @@ static hipError_t launch_mx_t(Mfma2Args& m, uint32_t max_nout, uint32_t nrows, h
     m.off_out = 2u * (uint32_t)mx_stream_bytes(MB, NT, G);
     m.wave_lds = m.off_out + (SBY ? 2u * TILE * 4u : 0u);
     static const char* wenv = getenv("D2D_MFMA_WAVES");   // diagnostic override
-    uint32_t nwaves = wenv ? (uint32_t)atoi(wenv) : 8u;
-    if (nwaves < 1 || nwaves > 8) nwaves = 8;
+    uint32_t nwaves = wenv ? (uint32_t)atoi(wenv) : (uint32_t)(D2D_MX_THREADS / 64);
+    if (nwaves < 1 || nwaves > D2D_MX_THREADS / 64) nwaves = D2D_MX_THREADS / 64;
     while (nwaves > 1 && (size_t)m.off_waves + (size_t)nwaves * m.wave_lds > 160 * 1024) nwaves >>= 1;
     m.nwaves = nwaves;
     const size_t smem = (size_t)m.off_waves + (size_t)m.nwaves * m.wave_lds;

@@ -23,7 +23,10 @@ __host__ __device__ constexpr int mx_pf(int MB, int NT, int G) { return (mx_chun
 #ifndef D2D_MX_NOFLAT
 #define D2D_MX_NOFLAT 0     // 1: the padded image for every shape (A/B builds)
 #endif
-__host__ __device__ constexpr bool mx_flat(int MB, int G) { return !D2D_MX_NOFLAT && mx_cs(MB, G) % 4 == 2; }        // unpadded LDS image (see the kernel)
+#ifndef D2D_MX_FORCEFLAT
+#define D2D_MX_FORCEFLAT 0  // 1: the unpadded image for every shape (A/B builds: bank conflicts on the window reads against fewer registers)
+#endif
+__host__ __device__ constexpr bool mx_flat(int MB, int G) { return D2D_MX_FORCEFLAT || (!D2D_MX_NOFLAT && mx_cs(MB, G) % 4 == 2); }        // unpadded LDS image (see the kernel)
 __host__ __device__ constexpr int mx_stream_bytes(int MB, int NT, int G) {
     const int dw = 4 * mx_chunks(MB, NT, G);
     if (mx_flat(MB, G)) return 4 * dw + 16;

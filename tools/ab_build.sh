@@ -21,6 +21,6 @@ case $UNIT in
 esac
 # (the engine sees the geometry macros too: groups per column name the kernel)
 /opt/rocm/bin/hipcc $FL -x hip "$@" -c $CS/d2d_engine.cpp -o $O/d2d_engine.o
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $O/libdsd2dxd_amd.so $K $CS/d2d_kernels_mfma.o $CS/d2d_kernels_mfma2.o $M3 $M3B $MX $O/d2d_engine.o \
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $O/libdsd2dxd_amd.so $K $CS/d2d_kernels_rs.o $CS/d2d_kernels_mfma.o $CS/d2d_kernels_mfma2.o $M3 $M3B $MX $O/d2d_engine.o \
   $CS/host/dsd_reader.o $CS/host/pcm_sink.o $CS/host/id3_tag.o $CS/host/rdsd2pcm.o $CS/host/rdsd2pcm_c.o -lpthread
 echo built ab/$NAME
