@@ -46,9 +46,10 @@ typedef int32_t i32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
 typedef uint32_t u32x4_a2 __attribute__((ext_vector_type(4), aligned(2)));
 typedef uint32_t u32x2_a2 __attribute__((ext_vector_type(2), aligned(2)));
 
-constexpr int RS2_NCYC = 16;            // cycles (matrix columns) per wave-tile
-constexpr int RS2_RP = 272;             // bytes between two rows of a limb plane: 256 samples + 16 (the 64 lanes' 16-byte reads fall on all banks)
-constexpr int RS2_PLANE = RS2_NCYC * RS2_RP;
+constexpr int RS2_NCOL = 16;            // matrix columns per wave-tile: 16 cycles of one channel, or 8 cycles of a channel pair
+// bytes between two rows of a limb plane: the samples a row needs (P + 146) rounded up to 16, plus 16 or 32 so that the pitch is an
+// ODD number of 16-byte slots (the 64 lanes' 16-byte reads then fall on all banks)
+__host__ __device__ constexpr int rs2_rp(int P) { return 16 * ((P + 146 + 15) / 16 + (((P + 146 + 15) / 16) % 2 ? 2 : 1)); }
 constexpr uint32_t RS2_C0 = 0x00808080u;
 constexpr int64_t RS2_GUARD = 8;        // numerator units: 2^-28 LSB at F = 31
 
@@ -59,11 +60,13 @@ __device__ __forceinline__ void rs2_wave_sync() {
 }
 
 // DK: dither of the all-integer requantiser (0 none, 1 triangular, 2 rectangular); -1: no fast path (every output through the f64 epilogue)
-template <int NSTEP, int DK>
+// RP: row pitch of a limb plane (rs2_rp(P))
+template <int NSTEP, int DK, int RP>
 __global__ __launch_bounds__(512) void d2d_resample_mfma_kernel(Rs2Args a) {
     extern __shared__ __align__(16) unsigned char smem[];
     const uint32_t tid = threadIdx.x, lane = tid & 63;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    constexpr int PLANE = RS2_NCOL * RP;
     const uint32_t L = a.L, P = a.P, NB = a.NB;
     {   // coefficient fragments and the blocks' row offsets: L2 -> LDS once per block
         const uint32_t n16 = NB * NSTEP * 64u + (NB * 4u + 15u) / 16u;
@@ -74,7 +77,7 @@ __global__ __launch_bounds__(512) void d2d_resample_mfma_kernel(Rs2Args a) {
     __syncthreads();
     const uint8_t* frag = smem + 16u * lane;
     const uint32_t* rowoff = reinterpret_cast<const uint32_t*>(smem + (size_t)NB * NSTEP * 1024u);
-    uint8_t* wbase = smem + a.off_waves + wave * a.wave_lds;      // [4 limb planes][16 rows][RS2_RP] | output slice [cw][16 L] dwords
+    uint8_t* wbase = smem + a.off_waves + wave * a.wave_lds;      // [4 limb planes][16 rows][RP] | output slice [channel of the group][frames of the tile] dwords
     uint32_t* ob = reinterpret_cast<uint32_t*>(wbase + a.off_out);
 
     const uint32_t C = a.epi.channels, cw_n = a.cw;
@@ -85,13 +88,16 @@ __global__ __launch_bounds__(512) void d2d_resample_mfma_kernel(Rs2Args a) {
     const uint32_t nres = j0.nres;
     const uint64_t c_first = j0.m0 / L;
     const uint32_t ncyc = nres ? (uint32_t)((j0.m0 + nres - 1) / L - c_first) + 1u : 0u;
-    const uint32_t ntiles = (ncyc + RS2_NCYC - 1) / RS2_NCYC;
+    // a column = (cycle, channel of the wave's group): a channel pair shares a tile of eight cycles, a single channel takes sixteen
+    const uint32_t cw_sh = cw_n == 2 ? 1u : 0u, CPT = RS2_NCOL >> cw_sh;
+    const uint32_t ntiles = (ncyc + CPT - 1) / CPT;
     // everything below is 32-bit and relative to this call: stage-A indices to job.n0, outputs to m0
     const int32_t rs0 = (int32_t)((int64_t)(a.Mdn * c_first) - (int64_t)j0.n0) - (int32_t)(P - 1);     // row start of cycle c_first
     const int32_t o0 = (int32_t)((int64_t)(c_first * L) - (int64_t)j0.m0);                               // its first output, in (-L, 0]
     const int32_t jlo = -(int32_t)P, jhi = (int32_t)j0.nout - 1;
     const uint32_t col = lane & 15, kg = lane >> 4;
-    const uint32_t tile_out = RS2_NCYC * L;
+    const uint32_t cyc_l = col >> cw_sh, ch_l = col & (cw_n - 1u);     // the lane's cycle inside the tile and its channel inside the group
+    const uint32_t tile_out = CPT * L;                                // frames per tile
 
     // epilogue constants
     const int F = a.fbits;
@@ -108,66 +114,71 @@ __global__ __launch_bounds__(512) void d2d_resample_mfma_kernel(Rs2Args a) {
     }
     const int64_t fmask = ((int64_t)1 << F) - 1;
 
-    i32x4_rs pf[RS2_NCYC];
-    auto issue_rows = [&](uint32_t tile, const StreamJob* job) {
-        const D2D_GLOBAL int32_t* xs = as_global(job->xs);
-        const int32_t rel_t = rs0 + (int32_t)(tile * RS2_NCYC * a.Mdn) + 4 * (int32_t)lane;
-        const bool inside = rel_t - 4 * (int32_t)lane >= jlo && rel_t - 4 * (int32_t)lane + (int32_t)((RS2_NCYC - 1) * a.Mdn) + 255 <= jhi;
+    i32x4_rs pf[RS2_NCOL];
+    const D2D_GLOBAL int32_t* xs0 = as_global(jobs[0].xs);
+    const D2D_GLOBAL int32_t* xs1 = as_global(jobs[cw_n - 1u].xs);
+    // row r of the tile = column r: cycle r >> cw_sh, channel r & (cw_n - 1)
+    auto issue_rows = [&](uint32_t tile) {
+        const int32_t rel_t = rs0 + (int32_t)(tile * CPT * a.Mdn) + 4 * (int32_t)lane;
+        const bool inside = rel_t - 4 * (int32_t)lane >= jlo && rel_t - 4 * (int32_t)lane + (int32_t)((CPT - 1) * a.Mdn) + 255 <= jhi;
         if (inside) {
 #pragma unroll
-            for (int r = 0; r < RS2_NCYC; ++r) {
-                const i32x4_a4 v = *reinterpret_cast<const D2D_GLOBAL i32x4_a4*>(xs + (rel_t + r * (int32_t)a.Mdn));
+            for (int r = 0; r < RS2_NCOL; ++r) {
+                const D2D_GLOBAL int32_t* xs = (r & 1) && cw_n == 2 ? xs1 : xs0;
+                const i32x4_a4 v = *reinterpret_cast<const D2D_GLOBAL i32x4_a4*>(xs + (rel_t + (int32_t)(((uint32_t)r >> cw_sh) * a.Mdn)));
                 pf[r] = i32x4_rs{v.x, v.y, v.z, v.w};
             }
         } else {
 #pragma unroll 1
-            for (int r = 0; r < RS2_NCYC; ++r) {
+            for (int r = 0; r < RS2_NCOL; ++r) {
+                const D2D_GLOBAL int32_t* xs = (r & 1) && cw_n == 2 ? xs1 : xs0;
                 int32_t e[4];
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    const int32_t j = rel_t + r * (int32_t)a.Mdn + k;
+                    const int32_t j = rel_t + (int32_t)(((uint32_t)r >> cw_sh) * a.Mdn) + k;
                     const int32_t x = xs[min(max(j, jlo), jhi)];          // always a valid address
                     e[k] = (j >= jlo && j <= jhi) ? x : 0;                 // samples that do not exist only meet outputs that are not stored
                 }
                 const i32x4_rs v = {e[0], e[1], e[2], e[3]};
 #pragma unroll
-                for (int q = 0; q < RS2_NCYC; ++q) if (q == r) pf[q] = v;
+                for (int q = 0; q < RS2_NCOL; ++q) if (q == r) pf[q] = v;
             }
         }
     };
     auto write_rows = [&]() {
+        if (4u * lane < (uint32_t)RP) {                                    // (a row is narrower than the 256 samples a wave fetches)
 #pragma unroll
-        for (int r = 0; r < RS2_NCYC; ++r) {
-            const uint32_t y0 = (uint32_t)pf[r].x, y1 = (uint32_t)pf[r].y, y2 = (uint32_t)pf[r].z, y3 = (uint32_t)pf[r].w;
-            // 4 x 4 byte transposition: limb b of four consecutive samples in one dword; the three low limbs then flip their top bit
-            const uint32_t p01l = __builtin_amdgcn_perm(y1, y0, 0x05010400u), p01h = __builtin_amdgcn_perm(y1, y0, 0x07030602u);
-            const uint32_t p23l = __builtin_amdgcn_perm(y3, y2, 0x05010400u), p23h = __builtin_amdgcn_perm(y3, y2, 0x07030602u);
-            uint8_t* d = wbase + (uint32_t)r * RS2_RP + 4u * lane;
-            *reinterpret_cast<uint32_t*>(d) = __builtin_amdgcn_perm(p23l, p01l, 0x05040100u) ^ 0x80808080u;
-            *reinterpret_cast<uint32_t*>(d + RS2_PLANE) = __builtin_amdgcn_perm(p23l, p01l, 0x07060302u) ^ 0x80808080u;
-            *reinterpret_cast<uint32_t*>(d + 2 * RS2_PLANE) = __builtin_amdgcn_perm(p23h, p01h, 0x05040100u) ^ 0x80808080u;
-            *reinterpret_cast<uint32_t*>(d + 3 * RS2_PLANE) = __builtin_amdgcn_perm(p23h, p01h, 0x07060302u);
+            for (int r = 0; r < RS2_NCOL; ++r) {
+                const uint32_t y0 = (uint32_t)pf[r].x, y1 = (uint32_t)pf[r].y, y2 = (uint32_t)pf[r].z, y3 = (uint32_t)pf[r].w;
+                // 4 x 4 byte transposition: limb b of four consecutive samples in one dword; the three low limbs then flip their top bit
+                const uint32_t p01l = __builtin_amdgcn_perm(y1, y0, 0x05010400u), p01h = __builtin_amdgcn_perm(y1, y0, 0x07030602u);
+                const uint32_t p23l = __builtin_amdgcn_perm(y3, y2, 0x05010400u), p23h = __builtin_amdgcn_perm(y3, y2, 0x07030602u);
+                uint8_t* d = wbase + (uint32_t)r * RP + 4u * lane;
+                *reinterpret_cast<uint32_t*>(d) = __builtin_amdgcn_perm(p23l, p01l, 0x05040100u) ^ 0x80808080u;
+                *reinterpret_cast<uint32_t*>(d + PLANE) = __builtin_amdgcn_perm(p23l, p01l, 0x07060302u) ^ 0x80808080u;
+                *reinterpret_cast<uint32_t*>(d + 2 * PLANE) = __builtin_amdgcn_perm(p23h, p01h, 0x05040100u) ^ 0x80808080u;
+                *reinterpret_cast<uint32_t*>(d + 3 * PLANE) = __builtin_amdgcn_perm(p23h, p01h, 0x07060302u);
+            }
         }
     };
 
-    double pk[2] = {0.0, 0.0};
+    double pk = 0.0;                                                   // the lane's channel: max |v| over its outputs
+    // dither key of the lane's channel
+    const uint32_t rkey = ch_l ? jobs[cw_n - 1u].rng_key : jobs[0].rng_key, rstep = ch_l ? jobs[cw_n - 1u].rng_kstep : jobs[0].rng_kstep;
+    const uint32_t rlo0 = j0.rng_lo0;                                 // (the index the counter runs on is common to a file's channels)
     const uint32_t wstride = gridDim.x * a.nwaves;
     uint32_t tile = blockIdx.x * a.nwaves + wave;
-    if (tile < ntiles) issue_rows(tile, jobs);
+    if (tile < ntiles) issue_rows(tile);
     for (; tile < ntiles; tile += wstride) {
         const int32_t o_tile = o0 + (int32_t)(tile * tile_out);
-        for (uint32_t cw = 0; cw < cw_n; ++cw) {
-            const StreamJob* job = jobs + cw;
+        {
             rs2_wave_sync();
             write_rows();
-            // the next (channel, tile)'s samples are on their way while this one's matrix work runs
-            if (cw + 1 < cw_n) issue_rows(tile, jobs + cw + 1);
-            else if (tile + wstride < ntiles) issue_rows(tile + wstride, jobs);
+            if (tile + wstride < ntiles) issue_rows(tile + wstride);     // the next tile's samples are on their way while this one's matrix work runs
             rs2_wave_sync();
-            const uint32_t rkey = job->rng_key, rstep = job->rng_kstep, rlo0 = job->rng_lo0;
-            const uint8_t* xrow = wbase + col * RS2_RP + 16u * kg;
-            uint32_t* oslot = ob + cw * tile_out + col * L + kg;
-            const int32_t o_lane = o_tile + (int32_t)(col * L + kg);          // the lane's output of block 0; block rho: + 4 rho
+            const uint8_t* xrow = wbase + col * RP + 16u * kg;
+            uint32_t* oslot = ob + ch_l * tile_out + cyc_l * L + kg;
+            const int32_t o_lane = o_tile + (int32_t)(cyc_l * L + kg);        // the lane's output of block 0; block rho: + 4 rho
             // one block of four residues: four MFMA chains, then the lane's sixteen digit-pair sums as the 64-bit v (mod 2^64)
             auto block_sum = [&](uint32_t rho) -> uint64_t {
                 const uint32_t ro = rowoff[rho];
@@ -177,7 +188,7 @@ __global__ __launch_bounds__(512) void d2d_resample_mfma_kernel(Rs2Args a) {
                     const v4i_rs A = *reinterpret_cast<const v4i_rs*>(frag + (size_t)(rho * NSTEP + s) * 1024u);
 #pragma unroll
                     for (int b = 0; b < 4; ++b) {
-                        const v4i_rs B = *reinterpret_cast<const v4i_rs*>(xrow + b * RS2_PLANE + ro + 64u * s);
+                        const v4i_rs B = *reinterpret_cast<const v4i_rs*>(xrow + b * PLANE + ro + 64u * s);
                         acc[b] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A, B, acc[b], 0, 0, 0);
                     }
                 }
@@ -262,7 +273,7 @@ __global__ __launch_bounds__(512) void d2d_resample_mfma_kernel(Rs2Args a) {
                     vmn = live && v < vmn ? v : vmn;
                 }
             }
-            pk[cw] = fmax(pk[cw], fmax((double)vmx, -(double)vmn));           // correctly rounded conversions: the oracle's |(double)isum|
+            pk = fmax(pk, fmax((double)vmx, -(double)vmn));           // correctly rounded conversions: the oracle's |(double)isum|
         }
         rs2_wave_sync();
         // ---- the tile's frames: 16 L consecutive outputs, the wave's channels side by side ----
@@ -311,9 +322,9 @@ __global__ __launch_bounds__(512) void d2d_resample_mfma_kernel(Rs2Args a) {
             }
         }
     }
-    // peak meter: |y * gain|
+    // peak meter: |y * gain|, per channel of the group
     for (uint32_t cw = 0; cw < cw_n; ++cw) {
-        double p = pk[cw] * yscale * a.epi.gain;
+        double p = ch_l == cw ? pk * yscale * a.epi.gain : 0.0;
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) p = fmax(p, __shfl_xor(p, o));
         if (lane == 0 && p > 0.0)
@@ -377,8 +388,9 @@ hipError_t launch_resample2(Rs2Args& a, const d2d_resamp_def& r, uint32_t max_ou
     a.dkind = a.epi.dither == 'T' ? 1u : (a.epi.dither == 'R' ? 2u : 0u);
     a.fast = (a.epi.gain == 1.0 && (a.epi.bits == 24 || a.epi.bits == 16) && a.epi.dither != 'F' && a.fbits >= 20 && a.fbits <= 46) ? 1u : 0u;
     a.off_waves = a.NB * NSTEP * 1024u + ((a.NB * 4u + 15u) & ~15u);
-    a.off_out = 4u * RS2_PLANE + 16u;                                       // (+16: the last row's reads run 15 bytes past its samples)
-    a.wave_lds = a.off_out + a.cw * RS2_NCYC * a.L * 4u;
+    const uint32_t RP = (uint32_t)rs2_rp(r.P);
+    a.off_out = 4u * RS2_NCOL * RP + 64u;                                   // (the last row's reads run past its samples, against zero coefficients)
+    a.wave_lds = a.off_out + RS2_NCOL * a.L * 4u;                           // the tile's frames: 16 cycles of one channel or 8 of a pair
     uint32_t nwaves = 8;
     while (nwaves > 1 && (size_t)a.off_waves + (size_t)nwaves * a.wave_lds > 160 * 1024) --nwaves;
     a.nwaves = nwaves;
@@ -389,19 +401,21 @@ hipError_t launch_resample2(Rs2Args& a, const d2d_resamp_def& r, uint32_t max_ou
     if (e != hipSuccess) return e;
     if ((e = hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev)) != hipSuccess) return e;
     const uint32_t nrows = nfiles * (C / a.cw);
-    const uint32_t ntiles = (max_out / a.L + 2 + RS2_NCYC - 1) / RS2_NCYC;
+    const uint32_t cpt = RS2_NCOL / a.cw;
+    const uint32_t ntiles = (max_out / a.L + 2 + cpt - 1) / cpt;
     uint32_t gx = std::max(1u, (uint32_t)ncu / std::max(1u, nrows));
     gx = std::min(gx, (ntiles + nwaves - 1) / nwaves);
     const int dk = a.fast ? (int)a.dkind : -1;
-#define RS2_LAUNCH(ns, d)                                                                                                  \
-    if (NSTEP == ns && dk == d) {                                                                                          \
+#define RS2_LAUNCH(ns, d, rp)                                                                                              \
+    if (NSTEP == ns && dk == d && RP == rp) {                                                                              \
         static KernelPrep prep;                                                                                            \
-        if ((e = prep.max_dynamic_lds(reinterpret_cast<const void*>(&d2d_resample_mfma_kernel<ns, d>), 160 * 1024)) != hipSuccess) return e; \
-        hipLaunchKernelGGL((d2d_resample_mfma_kernel<ns, d>), dim3(gx, nrows), dim3(64 * nwaves), smem, s, a);               \
+        if ((e = prep.max_dynamic_lds(reinterpret_cast<const void*>(&d2d_resample_mfma_kernel<ns, d, rp>), 160 * 1024)) != hipSuccess) return e; \
+        hipLaunchKernelGGL((d2d_resample_mfma_kernel<ns, d, rp>), dim3(gx, nrows), dim3(64 * nwaves), smem, s, a);           \
         return hipGetLastError();                                                                                          \
     }
-    RS2_LAUNCH(1, -1) RS2_LAUNCH(1, 0) RS2_LAUNCH(1, 1) RS2_LAUNCH(1, 2)
-    RS2_LAUNCH(2, -1) RS2_LAUNCH(2, 0) RS2_LAUNCH(2, 1) RS2_LAUNCH(2, 2)
+#define RS2_SHAPE(ns, rp) RS2_LAUNCH(ns, -1, rp) RS2_LAUNCH(ns, 0, rp) RS2_LAUNCH(ns, 1, rp) RS2_LAUNCH(ns, 2, rp)
+    RS2_SHAPE(2, rs2_rp(96)) RS2_SHAPE(2, rs2_rp(48)) RS2_SHAPE(1, rs2_rp(32))      // B_96000, B_192000, B_384000
+#undef RS2_SHAPE
 #undef RS2_LAUNCH
     return hipErrorInvalidValue;
 }
