@@ -256,6 +256,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pcie", action="store_true", help="skip the host-resident batch (pinned host in/out, upload/convert/download overlapped) that is reported as the extra pcie_inclusive object, never as value")
     ap.add_argument("--cpu-budget", type=float, default=12.0, help="seconds of CPU-baseline work")
+    ap.add_argument("--pcie-slice", type=int, default=0, help="bytes per channel per slice of the host-resident batch (0 = the library's default)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -478,13 +479,13 @@ def main():
             hios[f].bytes_per_channel = bpc
             hios[f].pcm = h_out[f].data_ptr()
             hios[f].pcm_capacity_bytes = frames * fb
-        e2.translate_batch_host(hios, 0)                         # warm-up (allocates the staging)
+        e2.translate_batch_host(hios, args.pcie_slice)           # warm-up (allocates the staging)
         reps = 2
         if world > 1:
             dist.barrier()
         t1 = time.perf_counter()
         for _ in range(reps):
-            e2.translate_batch_host(hios, 0)
+            e2.translate_batch_host(hios, args.pcie_slice)
         dth = (time.perf_counter() - t1) / reps
         if world > 1:
             t = torch.tensor([dth], dtype=torch.float64, device=cdev)
@@ -493,6 +494,7 @@ def main():
         hb = args.files * (bpc * channels + frames * fb)
         out["pcie_inclusive"] = {"value": round(total_samples / args.steps / dth / 1e6, 3), "unit": "Msamples/s", "ms_per_step": round(dth * 1e3, 3),
                                  "host_bytes_per_step_per_gpu": int(hb), "link_GBps_both_ways_per_gpu": round(hb / dth / 1e9, 2),
+                                 "link_GBps_up_per_gpu": round(args.files * bpc * channels / dth / 1e9, 2), "link_GBps_down_per_gpu": round(args.files * frames * fb / dth / 1e9, 2),
                                  "note": "pinned host buffers -> pinned host buffers through d2d_translate_batch_host, all %d GPU(s) at once; never the reported value" % world}
         del e2
 

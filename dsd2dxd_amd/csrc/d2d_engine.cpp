@@ -67,6 +67,7 @@ struct d2d_engine {
     bool noise_shape = false;             // 'N' dither: the FIR writes integers, a sequential pass requantises
     double* d_ns[2] = {nullptr, nullptr}; int ns_cur = 0;   // its state: two errors per stream, ping-pong between calls
     uint8_t* d_ns_dump = nullptr;                            // NoiseShapeArgs::dump
+    double* d_ys = nullptr; size_t ys_stride = 0;            // 'N' on the 48k family: stage B's outputs as f64, one line per stream
     uint32_t xs_hist = 0;                 // samples carried in front of each scratch line (P of the resampler, else 0)
     StreamJob* d_jobs = nullptr;
     StreamJob* h_jobs = nullptr;          // pinned, JOB_SLOTS x nstreams
@@ -146,6 +147,7 @@ static void free_device(d2d_engine* e) {
     if (e->d_scratch) hipFree(e->d_scratch);
     for (int i = 0; i < 2; ++i) if (e->d_ns[i]) hipFree(e->d_ns[i]);
     if (e->d_ns_dump) hipFree(e->d_ns_dump);
+    if (e->d_ys) hipFree(e->d_ys);
     if (e->d_jobs) hipFree(e->d_jobs);
     if (e->h_jobs) hipHostFree(e->h_jobs);
     if (e->d_in) hipFree(e->d_in);
@@ -231,7 +233,6 @@ int d2d_create(const d2d_params* params, uint32_t n_files, d2d_engine** out) {
     e->epi.bits = e->p.bit_depth;
     e->epi.dither = e->p.dither;
     if (e->p.dither == 'N') {
-        if (e->fc.resamp) { g_create_error = "Noise-shaped dither is available for 44.1 kHz-family output rates only"; delete e; return D2D_ERR_PARAM; }
         if (e->p.bit_depth == 32) e->epi.dither = 'X';                     // float output: nothing to shape
         else e->noise_shape = true;
     }
@@ -305,8 +306,10 @@ int d2d_create(const d2d_params* params, uint32_t n_files, d2d_engine** out) {
         CK(hipMalloc((void**)&e->d_scratch, sizeof(int32_t) * e->scratch_stride * e->nstreams));
     }
     if (e->noise_shape) {
-        e->scratch_stride = 4096;
-        CK(hipMalloc((void**)&e->d_scratch, sizeof(int32_t) * e->scratch_stride * e->nstreams));
+        if (!e->fc.resamp) {
+            e->scratch_stride = 4096;
+            CK(hipMalloc((void**)&e->d_scratch, sizeof(int32_t) * e->scratch_stride * e->nstreams));
+        }
         for (int i = 0; i < 2; ++i) CK(hipMalloc((void**)&e->d_ns[i], sizeof(double) * 2 * e->nstreams));
         CK(hipMalloc((void**)&e->d_ns_dump, 1024));
     }
@@ -392,6 +395,14 @@ int d2d_translate_batch_device(d2d_engine* e, d2d_file_io* io, uint32_t n_files,
     if (e->fc.resamp || e->noise_shape) {
         int rc = grow_scratch(e, (size_t)e->xs_hist + max_nx, s);
         if (rc) return rc;
+    }
+    if (e->noise_shape && e->fc.resamp && (size_t)max_frames + 8 > e->ys_stride) {
+        HIPCHK(e, hipStreamSynchronize(s));
+        if (e->d_ys) HIPCHK(e, hipFree(e->d_ys));
+        e->d_ys = nullptr; e->ys_stride = 0;
+        const size_t ns = ((size_t)max_frames + 8 + 1023) & ~(size_t)1023;
+        HIPCHK(e, hipMalloc((void**)&e->d_ys, sizeof(double) * ns * e->nstreams));
+        e->ys_stride = ns;
     }
     uint32_t max_L = 0;
     for (uint32_t f = 0; f < n_files; ++f) max_L = std::max<uint32_t>(max_L, (uint32_t)io[f].bytes_per_channel);
@@ -480,22 +491,24 @@ int d2d_translate_batch_device(d2d_engine* e, d2d_file_io* io, uint32_t n_files,
     }
     if (pe) HIPCHK(e, hipEventRecord(pe->second, s));
     if (max_nx && d2d_last_launched_kernel) e->launched = d2d_last_launched_kernel;
+    if (e->fc.resamp) {
+        Rs2Args r{};
+        r.jobs = e->d_jobs; r.tables = reinterpret_cast<const uint8_t*>(e->d_resamp);
+        r.S = e->S; r.epi = e->epi;
+        if (e->noise_shape) { r.ys = e->d_ys; r.ys_stride = (uint32_t)e->ys_stride; }
+        HIPCHK(e, launch_resample2(r, *e->fc.resamp, max_frames, n_files, s));
+        HIPCHK(e, launch_xhist(e->d_jobs, e->nstreams, (uint32_t)e->fc.resamp->P, s));
+    }
     if (e->noise_shape) {
         NoiseShapeArgs ns{};
         ns.jobs = e->d_jobs; ns.state = e->d_ns[e->ns_cur]; ns.state_next = e->d_ns[e->ns_cur ^ 1]; ns.dump = e->d_ns_dump;
-        ns.scale_bits = e->S; ns.nstreams = e->nstreams; ns.max_nout = max_nx; ns.epi = e->epi;
+        ns.scale_bits = e->S; ns.nstreams = e->nstreams; ns.max_nout = e->fc.resamp ? max_frames : max_nx; ns.epi = e->epi;
+        if (e->fc.resamp) { ns.ys = e->d_ys; ns.ys_stride = (uint32_t)e->ys_stride; ns.res = 1; }
         { static const char* noint = getenv("D2D_NO_INTQ"); FirArgs fa{}; fir_args_static(e, fa); ns.intq = (!noint && fa.sum_abs_q + (1ull << 24) < (1ull << 31)) ? 1u : 0u; }
         // a stream whose call ends exactly on a segment boundary, or feeds nothing, writes no state: start the next buffer from the current one
         HIPCHK(e, hipMemcpyAsync(e->d_ns[e->ns_cur ^ 1], e->d_ns[e->ns_cur], sizeof(double) * 2 * e->nstreams, hipMemcpyDeviceToDevice, s));
         HIPCHK(e, launch_noise_shape(ns, s));
         e->ns_cur ^= 1;
-    }
-    if (e->fc.resamp) {
-        Rs2Args r{};
-        r.jobs = e->d_jobs; r.tables = reinterpret_cast<const uint8_t*>(e->d_resamp);
-        r.S = e->S; r.epi = e->epi;
-        HIPCHK(e, launch_resample2(r, *e->fc.resamp, max_frames, n_files, s));
-        HIPCHK(e, launch_xhist(e->d_jobs, e->nstreams, (uint32_t)e->fc.resamp->P, s));
     }
     HIPCHK(e, launch_history(e->d_jobs, e->nstreams, e->Cin, e->B, e->keep, s));
     if (ps) HIPCHK(e, hipEventRecord(ps->second, s));
@@ -590,13 +603,17 @@ int d2d_translate_batch_host(d2d_engine* e, d2d_file_io* io, uint32_t n_files, s
     hipEvent_t* in_done = e->hb_ev; hipEvent_t* comp_done = e->hb_ev + 2; hipEvent_t* out_done = e->hb_ev + 4;
     std::vector<size_t> done(n_files, 0);
     std::vector<d2d_file_io> dio(n_files);
+    // (equal slices: ramping them up and down -- slice/8, /4, /2, full ... -- to shorten the first upload and the last download was
+    // measured and is slower, 64.2 against 61.7 ms per step: the step is bound by the per-copy cost of 2 x 64 transfers per slice,
+    // not by fill and drain; the link alone moves the batch both ways in 47 ms, tools/link_probe.py)
     const size_t nslices = (max_L + slice - 1) / slice;
     for (size_t k = 0; k < nslices; ++k) {
         const int b = (int)(k & 1);
+        const size_t slice_k = slice;
         // upload: the staging buffer is free once the conversion of slice k-2 has read it
         if (k >= 2) HIPCHK(e, hipStreamWaitEvent(s_in, comp_done[b], 0));
         for (uint32_t f = 0; f < n_files; ++f) {
-            const size_t L = std::min(slice, io[f].bytes_per_channel - done[f]);
+            const size_t L = std::min(slice_k, io[f].bytes_per_channel - done[f]);
             dio[f].dsd = e->hb_in[b] + in_stride * f;
             dio[f].bytes_per_channel = L;
             dio[f].pcm = e->hb_out[b] + out_stride * f;

@@ -77,6 +77,11 @@ struct NoiseShapeArgs {
     uint32_t max_nout;         // the longest stream's outputs this call (sizes the grid)
     uint32_t cp_bits;          // log2(channels rounded up to a power of two): filled by the launcher
     uint32_t intq;             // 1: |y * 2^S| + a few LSB stay inside int32 (the engine checks the tap table): the all-integer loop may run at unit gain
+    // 48k family: the pass runs on stage B's outputs -- index m (job.m0, job.nres), input y as f64 in ys[stream * ys_stride + i] (the
+    // resampler's 64-bit integers do not fit the int32 recurrence), peaks already taken by stage B
+    const double* ys;
+    uint32_t ys_stride;
+    uint32_t res;
     Epilogue epi;
 };
 
@@ -92,6 +97,8 @@ struct Rs2Args {
     uint32_t fast;             // 1: unit gain at 24 or 16 bits, dither T / R / X: the all-integer requantiser (with its guard band)
     uint32_t dkind;            // 0 none, 1 triangular, 2 rectangular
     int32_t  fbits;            // F = S + T - (bits - 1): y in LSB is v * 2^-F
+    double*  ys;               // non-null: the samples go as y = (double)v * 2^-(S+T) to ys[stream * ys_stride + i] for the noise-shaping pass, no frames
+    uint32_t ys_stride;
     Epilogue epi;
 };
 

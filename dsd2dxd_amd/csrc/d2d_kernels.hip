@@ -183,9 +183,12 @@ __global__ __launch_bounds__(256) void d2d_noise_shape_kernel(NoiseShapeArgs a) 
     const uint32_t file = blockIdx.y;
     const StreamJob* jobs = a.jobs + (size_t)file * C;
     const StreamJob j0 = jobs[0];                                          // n0, nout, out are common to a file's channels
-    if (j0.nout == 0) return;
-    const uint64_t n_end = j0.n0 + j0.nout;
-    const uint64_t k0 = j0.n0 >> NS_SEG_BITS, k1 = (n_end - 1) >> NS_SEG_BITS;
+    // the index the pass runs on: the FIR outputs n (44.1k family) or stage B's outputs m (48k family)
+    const uint64_t N0 = a.res ? j0.m0 : j0.n0;
+    const uint32_t NOUT = a.res ? j0.nres : j0.nout;
+    if (NOUT == 0) return;
+    const uint64_t n_end = N0 + NOUT;
+    const uint64_t k0 = N0 >> NS_SEG_BITS, k1 = (n_end - 1) >> NS_SEG_BITS;
     const uint64_t k = k0 + (uint64_t)(blockIdx.x * (blockDim.x >> 6) + wave) * spw + sw;
     const bool active = k <= k1 && ch < C;
     const uint32_t rb = NS_FRAMES * fb;                                    // row bytes (a multiple of 8)
@@ -193,12 +196,13 @@ __global__ __launch_bounds__(256) void d2d_noise_shape_kernel(NoiseShapeArgs a) 
     uint8_t* row = ns_smem + (size_t)(wave * spw + sw) * rstride;
     // (every lane of a wave runs the same number of loop trips; inactive ones do nothing inside)
     const uint64_t seg_lo = k << NS_SEG_BITS, seg_hi = (k + 1) << NS_SEG_BITS;
-    const uint32_t i0 = active ? (seg_lo > j0.n0 ? (uint32_t)(seg_lo - j0.n0) : 0u) : 0u;
-    const uint32_t i1 = active ? (uint32_t)((seg_hi < n_end ? seg_hi : n_end) - j0.n0) : 0u;
+    const uint32_t i0 = active ? (seg_lo > N0 ? (uint32_t)(seg_lo - N0) : 0u) : 0u;
+    const uint32_t i1 = active ? (uint32_t)((seg_hi < n_end ? seg_hi : n_end) - N0) : 0u;
     const StreamJob job = jobs[ch < C ? ch : 0];
     const D2D_GLOBAL int32_t* xs = as_global(job.xs);
     const uint32_t sidx = file * C + (ch < C ? ch : 0);
-    const bool carried = active && seg_lo < j0.n0;                         // begun in an earlier call
+    const D2D_GLOBAL double* ys = as_global(a.ys) + (size_t)sidx * a.ys_stride;      // (res only)
+    const bool carried = active && seg_lo < N0;                         // begun in an earlier call
     double e1 = carried ? a.state[2 * sidx] : 0.0, e2 = carried ? a.state[2 * sidx + 1] : 0.0, pk = 0.0;
     const double lim = (double)(1u << (a.epi.bits - 1));
     const double xscale = ldexp(a.epi.scale, -a.scale_bits);
@@ -214,8 +218,12 @@ __global__ __launch_bounds__(256) void d2d_noise_shape_kernel(NoiseShapeArgs a) 
     for (uint32_t t0 = 0; t0 < len; t0 += NS_FRAMES) {
         // this lane's integers of the next eight steps (two 16-byte loads: 4-byte aligned is enough)
         int32_t v[NS_FRAMES];
+        double yv[NS_FRAMES];
         const uint32_t ib = i0 + t0;
-        if (active && ib + NS_FRAMES <= i1) {
+        if (a.res) {
+#pragma unroll
+            for (uint32_t u = 0; u < NS_FRAMES; ++u) { v[u] = 0; yv[u] = (active && ib + u < i1) ? ys[ib + u] : 0.0; }
+        } else if (active && ib + NS_FRAMES <= i1) {
             typedef int32_t i32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
             const i32x4_a4 lo4 = *reinterpret_cast<D2D_GLOBAL const i32x4_a4*>(xs + ib), hi4 = *reinterpret_cast<D2D_GLOBAL const i32x4_a4*>(xs + ib + 4);
             v[0] = lo4.x; v[1] = lo4.y; v[2] = lo4.z; v[3] = lo4.w; v[4] = hi4.x; v[5] = hi4.y; v[6] = hi4.z; v[7] = hi4.w;
@@ -229,8 +237,8 @@ __global__ __launch_bounds__(256) void d2d_noise_shape_kernel(NoiseShapeArgs a) 
             if (active && i < i1) {
                 // y = v * 2^-S is exact and x = y * scale rounds once: v * (scale * 2^-S) is the same product, rounded the same
                 vmax = max(vmax, (uint32_t)(v[u] < 0 ? -v[u] : v[u]));
-                const double x = (double)v[u] * xscale;
-                const uint32_t rnd = rng32(job, job.n0 + i);
+                const double x = a.res ? yv[u] * a.epi.scale : (double)v[u] * xscale;      // (res: y is the resampler's f64, x = y * scale rounds once)
+                const uint32_t rnd = rng32(job, N0 + i);
                 const double d = (double)((rnd & 0xFFFFu) + (rnd >> 16) + 1u) * 0x1p-16 - 1.0;
                 const double fbk = 2.0 * e1 - e2;
                 const double w = x - fbk;
@@ -273,7 +281,7 @@ __global__ __launch_bounds__(256) void d2d_noise_shape_kernel(NoiseShapeArgs a) 
     // the lane that writes its new one may sit in different blocks
     if (active && k == k1) { a.state_next[2 * sidx] = e1; a.state_next[2 * sidx + 1] = e2; }
     pk = fabs(ldexp((double)vmax, -a.scale_bits) * a.epi.gain);            // |y * gain| is monotonic in |y|
-    if (active && pk > 0.0) atomicMax(reinterpret_cast<unsigned long long*>(job.peak), (unsigned long long)__double_as_longlong(pk));
+    if (active && pk > 0.0 && !a.res) atomicMax(reinterpret_cast<unsigned long long*>(job.peak), (unsigned long long)__double_as_longlong(pk));
 }
 
 
@@ -601,7 +609,7 @@ hipError_t launch_noise_shape(const NoiseShapeArgs& a0, hipStream_t s) {
     const size_t smem = (size_t)waves * spw * (NS_FRAMES * fb + 4);
     const uint32_t nfiles = a.nstreams / C;
     static const char* gen = getenv("D2D_NS_GENERAL");                          // diagnostic: the general kernel for stereo too
-    if (C == 2 && (a.epi.bits == 16 || a.epi.bits == 24) && !(gen && atoi(gen))) {
+    if (C == 2 && (a.epi.bits == 16 || a.epi.bits == 24) && !(gen && atoi(gen)) && !a.res) {
         const int F = a.scale_bits - ((int)a.epi.bits - 1);
         const bool intq = a.intq && a.epi.gain == 1.0 && F >= 1 && F <= 16;
         const dim3 grid((max_seg + waves * 32 - 1) / (waves * 32), nfiles);

@@ -264,11 +264,13 @@ __global__ __launch_bounds__(512) void d2d_resample_mfma_kernel(Rs2Args a) {
                     }
                 }
             } else {
+                D2D_GLOBAL double* ysl = a.ys ? as_global(a.ys) + (size_t)(file * C + grp * cw_n + ch_l) * a.ys_stride : nullptr;
                 for (uint32_t rho = 0; rho < NB; ++rho) {
                     const int64_t v = (int64_t)block_sum(rho);
                     const int32_t o = o_lane + (int32_t)(4u * rho);
                     const bool live = (uint32_t)o < nres;
-                    oslot[4u * rho] = live ? careful_bits(v, hash(o)) : 0u;
+                    if (ysl) { if (live) ysl[o] = (double)v * yscale; }          // the noise-shaping pass requantises
+                    else oslot[4u * rho] = live ? careful_bits(v, hash(o)) : 0u;
                     vmx = live && v > vmx ? v : vmx;
                     vmn = live && v < vmn ? v : vmn;
                 }
@@ -276,6 +278,7 @@ __global__ __launch_bounds__(512) void d2d_resample_mfma_kernel(Rs2Args a) {
             pk = fmax(pk, fmax((double)vmx, -(double)vmn));           // correctly rounded conversions: the oracle's |(double)isum|
         }
         rs2_wave_sync();
+        if (a.ys) continue;
         // ---- the tile's frames: 16 L consecutive outputs, the wave's channels side by side ----
         const uint32_t SBY = a.epi.sample_bytes, fb = SBY * C;
         uint8_t* out = reinterpret_cast<uint8_t*>(j0.out) + (size_t)j0.och * SBY;
@@ -386,7 +389,7 @@ hipError_t launch_resample2(Rs2Args& a, const d2d_resamp_def& r, uint32_t max_ou
     a.cw = (C % 2 == 0) ? 2u : 1u;
     a.fbits = a.S + a.T - ((int)a.epi.bits - 1);
     a.dkind = a.epi.dither == 'T' ? 1u : (a.epi.dither == 'R' ? 2u : 0u);
-    a.fast = (a.epi.gain == 1.0 && (a.epi.bits == 24 || a.epi.bits == 16) && a.epi.dither != 'F' && a.fbits >= 20 && a.fbits <= 46) ? 1u : 0u;
+    a.fast = (!a.ys && a.epi.gain == 1.0 && (a.epi.bits == 24 || a.epi.bits == 16) && a.epi.dither != 'F' && a.fbits >= 20 && a.fbits <= 46) ? 1u : 0u;
     a.off_waves = a.NB * NSTEP * 1024u + ((a.NB * 4u + 15u) & ~15u);
     const uint32_t RP = (uint32_t)rs2_rp(r.P);
     a.off_out = 4u * RS2_NCOL * RP + 64u;                                   // (the last row's reads run past its samples, against zero coefficients)

@@ -234,12 +234,32 @@ def test_noise_shaped_dither_matches_the_oracle(engine_lib, oracle_mod, dsd_rate
     kw_t = dict(kw, dither="T")
     g_t, _, _, _ = run_pair(engine_lib, oracle_mod, bufs, kw_t, kernel)
     assert not np.array_equal(g, g_t)
-    # ... float output has nothing to shape, and the 48 kHz family refuses the option
+    # ... and float output has nothing to shape
     e32 = engine_lib.Engine(n_files=1, kernel=kernel, **dict(kw, bit_depth=32))
     x32 = engine_lib.Engine(n_files=1, kernel=kernel, **dict(kw, bit_depth=32, dither="X"))
     assert np.array_equal(e32.translate(bufs[0])[0], x32.translate(bufs[0])[0])
-    with pytest.raises(engine_lib.D2DError, match="44.1 kHz-family"):
-        engine_lib.Engine(n_files=1, kernel=kernel, **dict(kw, dsd_rate=1, output_rate=96000))
+
+
+@pytest.mark.parametrize("kernel", KERNELS)
+@pytest.mark.parametrize("dsd_rate,out_rate,bits,level,channels", [(1, 96000, 24, 0.0, 2), (2, 192000, 16, -1.5, 2), (1, 384000, 20, 0.0, 3)])
+def test_noise_shaped_dither_on_the_48k_family(engine_lib, oracle_mod, dsd_rate, out_rate, bits, level, channels, kernel):
+    """'N' behind the two-stage path (round 3): stage B hands its outputs to the shaper as f64 (y = (double)v * 2^-(S+T), the oracle's
+    number), the loop runs on the output index m with its 8192-output segments and its two carried errors: ragged calls, a call that
+    ends inside a segment, odd channel count -- all equal to the oracle"""
+    nbytes = 4096 * 12 * dsd_rate + 77
+    chans = [synth("sine" if c % 2 == 0 else "pink", nbytes, seed=31 + c, dsd_rate=dsd_rate, amp=0.45 if c % 2 == 0 else 0.098) for c in range(channels)]
+    cuts = [0, 4096 * 3, 4096 * 3 + 1000, 4096 * 9, nbytes]
+    bufs = [pack_layout([ch[a:b] for ch in chans], "P", 4096) for a, b in zip(cuts[:-1], cuts[1:])]
+    kw = dict(dsd_rate=dsd_rate, output_rate=out_rate, channels=channels, fmt="P", endianness="L", block_size=4096,
+              filter="E", bit_depth=bits, dither="N", seed=8, level_db=level)
+    g, r, e, o = run_pair(engine_lib, oracle_mod, bufs, kw, kernel)
+    assert g.size == r.size and g.size > 0
+    assert np.array_equal(g, r)
+    assert e.peak_dbfs() == o.peak_dbfs()
+    one, _, _, _ = run_pair(engine_lib, oracle_mod, [pack_layout(chans, "P", 4096)], kw, kernel)
+    assert np.array_equal(one, g)
+    g_t, _, _, _ = run_pair(engine_lib, oracle_mod, bufs, dict(kw, dither="T"), kernel)
+    assert not np.array_equal(g, g_t)
 
 
 @pytest.mark.parametrize("kernel", KERNELS)
