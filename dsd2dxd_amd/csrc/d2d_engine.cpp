@@ -88,6 +88,7 @@ struct d2d_engine {
     // planar copies of byte-interleaved inputs (one slice per file), see d2d_deinterleave_kernel
     uint8_t* d_planar = nullptr; size_t planar_stride = 0;
     bool deinterleave = false;
+    bool coop = false;                    // byte-interleaved 4/8-channel input de-interleaved inside the fp6 kernel's staging (FirArgs::coop)
     uint8_t* d_out = nullptr; size_t d_out_cap = 0;
 
     int fail(int code, const std::string& m) { err = m; return code; }
@@ -193,6 +194,7 @@ static void fir_args_static(const d2d_engine* e, FirArgs& a) {
     a.epi = e->epi;
     a.pipelined = (uint32_t)e->mfma_pipe;
     a.mx_exact = mx_exact(*e->fc.fir) ? 1u : 0u;
+    a.coop = e->coop ? 1u : 0u;
 }
 
 namespace d2d { thread_local const char* d2d_last_launched_kernel = nullptr; }
@@ -290,6 +292,15 @@ int d2d_create(const d2d_params* params, uint32_t n_files, d2d_engine** out) {
         CK(hipMemcpy(e->d_fir_tables, t.data(), e->fir_table_bytes, hipMemcpyHostToDevice));
     } else {
         if (e->mfma_v2) { FirArgs a{}; fir_args_static(e, a); e->mfma_pipe = mfma2_pipelined(a, e->M, e->N); }
+        // byte-interleaved 4- or 8-channel input into the scratch (48k family, noise shaping) through the fp6 kernel: no planar copy, the
+        // kernel's staging de-interleaves (D2D_NO_COOP=1: the pre-pass)
+        {
+            const char* nocoop = getenv("D2D_NO_COOP");   // (read at every engine creation: the tests switch it inside one process)
+            if (e->deinterleave && e->mfma_pipe == 5 && (e->fc.resamp || e->noise_shape) && e->C == e->Cin && (e->Cin == 8 || e->Cin == 4) &&
+                !(nocoop && atoi(nocoop))) {
+                e->coop = true; e->deinterleave = false; e->B = 1;
+            }
+        }
         std::vector<int8_t> t = e->mfma_pipe == 5 ? build_mx_tables(f, msb) : e->mfma_pipe == 4 ? build_mfma4_tables(f, msb)
                               : e->mfma_v2 ? build_mfma2_tables(f, msb, !e->mfma_pipe) : build_mfma_tables(f, e->mfma, msb);
         e->fir_table_bytes = t.size();

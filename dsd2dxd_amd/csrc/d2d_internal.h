@@ -62,6 +62,8 @@ struct FirArgs {
     uint64_t sum_abs_q;        // sum |q_j| of the tap table (bounds |y*2^S|)
     uint32_t pipelined;        // two-group MFMA kernels: 0, or the variant of the pipelined kernel whose tap table the engine built (3 dense, 4 sparse,
                                // 5 the fp6 x fp4 kernel of d2d_kernels_mx.hip)
+    uint32_t coop;             // 1 (d2d_kernels_mx.hip, scratch flavour): byte-interleaved 4- or 8-channel input, every channel converted: the kernel
+                               // de-interleaves inside its staging, a block per (file, tile) with one wave per channel pair; B = 1 then
     uint32_t mx_exact;         // 1: the table's base-32 digit sums recombine exactly in f32 (d2d_mx.h: mx_exact)
     Epilogue epi;
 };

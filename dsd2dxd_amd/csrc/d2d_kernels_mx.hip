@@ -94,10 +94,13 @@ __global__ __launch_bounds__(D2D_MX_THREADS) void d2d_fir_mx_kernel(Mfma2Args m)
     const FirArgs& a = m.f;
     extern __shared__ __align__(16) unsigned char smem[];
     const uint32_t Ct = a.in_channels;
-    const uint32_t fidx = SCR ? blockIdx.y / m.ngroups : blockIdx.y;
-    const uint32_t cbase = SCR ? (blockIdx.y - fidx * m.ngroups) * 2u : 0u;
     const uint32_t tid = threadIdx.x, lane = tid & 63;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // COOP (scratch flavour, byte-interleaved 4- or 8-channel input, a.coop): a block = one tile of ALL the file's channel pairs, wave p
+    // converts pair p, and the waves de-interleave the tile's bytes together (below); otherwise a block row = a file or one of its pairs
+    const bool coop = SCR && a.coop;
+    const uint32_t fidx = coop ? blockIdx.y : (SCR ? blockIdx.y / m.ngroups : blockIdx.y);
+    const uint32_t cbase = coop ? 2u * wave : (SCR ? (blockIdx.y - fidx * m.ngroups) * 2u : 0u);
     uint8_t* wbase = smem + m.off_waves + wave * m.wave_lds;       // [channel 0 stream buffer | channel 1 stream buffer | output slice]
     const StreamJob* jobs = a.jobs + (size_t)fidx * (SCR ? a.epi.channels : 2u) + cbase;
     const StreamJob j0 = jobs[0];          // in, L, e0, n0, nout are common to a file's channels
@@ -112,7 +115,7 @@ __global__ __launch_bounds__(D2D_MX_THREADS) void d2d_fir_mx_kernel(Mfma2Args m)
     __syncthreads();
 
     const uint32_t nwt = (j0.nout + (TILE - 1)) / TILE;            // wave-tiles in this file
-    const uint32_t wstride = gridDim.x * m.nwaves;
+    const uint32_t wstride = coop ? gridDim.x : gridDim.x * m.nwaves;
     const uint32_t r = lane & 31, h = lane >> 5;
 
     // ---- staging geometry: window dword L of a tile sits at LDS dword L + L / CS (one pad dword per column stride: CS is even, so the
@@ -177,6 +180,69 @@ __global__ __launch_bounds__(D2D_MX_THREADS) void d2d_fir_mx_kernel(Mfma2Args m)
                     for (int k = 0; k < 4; ++k) *reinterpret_cast<uint32_t*>(buf + wad[i][k]) = v[k];
                 }
             }
+    };
+
+    // ---- COOP: the tile's bytes of all channels come as they lie in memory (frame after frame), each wave fetching a share of the 16-byte
+    // pieces; a piece holds 16 / Ct frames, from which one v_perm_b32 per channel pair pulls the pair's bytes -- two 2-byte (Ct = 8) or
+    // 4-byte (Ct = 4) runs that go straight into the pair's two stream buffers, whichever wave owns them.  Two block barriers per tile.
+    constexpr int PFI = SCR ? (NCHK + 31) / 32 : 1;           // pieces per lane: NCHK * Ct pieces over Ct / 2 waves of 64 lanes
+    u32x4 pfi[PFI];
+    uint32_t cad[PFI];                                         // where a piece's frames start inside a stream buffer
+    const uint32_t nw = m.nwaves;
+    if constexpr (SCR) {
+        if (coop) {
+            const uint32_t ts_sh = Ct == 8 ? 1u : 2u;          // log2(frames per piece)
+#pragma unroll
+            for (int i = 0; i < PFI; ++i) {
+                const uint32_t g = lane + 64u * (wave + nw * (uint32_t)i);
+                const uint32_t tau = g << ts_sh;                // first frame of the piece = byte of a channel's stream, relative to the tile's first chunk
+                const int32_t Lw = (int32_t)(tau >> 2) - (int32_t)X0;
+                cad[i] = Lw < 0 ? DUMMY + (tau & 3u) : 4u * ((uint32_t)Lw + (uint32_t)Lw / (uint32_t)CS) + (tau & 3u);
+            }
+        }
+    }
+    auto coop_fast = [&](uint32_t w) -> bool {                 // the tile's bytes all lie inside this call's data (block-uniform)
+        const int32_t ab = tile_ab16(w);
+        return ab >= 0 && (uint32_t)ab + 16u * NCHK <= Lcall;
+    };
+    auto coop_issue = [&](uint32_t w) {
+        const uint8_t* src = j0.in + (size_t)(uint32_t)tile_ab16(w) * Ct;
+#pragma unroll
+        for (int i = 0; i < PFI; ++i) {
+            uint32_t g = lane + 64u * (wave + nw * (uint32_t)i);
+            g = g < (uint32_t)NCHK * Ct ? g : (uint32_t)NCHK * Ct - 1u;      // (lanes past the last piece re-read it; their writes are masked)
+            pfi[i] = *reinterpret_cast<D2D_GLOBAL const u32x4*>(as_global(src) + 16u * g);
+        }
+    };
+    auto coop_write = [&]() {
+        uint8_t* b0 = smem + m.off_waves;
+#pragma unroll
+        for (int i = 0; i < PFI; ++i) {
+            const uint32_t g = lane + 64u * (wave + nw * (uint32_t)i);
+            if (g < (uint32_t)NCHK * Ct) {
+                const uint32_t d[4] = {pfi[i].x, pfi[i].y, pfi[i].z, pfi[i].w};
+                if (Ct == 8) {
+                    // dwords 0, 1 = frame 0 (channels 0-3, 4-7), dwords 2, 3 = frame 1: pair p = channels 2p, 2p+1
+#pragma unroll
+                    for (int p = 0; p < 4; ++p) {
+                        const uint32_t v = __builtin_amdgcn_perm(d[2 + (p >> 1)], d[p >> 1], (p & 1) ? 0x07030602u : 0x05010400u);   // [c.t0 c.t1 c'.t0 c'.t1]
+                        uint8_t* pb = b0 + (uint32_t)p * m.wave_lds + cad[i];
+                        *reinterpret_cast<uint16_t*>(pb) = (uint16_t)v;
+                        *reinterpret_cast<uint16_t*>(pb + SB) = (uint16_t)(v >> 16);
+                    }
+                } else {
+                    // Ct = 4: dword k = frame k (channels 0-3)
+#pragma unroll
+                    for (int p = 0; p < 2; ++p) {
+                        const uint32_t sel = p ? 0x07030602u : 0x05010400u;
+                        const uint32_t x = __builtin_amdgcn_perm(d[1], d[0], sel), y = __builtin_amdgcn_perm(d[3], d[2], sel);   // [c.t0 c.t1 c'.t0 c'.t1], [c.t2 c.t3 c'.t2 c'.t3]
+                        uint8_t* pb = b0 + (uint32_t)p * m.wave_lds + cad[i];
+                        *reinterpret_cast<uint32_t*>(pb) = __builtin_amdgcn_perm(y, x, 0x05040100u);
+                        *reinterpret_cast<uint32_t*>(pb + SB) = __builtin_amdgcn_perm(y, x, 0x07060302u);
+                    }
+                }
+            }
+        }
     };
 
     // tap fragment f: 16 bytes per lane at f * 1536 + 16 lane, 8 more at f * 1536 + 1024 + 8 lane
@@ -471,7 +537,7 @@ __global__ __launch_bounds__(D2D_MX_THREADS) void d2d_fir_mx_kernel(Mfma2Args m)
     };
     auto merge_extremes = [&](const Fast& f, uint32_t c) { vmn[c] = min(vmn[c], f.tmn); vmx[c] = max(vmx[c], f.tmx); };
 
-    const uint32_t wv = blockIdx.x * m.nwaves + wave;       // this wave's index among the file's waves
+    const uint32_t wv = coop ? blockIdx.x : blockIdx.x * m.nwaves + wave;       // this wave's (COOP: this block's) index among the file's tile workers
 #if D2D_MX_STAMPS
     const unsigned long long t_start = __builtin_amdgcn_s_memtime(), rt_start = __builtin_amdgcn_s_memrealtime();
     unsigned long long st_sum[3] = {0, 0, 0}, st_last = t_start;
@@ -488,7 +554,8 @@ __global__ __launch_bounds__(D2D_MX_THREADS) void d2d_fir_mx_kernel(Mfma2Args m)
         constexpr bool AF = decltype(af)::value;
         uint32_t wt = t_begin + wv;
         if (wt < t_end) {
-            issue_loads(wt, C0{}, af);
+            if (coop) { if (coop_fast(wt)) coop_issue(wt); }
+            else issue_loads(wt, C0{}, af);
             // AF: every trip issues the same loads and stores in the same order (the first trip stores whatever the slice holds to its
             // own tile, rewritten one trip later; the last trip re-requests its own tile): the compiler can then count its waits
             if (AF && !SCR && !(dbg & 64)) store_tile(wt, true);
@@ -505,12 +572,24 @@ __global__ __launch_bounds__(D2D_MX_THREADS) void d2d_fir_mx_kernel(Mfma2Args m)
             const uint32_t nxt = more ? wt + wstride : wt;
             // ---- region A ----
             stamp(2);
-            wave_sync2();
-            if (!(dbg & 4)) {
-                write_lds(C0{});
-                issue_loads(wt, C1{}, af);
+            if (coop) {
+                // (the tile index is the block's: every wave takes the same branches and meets the same barriers)
+                __syncthreads();                                  // every wave is done with the tile before
+                if (coop_fast(wt)) coop_write();
+                else {                                            // a tile at the call's edges: every wave gathers its own two channels byte by byte
+                    issue_loads(wt, C0{}, std::false_type{}); write_lds(C0{});
+                    issue_loads(wt, C1{}, std::false_type{}); write_lds(C1{});
+                }
+                if (more && coop_fast(nxt)) coop_issue(nxt);
+                __syncthreads();
+            } else {
+                wave_sync2();
+                if (!(dbg & 4)) {
+                    write_lds(C0{});
+                    issue_loads(wt, C1{}, af);
+                }
+                wave_sync2();
             }
-            wave_sync2();
             stamp(0);
             {
                 Fast f;
@@ -530,7 +609,7 @@ __global__ __launch_bounds__(D2D_MX_THREADS) void d2d_fir_mx_kernel(Mfma2Args m)
             // ---- region B ----
             stamp(2);
             wave_sync2();
-            if (!(dbg & 4)) {
+            if (!(dbg & 4) && !coop) {
                 write_lds(C1{});
                 if (AF || more) issue_loads(nxt, C0{}, af);
             }
@@ -746,6 +825,8 @@ static hipError_t launch_mx_t(Mfma2Args& m, uint32_t max_nout, uint32_t nrows, h
     uint32_t nwaves = wenv ? (uint32_t)atoi(wenv) : (uint32_t)(D2D_MX_THREADS / 64);
     if (nwaves < 1 || nwaves > D2D_MX_THREADS / 64) nwaves = D2D_MX_THREADS / 64;
     while (nwaves > 1 && (size_t)m.off_waves + (size_t)nwaves * m.wave_lds > 160 * 1024) nwaves >>= 1;
+    const bool coop = SBY == 0 && m.f.coop;                 // a block = all channel pairs of a file on one tile: one wave per pair, one grid row per file
+    if (coop) { nwaves = m.f.epi.channels / 2u; nrows /= m.ngroups; }
     m.nwaves = nwaves;
     const size_t smem = (size_t)m.off_waves + (size_t)m.nwaves * m.wave_lds;
     if (smem > 160 * 1024) return hipErrorInvalidValue;
@@ -768,7 +849,7 @@ static hipError_t launch_mx_t(Mfma2Args& m, uint32_t max_nout, uint32_t nrows, h
     const uint32_t nwt_max = (max_nout + TILE - 1) / TILE;
     uint32_t gx = (uint32_t)(ncu * blocks_per_cu) / nrows;
     if (gx < 1) gx = 1;
-    const uint32_t need = (nwt_max + m.nwaves - 1) / m.nwaves;
+    const uint32_t need = coop ? nwt_max : (nwt_max + m.nwaves - 1) / m.nwaves;
     if (gx > need) gx = need;
     hipLaunchKernelGGL((d2d_fir_mx_kernel<MB, NT, G, KIND, SBY>), dim3(gx, nrows), dim3(64 * m.nwaves), smem, s, m);
     d2d_last_launched_kernel = launched_name<MB, NT, G, KIND, SBY>("d2d_fir_mx_kernel");
