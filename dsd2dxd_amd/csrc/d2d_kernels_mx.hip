@@ -197,7 +197,8 @@ __global__ __launch_bounds__(D2D_MX_THREADS) void d2d_fir_mx_kernel(Mfma2Args m)
                 const uint32_t g = lane + 64u * (wave + nw * (uint32_t)i);
                 const uint32_t tau = g << ts_sh;                // first frame of the piece = byte of a channel's stream, relative to the tile's first chunk
                 const int32_t Lw = (int32_t)(tau >> 2) - (int32_t)X0;
-                cad[i] = Lw < 0 ? DUMMY + (tau & 3u) : 4u * ((uint32_t)Lw + (uint32_t)Lw / (uint32_t)CS) + (tau & 3u);
+                if constexpr (FLAT) cad[i] = tau;                 // the unpadded image: a channel's bytes as they come
+                else cad[i] = Lw < 0 ? DUMMY + (tau & 3u) : 4u * ((uint32_t)Lw + (uint32_t)Lw / (uint32_t)CS) + (tau & 3u);
             }
         }
     }

@@ -350,3 +350,54 @@ def test_pipelined_stereo_kernel_fast_and_careful_tiles(engine_lib, oracle_mod, 
         assert pcm.max() == (1 << (bits - 1)) - 1 and pcm.min() == -(1 << (bits - 1))      # both rails were reached
     for c in range(2):
         assert e.peak(c) == o.peak(c)
+
+
+@pytest.mark.parametrize("channels,dsd_rate,out_rate,dither,endian", [(8, 8, 96000, "T", "M"), (4, 8, 96000, "X", "L"), (8, 4, 192000, "R", "M"),
+                                                                      (4, 2, 88200, "N", "M"), (8, 1, 88200, "N", "L")])
+def test_multichannel_interleaved_input_is_deinterleaved_inside_the_fir_kernel(engine_lib, oracle_mod, monkeypatch, channels, dsd_rate, out_rate, dither, endian):
+    """byte-interleaved 4- and 8-channel streams (DFF) into the stage-A / noise-shaper scratch through d2d_fir_mx_kernel (M = 32, 64): the
+    kernel's staging de-interleaves -- a block per (file, tile), one wave per channel pair, two block barriers per tile; tiles at the
+    call's edges (history in front, the ragged end) are gathered byte by byte.  Ragged calls, two files of different length, equal to
+    the oracle and to the pre-pass route (D2D_NO_COOP=1)."""
+    nbytes = 4096 * 9 * dsd_rate // 2 + 333
+    files = []
+    for f in range(2):
+        n = nbytes - 1500 * f
+        files.append([synth("sine" if (c + f) % 3 else "pink", n, seed=50 + 10 * f + c, dsd_rate=dsd_rate, msb_first=endian == "M",
+                            amp=0.4 if (c + f) % 3 else 0.098) for c in range(channels)])
+    kw = dict(dsd_rate=dsd_rate, output_rate=out_rate, channels=channels, fmt="I", endianness=endian, block_size=1,
+              filter="E", bit_depth=24, dither=dither, seed=17)
+    cuts = [0, 1000, 4096 * 2 + 7, nbytes - 1500 - 40, nbytes]
+    outs = {}
+    for nocoop in ("0", "1"):
+        monkeypatch.setenv("D2D_NO_COOP", nocoop)
+        import torch
+        e = engine_lib.Engine(n_files=2, kernel=2, **kw)
+        got = [[], []]
+        for a, b in zip(cuts[:-1], cuts[1:]):
+            bufs = [pack_layout([ch[min(a, len(ch)):min(b, len(ch))] for ch in files[f]], "I", 1) for f in range(2)]
+            lens = [buf.size // channels for buf in bufs]
+            d_in = [torch.from_numpy(buf).cuda() if buf.size else torch.zeros(16, dtype=torch.uint8, device="cuda") for buf in bufs]
+            d_out = [torch.zeros(e.next_frames(n, file=i) * e.frame_bytes + 16, dtype=torch.uint8, device="cuda") for i, n in enumerate(lens)]
+            ios = (engine_lib.FileIO * 2)()
+            for i, n in enumerate(lens):
+                ios[i].dsd = d_in[i].data_ptr(); ios[i].bytes_per_channel = n
+                ios[i].pcm = d_out[i].data_ptr(); ios[i].pcm_capacity_bytes = d_out[i].numel()
+            e.translate_batch_device(ios, torch.cuda.current_stream().cuda_stream)
+            torch.cuda.synchronize()
+            for f in range(2):
+                got[f].append(d_out[f][:ios[f].frames_out * e.frame_bytes].cpu().numpy())
+        outs[nocoop] = [np.concatenate(g) for g in got]
+        peaks = [[e.peak(c, f) for c in range(channels)] for f in range(2)]
+        if nocoop == "0":
+            assert "d2d_fir_mx_kernel" in e.kernel_name()
+            for f in range(2):
+                o = oracle_mod.Oracle(**kw)
+                want = []
+                for a, b in zip(cuts[:-1], cuts[1:]):
+                    w, fr = o.translate(pack_layout([ch[min(a, len(ch)):min(b, len(ch))] for ch in files[f]], "I", 1))
+                    want.append(w[:fr * channels * 3])
+                assert np.array_equal(outs["0"][f], np.concatenate(want))
+                assert peaks[f] == [o.peak(c) for c in range(channels)]
+    for f in range(2):
+        assert np.array_equal(outs["0"][f], outs["1"][f])
