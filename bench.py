@@ -479,22 +479,37 @@ def main():
             hios[f].bytes_per_channel = bpc
             hios[f].pcm = h_out[f].data_ptr()
             hios[f].pcm_capacity_bytes = frames * fb
-        e2.translate_batch_host(hios, args.pcie_slice)           # warm-up (allocates the staging)
-        reps = 2
-        if world > 1:
-            dist.barrier()
-        t1 = time.perf_counter()
-        for _ in range(reps):
-            e2.translate_batch_host(hios, args.pcie_slice)
-        dth = (time.perf_counter() - t1) / reps
-        if world > 1:
-            t = torch.tensor([dth], dtype=torch.float64, device=cdev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dth = float(t.item())
+        def host_pass():
+            e2.reset()
+            e2.translate_batch_host(hios, args.pcie_slice)       # warm-up (allocates what the route needs)
+            reps = 2
+            if world > 1:
+                dist.barrier()
+            t1 = time.perf_counter()
+            for _ in range(reps):
+                e2.translate_batch_host(hios, args.pcie_slice)
+            dth = (time.perf_counter() - t1) / reps
+            if world > 1:
+                t = torch.tensor([dth], dtype=torch.float64, device=cdev)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                dth = float(t.item())
+            return dth
         hb = args.files * (bpc * channels + frames * fb)
+        up_b, down_b = args.files * bpc * channels, args.files * frames * fb
+        forced = os.environ.get("D2D_HOST_STAGED")
+        dth = host_pass()                                        # pinned buffers: the kernels address them directly (one pass, no staging)
+        os.environ["D2D_HOST_STAGED"] = "1"
+        dts_ = host_pass()                                       # the sliced upload / convert / download pipeline (what pageable buffers get)
+        if forced is None:
+            del os.environ["D2D_HOST_STAGED"]
+        else:
+            os.environ["D2D_HOST_STAGED"] = forced
         out["pcie_inclusive"] = {"value": round(total_samples / args.steps / dth / 1e6, 3), "unit": "Msamples/s", "ms_per_step": round(dth * 1e3, 3),
                                  "host_bytes_per_step_per_gpu": int(hb), "link_GBps_both_ways_per_gpu": round(hb / dth / 1e9, 2),
-                                 "link_GBps_up_per_gpu": round(args.files * bpc * channels / dth / 1e9, 2), "link_GBps_down_per_gpu": round(args.files * frames * fb / dth / 1e9, 2),
+                                 "link_GBps_up_per_gpu": round(up_b / dth / 1e9, 2), "link_GBps_down_per_gpu": round(down_b / dth / 1e9, 2),
+                                 "route": "staged pipeline (D2D_HOST_STAGED)" if forced not in (None, "", "0") else "kernels read and write the pinned host buffers in place",
+                                 "staged_pipeline": {"ms_per_step": round(dts_ * 1e3, 3), "link_GBps_both_ways_per_gpu": round(hb / dts_ / 1e9, 2),
+                                                     "link_GBps_up_per_gpu": round(up_b / dts_ / 1e9, 2), "link_GBps_down_per_gpu": round(down_b / dts_ / 1e9, 2)},
                                  "note": "pinned host buffers -> pinned host buffers through d2d_translate_batch_host, all %d GPU(s) at once; never the reported value" % world}
         del e2
 

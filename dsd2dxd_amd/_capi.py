@@ -183,6 +183,12 @@ class Engine:
         self._check(lib().d2d_translate(self._h, buf.ctypes.data, bpc, out.ctypes.data, out.size, C.byref(frames)))
         return out[:frames.value * self.frame_bytes], frames.value
 
+    def translate_into(self, dsd_ptr, bytes_per_channel, pcm_ptr, pcm_capacity_bytes):
+        """d2d_translate on raw HOST addresses (e.g. pinned tensors: the kernels then work on them directly); returns frames."""
+        frames = C.c_size_t()
+        self._check(lib().d2d_translate(self._h, C.c_void_p(dsd_ptr), bytes_per_channel, C.c_void_p(pcm_ptr), pcm_capacity_bytes, C.byref(frames)))
+        return frames.value
+
     def translate_batch_device(self, ios, stream=None):
         """ios: ctypes array of FileIO with DEVICE pointers; asynchronous on `stream` (hipStream_t int)."""
         self._check(lib().d2d_translate_batch_device(self._h, ios, len(ios), C.c_void_p(stream or 0)))

@@ -110,7 +110,8 @@ size_t d2d_next_frames(const d2d_engine* e, uint32_t file, size_t bytes_per_chan
  * `bytes_per_channel` more bytes per channel of file 0 (channels*bytes_per_channel bytes at `dsd`,
  * laid out as params.fmt/block_size say; README.md:9), get interleaved little-endian PCM frames.
  * FIR history, resampler history, dither counter and peak carry over to the next call.
- * Host pointers: the call stages through pinned memory and returns when `pcm` is filled. */
+ * Host pointers; returns when `pcm` is filled.  Buffers the GPU can address (hipHostMalloc / hipHostRegister, 16-byte
+ * aligned) are read and written by the kernels in place; any other memory is staged through device buffers. */
 int d2d_translate(d2d_engine* e, const uint8_t* dsd, size_t bytes_per_channel,
                   void* pcm, size_t pcm_capacity_bytes, size_t* frames_out);
 
@@ -131,12 +132,15 @@ typedef struct d2d_file_io {
  * use one stream or order the streams with events. */
 int d2d_translate_batch_device(d2d_engine* e, d2d_file_io* io, uint32_t n_files, void* hip_stream);
 
-/* The same batch with HOST-resident buffers: `dsd` and `pcm` of every d2d_file_io are host pointers
- * (pinned memory -- hipHostMalloc / hipHostRegister -- lets the three stages overlap; pageable memory
- * works but serialises).  The engine cuts the batch along time into slices of about
- * `slice_bytes_per_channel` (0 = 4 MiB; whole planar blocks), and runs upload, conversion and download
- * of consecutive slices on three streams over double-buffered device staging, so that the PCIe link
- * and the kernels work at the same time.  Synchronous: returns when every `pcm` is filled;
+/* The same batch with HOST-resident buffers: `dsd` and `pcm` of every d2d_file_io are host pointers.
+ * PINNED buffers (hipHostMalloc / hipHostRegister, 16-byte aligned) are addressed by the kernels
+ * themselves: one set of launches reads the DSD and writes the frames over the link, so upload,
+ * conversion and download overlap by construction and nothing is staged (bench shape: 90 GB/s over
+ * the link both ways, `pcie_inclusive`).  Any other memory -- or D2D_HOST_STAGED=1, or a file of 2 GiB
+ * per channel and more -- takes the pipeline: the batch is cut along time into slices of about
+ * `slice_bytes_per_channel` (0 = 4 MiB; whole planar blocks), and upload, conversion and download
+ * of consecutive slices run on three streams over double-buffered device staging (77 GB/s with
+ * pinned buffers; pageable ones serialise).  Synchronous: returns when every `pcm` is filled;
  * io[i].frames_out is the total.  What the many-file path of a host that holds its files in RAM
  * calls; the reference's analogue is one Rayon worker per file reading,
  * converting and writing block by block (src/main.rs:280-300,345). */

@@ -175,12 +175,21 @@ def test_engines_on_concurrent_threads(engine_lib, oracle_mod):
         assert got[i][1] == rf and np.array_equal(got[i][0], r[:rf * fb]), i
 
 
-@pytest.mark.parametrize("out_rate,fmt,pinned", [(88200, "P", True), (96000, "I", False), (176400, "P", False)])
-def test_host_resident_batch_pipeline(engine_lib, oracle_mod, out_rate, fmt, pinned):
+@pytest.mark.parametrize("out_rate,fmt,pinned,staged", [(88200, "P", True, True), (88200, "P", True, False), (96000, "I", True, False), (96000, "I", False, False),
+                                                        (176400, "P", False, False), (88200, "N24", True, False)])
+def test_host_resident_batch_pipeline(engine_lib, oracle_mod, monkeypatch, out_rate, fmt, pinned, staged):
     """d2d_translate_batch_host: ragged files, many slices (upload / convert / download overlapped), state
-    carried from slice to slice; the bytes equal the oracle's one-shot conversion of each file"""
+    carried from slice to slice; the bytes equal the oracle's one-shot conversion of each file.  Pinned buffers are
+    read and written by the kernels themselves (no staging, one call) unless D2D_HOST_STAGED=1 keeps the pipeline."""
     import torch
-    kw = dict(KW, output_rate=out_rate, fmt=fmt, endianness="L" if fmt == "P" else "M")
+    if staged:
+        monkeypatch.setenv("D2D_HOST_STAGED", "1")
+    else:
+        monkeypatch.delenv("D2D_HOST_STAGED", raising=False)
+    extra = {}
+    if fmt == "N24":
+        fmt, extra = "P", dict(dither="N")
+    kw = dict(KW, output_rate=out_rate, fmt=fmt, endianness="L" if fmt == "P" else "M", **extra)
     lens = [4096 * 7 + 123, 4096 * 3, 0, 4096 * 12 + 4000]
     files = [pack_layout([random_bytes(n, 60 + i), random_bytes(n, 70 + i)], fmt, 4096 if fmt == "P" else 1) for i, n in enumerate(lens)]
     e = engine_lib.Engine(n_files=len(lens), kernel=2, **kw)
@@ -208,11 +217,39 @@ def test_host_resident_batch_pipeline(engine_lib, oracle_mod, out_rate, fmt, pin
         e2.translate_batch_host(ios, 8192)
 
 
+@pytest.mark.parametrize("out_rate,dither", [(88200, "T"), (96000, "T"), (88200, "N")])
+def test_per_block_calls_on_pinned_buffers_need_no_staging(engine_lib, oracle_mod, monkeypatch, out_rate, dither):
+    """d2d_translate with buffers the GPU can address (hipHostMalloc / hipHostRegister: torch's pinned tensors): the kernels read
+    and write them in place, call after call with carried state; same bytes as the staged route and the oracle"""
+    import torch
+    kw = dict(KW, output_rate=out_rate, dither=dither)
+    blocks = [4096 * 2, 4096, 4096 * 5, 4096 * 3]
+    data = [pack_layout([random_bytes(n, 300 + i), random_bytes(n, 310 + i)], "P", 4096) for i, n in enumerate(blocks)]
+    o = oracle_mod.Oracle(**kw)
+    want = [o.translate(b) for b in data]
+    got = {}
+    for staged in ("0", "1"):
+        monkeypatch.setenv("D2D_HOST_STAGED", staged)
+        e = engine_lib.Engine(n_files=1, kernel=2, **kw)
+        fb = e.frame_bytes
+        res = []
+        for b, n in zip(data, blocks):
+            ti = torch.from_numpy(b.copy()).pin_memory()
+            to = torch.zeros(e.next_frames(n) * fb + 64, dtype=torch.uint8).pin_memory()
+            fr = e.translate_into(ti.data_ptr(), n, to.data_ptr(), to.numel())
+            res.append((to[:fr * fb].numpy().copy(), fr))
+        got[staged] = res
+    for (r, rf), (a, af), (b, bf) in zip(want, got["0"], got["1"]):
+        assert af == bf == rf and np.array_equal(a, r[:rf * 6]) and np.array_equal(b, a)
+
+
+@pytest.mark.parametrize("staged", [True, False])
 @pytest.mark.parametrize("block", [100, 4100, 7])
-def test_host_resident_batch_with_odd_block_sizes(engine_lib, oracle_mod, block):
+def test_host_resident_batch_with_odd_block_sizes(engine_lib, oracle_mod, monkeypatch, block, staged):
     """slices of d2d_translate_batch_host must be whole planar blocks for ANY block size (-s takes any
     value); rounding the slice to 16 bytes afterwards cut blocks in two and mixed the channels."""
     import torch
+    monkeypatch.setenv("D2D_HOST_STAGED", "1" if staged else "0")
     kw = dict(KW, output_rate=88200, fmt="P", endianness="L", block_size=block)
     lens = [block * 37 + 11, block * 5, block * 64]
     files = [pack_layout([random_bytes(n, 160 + i), random_bytes(n, 170 + i)], "P", block) for i, n in enumerate(lens)]
