@@ -89,6 +89,7 @@ struct d2d_engine {
     uint8_t* d_planar = nullptr; size_t planar_stride = 0;
     bool deinterleave = false;
     bool coop = false;                    // byte-interleaved 4/8-channel input de-interleaved inside the fp6 kernel's staging (FirArgs::coop)
+    bool il2 = false;                     // byte-interleaved stereo input de-interleaved inside the pipelined frame kernels' staging (FirArgs::il2)
     uint8_t* d_out = nullptr; size_t d_out_cap = 0;
 
     int fail(int code, const std::string& m) { err = m; return code; }
@@ -195,6 +196,7 @@ static void fir_args_static(const d2d_engine* e, FirArgs& a) {
     a.pipelined = (uint32_t)e->mfma_pipe;
     a.mx_exact = mx_exact(*e->fc.fir) ? 1u : 0u;
     a.coop = e->coop ? 1u : 0u;
+    a.il2 = e->il2 ? 1u : 0u;
 }
 
 namespace d2d { thread_local const char* d2d_last_launched_kernel = nullptr; }
@@ -299,6 +301,10 @@ int d2d_create(const d2d_params* params, uint32_t n_files, d2d_engine** out) {
             if (e->deinterleave && e->mfma_pipe == 5 && (e->fc.resamp || e->noise_shape) && e->C == e->Cin && (e->Cin == 8 || e->Cin == 4) &&
                 !(nocoop && atoi(nocoop))) {
                 e->coop = true; e->deinterleave = false; e->B = 1;
+            }
+            // byte-interleaved stereo (DFF files, the CLI's default -f I) into frames through the fp6 kernel: the same, inside one wave
+            if (e->deinterleave && e->mfma_pipe == 5 && !e->fc.resamp && !e->noise_shape && e->Cin == 2 && e->C == 2 && !(nocoop && atoi(nocoop))) {
+                e->il2 = true; e->deinterleave = false; e->B = 1;
             }
         }
         std::vector<int8_t> t = e->mfma_pipe == 5 ? build_mx_tables(f, msb) : e->mfma_pipe == 4 ? build_mfma4_tables(f, msb)

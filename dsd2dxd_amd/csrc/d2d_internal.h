@@ -64,6 +64,8 @@ struct FirArgs {
                                // 5 the fp6 x fp4 kernel of d2d_kernels_mx.hip)
     uint32_t coop;             // 1 (d2d_kernels_mx.hip, scratch flavour): byte-interleaved 4- or 8-channel input, every channel converted: the kernel
                                // de-interleaves inside its staging, a block per (file, tile) with one wave per channel pair; B = 1 then
+    uint32_t il2;              // 1 (pipelined frame kernels): byte-interleaved STEREO input (DFF, -f I), both channels converted: the kernel's staging
+                               // pulls the channels apart (one v_perm_b32 per channel and eight input bytes); B = 1, no planar copy
     uint32_t mx_exact;         // 1: the table's base-32 digit sums recombine exactly in f32 (d2d_mx.h: mx_exact)
     Epilogue epi;
 };

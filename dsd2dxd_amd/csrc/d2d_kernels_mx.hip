@@ -123,20 +123,27 @@ __global__ __launch_bounds__(D2D_MX_THREADS) void d2d_fir_mx_kernel(Mfma2Args m)
     // FLAT: chunk q at byte 16 q, window dword L at LDS dword L + X0 ----
     const uint32_t X0 = (uint32_t)(first0 >> 2) & 3u;
     constexpr uint32_t DUMMY = SB - 16u;
+    // IL (a.il2: byte-interleaved stereo -- DFF files, the CLI's default -f I -- both channels converted, frame flavours): the tile's
+    // frames come as they lie in memory, 2 NCHK pieces of 16 bytes = eight frames each, in two halves of PF pieces per lane; one
+    // v_perm_b32 per channel and dword pair pulls a channel's bytes (run_loop below).  Piece g holds a channel's bytes 8 g .. 8 g + 7.
+    const bool il = !SCR && a.il2 != 0;
+    auto pad_addr = [&](int32_t L, uint32_t k) -> uint32_t { return L < 0 ? DUMMY + 4u * k : 4u * ((uint32_t)L + (uint32_t)L / (uint32_t)CS); };
     uint32_t wad[FLAT ? 1 : PF][4];
     if constexpr (!FLAT) {
 #pragma unroll
         for (int i = 0; i < PF; ++i)
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                const int32_t L = (int32_t)(4u * (lane + 64u * i)) - (int32_t)X0 + k;
-                wad[i][k] = L < 0 ? DUMMY + 4u * k : 4u * ((uint32_t)L + (uint32_t)L / (uint32_t)CS);
+                // IL: entry 2 H + kk = dword kk of the piece the lane holds in slot i of half H
+                const int32_t L = il ? (int32_t)(2u * (lane + 64u * ((uint32_t)PF * (k >> 1) + i))) - (int32_t)X0 + (k & 1)
+                                     : (int32_t)(4u * (lane + 64u * i)) - (int32_t)X0 + k;
+                wad[i][k] = pad_addr(L, (uint32_t)k);
             }
     }
     const uint32_t Bsz = a.B, Lcall = (uint32_t)j0.L;
     const bool pow2B = Bsz >= 16 && (Bsz & (Bsz - 1)) == 0;
     const uint32_t bshift = pow2B ? 31 - __builtin_clz(Bsz) : 0;
-    const uint32_t full_bytes = pow2B ? (Lcall >> bshift) << bshift : 0;
+    const uint32_t full_bytes = il ? Lcall : pow2B ? (Lcall >> bshift) << bshift : 0;
     const uint32_t jump = (Ct - 1u) * Bsz;
     const bool fast_layout = pow2B && (uint64_t)full_bytes * Ct < (1ull << 32) && jump < (1u << 24);
     auto tile_ab16 = [&](uint32_t w) -> int32_t { return (int32_t)((first0 + (int64_t)w * (TILE * MB)) & ~(int64_t)15); };
@@ -167,7 +174,7 @@ __global__ __launch_bounds__(D2D_MX_THREADS) void d2d_fir_mx_kernel(Mfma2Args m)
             }
         }
     };
-    auto write_lds = [&](auto cc) {
+    auto write_lds_t = [&](auto cc, auto calc) {      // calc: the addresses are worked out here (IL: wad holds the other set)
         constexpr int c = decltype(cc)::value;
         uint8_t* buf = wbase + c * SB;
 #pragma unroll
@@ -177,9 +184,33 @@ __global__ __launch_bounds__(D2D_MX_THREADS) void d2d_fir_mx_kernel(Mfma2Args m)
                 else {
                     const uint32_t v[4] = {pf[i].x, pf[i].y, pf[i].z, pf[i].w};
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) *reinterpret_cast<uint32_t*>(buf + wad[i][k]) = v[k];
+                    for (int k = 0; k < 4; ++k) {
+                        if constexpr (decltype(calc)::value) *reinterpret_cast<uint32_t*>(buf + pad_addr((int32_t)(4u * (lane + 64u * i)) - (int32_t)X0 + k, (uint32_t)k)) = v[k];
+                        else *reinterpret_cast<uint32_t*>(buf + wad[i][k]) = v[k];
+                    }
                 }
             }
+    };
+    auto write_lds = [&](auto cc) { write_lds_t(cc, std::false_type{}); };
+    // IL staging: half H of the joint tile = pieces lane + 64 (PF H + i)
+    auto il_issue = [&](uint32_t w, auto hc) {
+        constexpr uint32_t H = decltype(hc)::value;
+        const uint8_t* src = j0.in + 2u * (size_t)(uint32_t)tile_ab16(w);
+#pragma unroll
+        for (int i = 0; i < PF; ++i) {
+            uint32_t g = lane + 64u * ((uint32_t)PF * H + (uint32_t)i);
+            g = g < 2u * (uint32_t)NCHK ? g : 2u * (uint32_t)NCHK - 1u;           // (slots past the last piece re-read it; their writes are masked)
+            pf[i] = *reinterpret_cast<D2D_GLOBAL const u32x4*>(as_global(src) + 16u * g);
+        }
+    };
+    auto il_put = [&](uint32_t c, auto hc, int i, uint32_t x, uint32_t y) {       // eight bytes of channel c from slot i of half H
+        constexpr uint32_t H = decltype(hc)::value;
+        const uint32_t g = lane + 64u * ((uint32_t)PF * H + (uint32_t)i);
+        uint8_t* buf = wbase + c * SB;
+        if (g < 2u * (uint32_t)NCHK) {
+            if constexpr (FLAT) { u32x2 v; v.x = x; v.y = y; *reinterpret_cast<u32x2*>(buf + 8u * g) = v; }
+            else { *reinterpret_cast<uint32_t*>(buf + wad[i][2u * H]) = x; *reinterpret_cast<uint32_t*>(buf + wad[i][2u * H + 1u]) = y; }
+        }
     };
 
     // ---- COOP: the tile's bytes of all channels come as they lie in memory (frame after frame), each wave fetching a share of the 16-byte
@@ -551,11 +582,36 @@ __global__ __launch_bounds__(D2D_MX_THREADS) void d2d_fir_mx_kernel(Mfma2Args m)
     // The pipelined loop over the tiles t_begin + wv + k * wstride < t_end:
     //   region A (tile t):  chain of channel 0  ||  requantise channel 1 of tile t-1; its frames leave after the next prefetch is out
     //   region B (tile t):  chain of channel 1  ||  requantise channel 0 of tile t
-    auto run_loop = [&](uint32_t t_begin, uint32_t t_end, auto af) {
+    //   IL (byte-interleaved stereo; every tile of the range inside the call): a piece carries both channels, so channel 0's bytes of the
+    //   NEXT tile go to its buffer while channel 1's chain runs, and channel 1's wait in `keep` (two registers per piece) until their
+    //   buffer is free one region later; each piece is fetched once, a whole chain ahead:
+    //   A start: [pf = 2nd half of tile t]  ch0 part -> buf0, ch1 part -> buf1, keep (1st half, ch1) -> buf1;  request 1st half of tile t+1
+    //   B start: [pf = 1st half of tile t+1]  ch0 part -> buf0, ch1 part -> keep;                              request 2nd half of tile t+1
+    auto run_loop = [&](uint32_t t_begin, uint32_t t_end, auto af, auto ilc) {
         constexpr bool AF = decltype(af)::value;
+        constexpr bool IL = decltype(ilc)::value;
+        static_assert(!IL || AF, "the interleaved staging has no gather path");
+        [[maybe_unused]] uint32_t keep[IL ? 2 * PF : 1];
+        [[maybe_unused]] auto il_first = [&]() {           // pf = a tile's first half: channel 0's bytes to its buffer, channel 1's kept
+#pragma unroll
+            for (int i = 0; i < PF; ++i) {
+                il_put(0u, C0{}, i, __builtin_amdgcn_perm(pf[i].y, pf[i].x, 0x06040200u), __builtin_amdgcn_perm(pf[i].w, pf[i].z, 0x06040200u));
+                keep[2 * i] = __builtin_amdgcn_perm(pf[i].y, pf[i].x, 0x07050301u);
+                keep[2 * i + 1] = __builtin_amdgcn_perm(pf[i].w, pf[i].z, 0x07050301u);
+            }
+        };
+        [[maybe_unused]] auto il_second = [&]() {          // pf = the second half: both channels' bytes, and the kept ones, to their buffers
+#pragma unroll
+            for (int i = 0; i < PF; ++i) {
+                il_put(0u, C1{}, i, __builtin_amdgcn_perm(pf[i].y, pf[i].x, 0x06040200u), __builtin_amdgcn_perm(pf[i].w, pf[i].z, 0x06040200u));
+                il_put(1u, C1{}, i, __builtin_amdgcn_perm(pf[i].y, pf[i].x, 0x07050301u), __builtin_amdgcn_perm(pf[i].w, pf[i].z, 0x07050301u));
+                il_put(1u, C0{}, i, keep[2 * i], keep[2 * i + 1]);
+            }
+        };
         uint32_t wt = t_begin + wv;
         if (wt < t_end) {
             if (coop) { if (coop_fast(wt)) coop_issue(wt); }
+            else if constexpr (IL) { il_issue(wt, C0{}); wave_sync2(); il_first(); il_issue(wt, C1{}); }
             else issue_loads(wt, C0{}, af);
             // AF: every trip issues the same loads and stores in the same order (the first trip stores whatever the slice holds to its
             // own tile, rewritten one trip later; the last trip re-requests its own tile): the compiler can then count its waits
@@ -583,6 +639,11 @@ __global__ __launch_bounds__(D2D_MX_THREADS) void d2d_fir_mx_kernel(Mfma2Args m)
                 }
                 if (more && coop_fast(nxt)) coop_issue(nxt);
                 __syncthreads();
+            } else if constexpr (IL) {
+                wave_sync2();
+                il_second();
+                il_issue(nxt, C0{});
+                wave_sync2();
             } else {
                 wave_sync2();
                 if (!(dbg & 4)) {
@@ -610,7 +671,10 @@ __global__ __launch_bounds__(D2D_MX_THREADS) void d2d_fir_mx_kernel(Mfma2Args m)
             // ---- region B ----
             stamp(2);
             wave_sync2();
-            if (!(dbg & 4) && !coop) {
+            if constexpr (IL) {
+                il_first();
+                il_issue(nxt, C1{});
+            } else if (!(dbg & 4) && !coop) {
                 write_lds(C1{});
                 if (AF || more) issue_loads(nxt, C0{}, af);
             }
@@ -652,9 +716,9 @@ __global__ __launch_bounds__(D2D_MX_THREADS) void d2d_fir_mx_kernel(Mfma2Args m)
     auto slow_tile = [&](uint32_t t) {
         wave_sync2();
         issue_loads(t, C0{}, std::false_type{});
-        write_lds(C0{});
+        if (il) write_lds_t(C0{}, std::true_type{}); else write_lds(C0{});
         issue_loads(t, C1{}, std::false_type{});
-        write_lds(C1{});
+        if (il) write_lds_t(C1{}, std::true_type{}); else write_lds(C1{});
         wave_sync2();
         int32_t o0[NS], o1[NS];
         redo(0u, t, 0, o0);
@@ -667,7 +731,8 @@ __global__ __launch_bounds__(D2D_MX_THREADS) void d2d_fir_mx_kernel(Mfma2Args m)
             store_tile(t);
         }
     };
-    if (fast_layout && !SCR) {
+    if constexpr (SCR) run_loop(0u, nwt, std::false_type{}, std::false_type{});
+    else if (fast_layout || il) {
         // the tiles [t_lo, t_hi) lie inside the call's full blocks: the loop without the gather path; the few around them one by one
         const int64_t T = (int64_t)TILE * MB;
         auto is_fast = [&](uint32_t w) { const int32_t ab = tile_ab16(w); return ab >= 0 && (uint32_t)ab + 16u * NCHK <= full_bytes; };
@@ -681,11 +746,12 @@ __global__ __launch_bounds__(D2D_MX_THREADS) void d2d_fir_mx_kernel(Mfma2Args m)
             while (t_hi < nwt && t_hi >= t_lo && is_fast(t_hi) && (t_hi > t_lo || is_fast(t_lo))) ++t_hi;
         }
         { const uint32_t nfull = j0.nout / (uint32_t)TILE; if (t_hi > nfull) t_hi = nfull > t_lo ? nfull : t_lo; }     // whole tiles only
-        run_loop(t_lo, t_hi, std::true_type{});
+        if (il) run_loop(t_lo, t_hi, std::true_type{}, std::true_type{});
+        else run_loop(t_lo, t_hi, std::true_type{}, std::false_type{});
         const uint32_t n_edge = t_lo + (nwt - t_hi);
         for (uint32_t i = wv; i < n_edge; i += wstride) slow_tile(i < t_lo ? i : t_hi + (i - t_lo));
     } else {
-        run_loop(0u, nwt, std::false_type{});
+        run_loop(0u, nwt, std::false_type{}, std::false_type{});
     }
 
 #if D2D_MX_STAMPS

@@ -401,3 +401,56 @@ def test_multichannel_interleaved_input_is_deinterleaved_inside_the_fir_kernel(e
                 assert peaks[f] == [o.peak(c) for c in range(channels)]
     for f in range(2):
         assert np.array_equal(outs["0"][f], outs["1"][f])
+
+
+@pytest.mark.parametrize("dsd_rate,out_rate,bits,dither,endian,nbytes", [
+    (1, 88200, 24, "T", "M", 4096 * 9 + 333), (1, 88200, 16, "R", "L", 4096 * 9 + 333), (1, 88200, 32, "X", "M", 4096 * 5 + 17),
+    (2, 88200, 24, "T", "M", 4096 * 18 + 100), (2, 176400, 16, "X", "L", 4096 * 9 + 333), (4, 176400, 24, "R", "M", 4096 * 30 + 5),
+    (1, 88200, 24, "T", "M", 6_000_000 + 123), (2, 88200, 24, "R", "M", 9_000_000 + 77)])
+def test_interleaved_stereo_is_deinterleaved_inside_the_fir_kernel(engine_lib, oracle_mod, monkeypatch, dsd_rate, out_rate, bits, dither, endian, nbytes):
+    """byte-interleaved STEREO (DFF files, the reference CLI's default -f I) into frames through d2d_fir_mx_kernel (M = 32, 64): the wave
+    that converts the pair pulls the channels apart inside its staging (both LDS images; pieces fetched once, channel 1's bytes parked
+    in registers for one region); tiles at the call's edges are gathered byte by byte.  Ragged calls, two files of different length,
+    waves that walk several tiles (the long cases); equal to the oracle and to the pre-pass route (D2D_NO_COOP=1)."""
+    import torch
+    files = []
+    for f in range(2):
+        n = nbytes - 1501 * f
+        files.append([synth("sine" if (c + f) % 2 else "pink", n, seed=150 + 10 * f + c, dsd_rate=dsd_rate, msb_first=endian == "M",
+                            amp=0.45 if (c + f) % 2 else 0.098) for c in range(2)])
+    kw = dict(dsd_rate=dsd_rate, output_rate=out_rate, channels=2, fmt="I", endianness=endian, block_size=1,
+              filter="E", bit_depth=bits, dither=dither, seed=23)
+    cuts = [0, 1000, 4096 * 2 + 7, nbytes - 1501 - 40, nbytes]
+    outs = {}
+    for nocoop in ("0", "1"):
+        monkeypatch.setenv("D2D_NO_COOP", nocoop)
+        e = engine_lib.Engine(n_files=2, kernel=2, **kw)
+        fb = e.frame_bytes
+        got = [[], []]
+        for a, b in zip(cuts[:-1], cuts[1:]):
+            bufs = [pack_layout([ch[min(a, len(ch)):min(b, len(ch))] for ch in files[f]], "I", 1) for f in range(2)]
+            lens = [buf.size // 2 for buf in bufs]
+            d_in = [torch.from_numpy(buf).cuda() if buf.size else torch.zeros(16, dtype=torch.uint8, device="cuda") for buf in bufs]
+            d_out = [torch.zeros(e.next_frames(n, file=i) * fb + 16, dtype=torch.uint8, device="cuda") for i, n in enumerate(lens)]
+            ios = (engine_lib.FileIO * 2)()
+            for i, n in enumerate(lens):
+                ios[i].dsd = d_in[i].data_ptr(); ios[i].bytes_per_channel = n
+                ios[i].pcm = d_out[i].data_ptr(); ios[i].pcm_capacity_bytes = d_out[i].numel()
+            e.translate_batch_device(ios, torch.cuda.current_stream().cuda_stream)
+            torch.cuda.synchronize()
+            for f in range(2):
+                got[f].append(d_out[f][:ios[f].frames_out * fb].cpu().numpy())
+        outs[nocoop] = [np.concatenate(g) for g in got]
+        peaks = [[e.peak(c, f) for c in range(2)] for f in range(2)]
+        if nocoop == "0":
+            assert "d2d_fir_mx_kernel" in e.kernel_name()
+            for f in range(2):
+                o = oracle_mod.Oracle(**kw)
+                want = []
+                for a, b in zip(cuts[:-1], cuts[1:]):
+                    w, fr = o.translate(pack_layout([ch[min(a, len(ch)):min(b, len(ch))] for ch in files[f]], "I", 1))
+                    want.append(w[:fr * fb])
+                assert np.array_equal(outs["0"][f], np.concatenate(want)), f
+                assert peaks[f] == [o.peak(c) for c in range(2)]
+    for f in range(2):
+        assert np.array_equal(outs["0"][f], outs["1"][f])
