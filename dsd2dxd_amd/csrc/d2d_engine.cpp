@@ -302,8 +302,10 @@ int d2d_create(const d2d_params* params, uint32_t n_files, d2d_engine** out) {
                 !(nocoop && atoi(nocoop))) {
                 e->coop = true; e->deinterleave = false; e->B = 1;
             }
-            // byte-interleaved stereo (DFF files, the CLI's default -f I) into frames through the fp6 kernel: the same, inside one wave
-            if (e->deinterleave && e->mfma_pipe == 5 && !e->fc.resamp && !e->noise_shape && e->Cin == 2 && e->C == 2 && !(nocoop && atoi(nocoop))) {
+            // byte-interleaved stereo (DFF files, the CLI's default -f I) into frames through a pipelined kernel (fp6: M = 32, 64; int8: M = 8, 16):
+            // the same, inside one wave
+            if (e->deinterleave && (e->mfma_pipe == 5 || (e->mfma_pipe == 3 && e->M < 64)) && !e->fc.resamp && !e->noise_shape && e->Cin == 2 && e->C == 2 &&
+                !(nocoop && atoi(nocoop))) {
                 e->il2 = true; e->deinterleave = false; e->B = 1;
             }
         }

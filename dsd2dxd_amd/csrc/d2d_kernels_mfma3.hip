@@ -146,7 +146,22 @@ __global__ __launch_bounds__(D2D_M3_THREADS) void d2d_fir_mfma3_kernel(Mfma2Args
     const uint32_t Bsz = a.B, Lcall = (uint32_t)j0.L;
     const bool pow2B = Bsz >= 16 && (Bsz & (Bsz - 1)) == 0;
     const uint32_t bshift = pow2B ? 31 - __builtin_clz(Bsz) : 0;
-    const uint32_t full_bytes = pow2B ? (Lcall >> bshift) << bshift : 0;
+    // IL (a.il2: byte-interleaved stereo -- DFF files, the CLI's default -f I -- both channels converted, frame flavours, M < 64): the
+    // tile's frames come as they lie in memory, 2 NCHK pieces of 16 bytes = eight frames each, slot s of a lane = piece lane + 64 s;
+    // one v_perm_b32 per channel and dword pair pulls a channel's eight bytes = its stream dwords 2 g, 2 g + 1 (run_loop below)
+    constexpr bool ILK = !SCR && MB < 8;
+    const bool il = ILK && a.il2 != 0;
+    const uint32_t full_bytes = il ? Lcall : pow2B ? (Lcall >> bshift) << bshift : 0;
+    uint32_t wil[ILK ? 2 * PF : 1][2];
+    if constexpr (ILK) {
+#pragma unroll
+        for (int sl = 0; sl < 2 * PF; ++sl)
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                const int32_t L = (int32_t)(2u * (lane + 64u * sl)) + kk - (int32_t)X0;
+                wil[sl][kk] = L < 0 ? DUMMY + 4u * kk : 4u * ((uint32_t)L + ((uint32_t)L >> LSH));
+            }
+    }
     const uint32_t jump = (Ct - 1u) * Bsz;
     const bool fast_layout = pow2B && (uint64_t)full_bytes * Ct < (1ull << 32) && jump < (1u << 24);
     auto tile_ab16 = [&](uint32_t w) -> int32_t { return (int32_t)((first0 + (int64_t)w * (M2_TILE * MB)) & ~(int64_t)15); };
@@ -201,6 +216,27 @@ __global__ __launch_bounds__(D2D_M3_THREADS) void d2d_fir_mfma3_kernel(Mfma2Args
         else if (X0 == 1) write_lds_x(cc, std::integral_constant<int, 1>{});
         else if (X0 == 2) write_lds_x(cc, std::integral_constant<int, 2>{});
         else write_lds_x(cc, std::integral_constant<int, 3>{});
+    };
+
+    auto il_issue = [&](uint32_t w) {
+        if constexpr (ILK) {
+            const uint8_t* src = j0.in + 2u * (size_t)(uint32_t)tile_ab16(w);
+#pragma unroll
+            for (int sl = 0; sl < 2 * PF; ++sl) {
+                uint32_t g = lane + 64u * (uint32_t)sl;
+                g = g < 2u * (uint32_t)NCHK ? g : 2u * (uint32_t)NCHK - 1u;       // (slots past the last piece re-read it; their writes are masked)
+                pf[sl / PF][sl % PF] = *reinterpret_cast<D2D_GLOBAL const u32x4*>(as_global(src) + 16u * g);
+            }
+        }
+    };
+    auto il_put = [&](uint32_t c, int sl, uint32_t x, uint32_t y) {
+        if constexpr (ILK) {
+            uint8_t* buf = wbase + c * SB;
+            if (lane + 64u * (uint32_t)sl < 2u * (uint32_t)NCHK) {
+                *reinterpret_cast<uint32_t*>(buf + wil[sl][0]) = x;
+                *reinterpret_cast<uint32_t*>(buf + wil[sl][1]) = y;
+            }
+        }
     };
 
     const v4i* tp = reinterpret_cast<const v4i*>(smem) + lane;      // fragment f: tp[64 * f]
@@ -551,15 +587,24 @@ __global__ __launch_bounds__(D2D_M3_THREADS) void d2d_fir_mfma3_kernel(Mfma2Args
     using C0 = std::integral_constant<int, 0>;
     using C1 = std::integral_constant<int, 1>;
     // The pipelined loop over the tiles t_begin + wv + k * wstride < t_end.
-    auto run_loop = [&](uint32_t t_begin, uint32_t t_end, auto af) {
+    //   IL (byte-interleaved stereo, two prefetch sets = all pieces of a tile; every tile of the range inside the call):
+    //   A start: [pf = the pieces of tile t]  ch0 parts -> buf0, ch1 parts -> keep;  request the pieces of tile t+1 (a whole tile ahead)
+    //   B start: keep -> buf1
+    auto run_loop = [&](uint32_t t_begin, uint32_t t_end, auto af, auto ilc) {
         constexpr bool AF = decltype(af)::value;
+        constexpr bool IL = decltype(ilc)::value;
+        static_assert(!IL || (AF && ILK && NPFSET == 2), "the interleaved staging: the fixed-order loop with two prefetch sets");
+        [[maybe_unused]] uint32_t keep[IL ? 4 * PF : 1];
         uint32_t wt = t_begin + wv;
         // the packed frames of the tile before: AF keeps them across trips (it stores on every trip), the general loop only from
         // the pack to the store
         u32x4 p4h[2] = {u32x4{0, 0, 0, 0}, u32x4{0, 0, 0, 0}}, p2h[2] = {u32x4{0, 0, 0, 0}, u32x4{0, 0, 0, 0}};
         if (wt < t_end) {
-            issue_loads(wt, C0{}, af);
-            if constexpr (NPFSET == 2) issue_loads(wt, C1{}, af);
+            if constexpr (IL) il_issue(wt);
+            else {
+                issue_loads(wt, C0{}, af);
+                if constexpr (NPFSET == 2) issue_loads(wt, C1{}, af);
+            }
             // AF: every trip issues the same loads and stores in the same order (the first trip stores zeros to its own tile, rewritten one
             // trip later; the last trip re-requests its own tile), so that the compiler can count exactly how many younger requests
             // may stay in flight at each LDS write -- with a conditional load or store in the loop it waits for all of them
@@ -580,7 +625,16 @@ __global__ __launch_bounds__(D2D_M3_THREADS) void d2d_fir_mfma3_kernel(Mfma2Args
             // ---- region A: channel 0's chain of tile wt, channel 1's epilogue of tile pw ----
             stamp(2);
             wave_sync2();
-            if (!(dbg & 4)) {
+            if constexpr (IL) {
+#pragma unroll
+                for (int sl = 0; sl < 2 * PF; ++sl) {
+                    const u32x4 d = pf[sl / PF][sl % PF];
+                    il_put(0u, sl, __builtin_amdgcn_perm(d.y, d.x, 0x06040200u), __builtin_amdgcn_perm(d.w, d.z, 0x06040200u));
+                    keep[2 * sl] = __builtin_amdgcn_perm(d.y, d.x, 0x07050301u);
+                    keep[2 * sl + 1] = __builtin_amdgcn_perm(d.w, d.z, 0x07050301u);
+                }
+                il_issue(nxt);
+            } else if (!(dbg & 4)) {
                 write_lds(C0{});
                 if constexpr (NPFSET == 2) { if (AF || more) issue_loads(nxt, C0{}, af); }
                 else issue_loads(wt, C1{}, af);
@@ -606,7 +660,10 @@ __global__ __launch_bounds__(D2D_M3_THREADS) void d2d_fir_mfma3_kernel(Mfma2Args
             // ---- region B: channel 1's chain of tile wt, channel 0's epilogue of tile wt ----
             stamp(2);
             wave_sync2();
-            if (!(dbg & 4)) {
+            if constexpr (IL) {
+#pragma unroll
+                for (int sl = 0; sl < 2 * PF; ++sl) il_put(1u, sl, keep[2 * sl], keep[2 * sl + 1]);
+            } else if (!(dbg & 4)) {
                 write_lds(C1{});
                 if (AF || more) { if constexpr (NPFSET == 2) issue_loads(nxt, C1{}, af); else issue_loads(nxt, C0{}, af); }
             }
@@ -661,7 +718,7 @@ __global__ __launch_bounds__(D2D_M3_THREADS) void d2d_fir_mfma3_kernel(Mfma2Args
         pack_tile(t, o0, o1, p4, p2);
         store_packed(t, p4, p2);
     };
-    if (fast_layout && MB < 8 && !SCR) {       // (M = 64: the general loop is faster there, 3.01 against 3.18 ms)
+    if ((fast_layout || il) && MB < 8 && !SCR) {       // (M = 64: the general loop is faster there, 3.01 against 3.18 ms)
         // the tiles [t_lo, t_hi) lie inside the call's full blocks: the loop without the gather path; the few around them one by one
         const int64_t T = (int64_t)M2_TILE * MB;
         auto is_fast = [&](uint32_t w) { const int32_t ab = tile_ab16(w); return ab >= 0 && (uint32_t)ab + 16u * NCHK <= full_bytes; };
@@ -675,11 +732,12 @@ __global__ __launch_bounds__(D2D_M3_THREADS) void d2d_fir_mfma3_kernel(Mfma2Args
             while (t_hi < nwt && t_hi >= t_lo && is_fast(t_hi) && (t_hi > t_lo || is_fast(t_lo))) ++t_hi;
         }
         { const uint32_t nfull = j0.nout / (uint32_t)M2_TILE; if (t_hi > nfull) t_hi = nfull > t_lo ? nfull : t_lo; }     // whole tiles only
-        run_loop(t_lo, t_hi, std::true_type{});
+        if constexpr (ILK && NPFSET == 2) { if (il) run_loop(t_lo, t_hi, std::true_type{}, std::true_type{}); else run_loop(t_lo, t_hi, std::true_type{}, std::false_type{}); }
+        else run_loop(t_lo, t_hi, std::true_type{}, std::false_type{});
         const uint32_t n_edge = t_lo + (nwt - t_hi);
         for (uint32_t i = wv; i < n_edge; i += wstride) slow_tile(i < t_lo ? i : t_hi + (i - t_lo));
     } else {
-        run_loop(0u, nwt, std::false_type{});
+        run_loop(0u, nwt, std::false_type{}, std::false_type{});
     }
 
 #if D2D_M3_STAMPS

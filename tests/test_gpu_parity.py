@@ -4,6 +4,8 @@ Bar (BASELINE.json north_star): integer output bit-exact for identical dither se
 within 1e-6 RMS of the f64 CPU path.  The taps are dyadic (q*2^-S), so the FIR sum is exact in both
 and the float output is asserted bit-identical as well; the 1e-6 RMS bound is checked alongside.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -406,13 +408,22 @@ def test_multichannel_interleaved_input_is_deinterleaved_inside_the_fir_kernel(e
 @pytest.mark.parametrize("dsd_rate,out_rate,bits,dither,endian,nbytes", [
     (1, 88200, 24, "T", "M", 4096 * 9 + 333), (1, 88200, 16, "R", "L", 4096 * 9 + 333), (1, 88200, 32, "X", "M", 4096 * 5 + 17),
     (2, 88200, 24, "T", "M", 4096 * 18 + 100), (2, 176400, 16, "X", "L", 4096 * 9 + 333), (4, 176400, 24, "R", "M", 4096 * 30 + 5),
-    (1, 88200, 24, "T", "M", 6_000_000 + 123), (2, 88200, 24, "R", "M", 9_000_000 + 77)])
+    (1, 88200, 24, "T", "M", 6_000_000 + 123), (2, 88200, 24, "R", "M", 9_000_000 + 77),
+    (1, 352800, 24, "T", "M", 4096 * 5 + 333), (1, 352800, 32, "X", "L", 4096 * 3 + 17), (1, 176400, 16, "R", "M", 4096 * 9 + 1), (2, 352800, 24, "X", "M", 4096 * 9 + 100),
+    (2, 705600, 16, "T", "L", 4096 * 7 + 5), (1, 352800, 24, "T", "M", 3_000_000 + 123), (1, 176400, 24, "R", "M", 4_000_000 + 9), (1, 88200, 24, "T", "m3", 4096 * 9 + 333),
+    (1, 88200, 16, "R", "m3", 5_000_000 + 3)])
 def test_interleaved_stereo_is_deinterleaved_inside_the_fir_kernel(engine_lib, oracle_mod, monkeypatch, dsd_rate, out_rate, bits, dither, endian, nbytes):
-    """byte-interleaved STEREO (DFF files, the reference CLI's default -f I) into frames through d2d_fir_mx_kernel (M = 32, 64): the wave
-    that converts the pair pulls the channels apart inside its staging (both LDS images; pieces fetched once, channel 1's bytes parked
-    in registers for one region); tiles at the call's edges are gathered byte by byte.  Ragged calls, two files of different length,
-    waves that walk several tiles (the long cases); equal to the oracle and to the pre-pass route (D2D_NO_COOP=1)."""
+    """byte-interleaved STEREO (DFF files, the reference CLI's default -f I) into frames through d2d_fir_mx_kernel (M = 32, 64) and
+    d2d_fir_mfma3_kernel (M = 8, 16; M = 32 with D2D_NO_MX: "m3"): the wave that converts the pair pulls the channels apart inside its
+    staging (pieces fetched once, channel 1's bytes parked in registers for one region); tiles at the call's edges are gathered byte by
+    byte.  Ragged calls, two files of different length, waves that walk several tiles (the long cases); equal to the oracle and to the
+    pre-pass route (D2D_NO_COOP=1)."""
     import torch
+    if endian == "m3":
+        endian = "M"
+        monkeypatch.setenv("D2D_NO_MX", "1")
+    else:
+        monkeypatch.delenv("D2D_NO_MX", raising=False)
     files = []
     for f in range(2):
         n = nbytes - 1501 * f
@@ -443,7 +454,7 @@ def test_interleaved_stereo_is_deinterleaved_inside_the_fir_kernel(engine_lib, o
         outs[nocoop] = [np.concatenate(g) for g in got]
         peaks = [[e.peak(c, f) for c in range(2)] for f in range(2)]
         if nocoop == "0":
-            assert "d2d_fir_mx_kernel" in e.kernel_name()
+            assert ("d2d_fir_mx_kernel" if 2822400 * dsd_rate // out_rate >= 32 and "D2D_NO_MX" not in os.environ else "d2d_fir_mfma3_kernel") in e.kernel_name()
             for f in range(2):
                 o = oracle_mod.Oracle(**kw)
                 want = []
