@@ -93,6 +93,10 @@ constexpr int M4_FRAG_BYTES = 1280;          // a tap fragment: 64 lanes x 16 co
 // KIND: 0 no dither, 1 triangular, 2 rectangular.  Stereo, unit gain; SBY = bytes per sample: 3 (24-bit packed frames), 2 (16-bit) or
 // 4 (32-bit float, KIND 0 only: the sample is (float)v * 2^-S, one rounding like the oracle's (float)(double)).
 // NT = 0: the dense chain (tables of build_mfma2_tables); NT = taps: the structured-sparse chain (build_mfma4_tables).
+#ifndef D2D_M3_SCR_AF
+#define D2D_M3_SCR_AF 0           // 1: the scratch flavour walks the call's inner tiles in the fixed-order loop too -- measured SLOWER (DSD64 -> 96 kHz 7.55-7.72
+                                  // against 7.14-7.31 ms per step in one lease, profiles/r03_experiments.txt item 13): the general loop stays
+#endif
 template <int MB, int NPG, int NT, int KIND, int SBY>
 __global__ __launch_bounds__(D2D_M3_THREADS) void d2d_fir_mfma3_kernel(Mfma2Args m) {
     using G = M2Geom<MB>;
@@ -563,12 +567,12 @@ __global__ __launch_bounds__(D2D_M3_THREADS) void d2d_fir_mfma3_kernel(Mfma2Args
         }
     };
     // SCR: the lane's 2 x 4 consecutive integers of channel c go straight to that channel's scratch line
-    auto store_scr = [&](uint32_t tile, uint32_t c, const int32_t (&v)[8]) {
+    auto store_scr = [&](uint32_t tile, uint32_t c, const int32_t (&v)[8], bool known_full = false) {
         D2D_GLOBAL int32_t* xs = as_global(jobs[c].xs) + (size_t)tile * M2_TILE + lane_fr;
         const uint32_t nl = tile * (uint32_t)M2_TILE + lane_fr;
 #pragma unroll
         for (int g = 0; g < 2; ++g) {
-            if (nl + 8u * g + 3u < j0.nout) *reinterpret_cast<D2D_GLOBAL i32x4*>(xs + 8 * g) = i32x4{v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]};
+            if (known_full || nl + 8u * g + 3u < j0.nout) *reinterpret_cast<D2D_GLOBAL i32x4*>(xs + 8 * g) = i32x4{v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]};
             else
 #pragma unroll
                 for (int k = 0; k < 4; ++k) if (nl + 8u * g + k < j0.nout) xs[8 * g + k] = v[4 * g + k];
@@ -608,7 +612,7 @@ __global__ __launch_bounds__(D2D_M3_THREADS) void d2d_fir_mfma3_kernel(Mfma2Args
             // AF: every trip issues the same loads and stores in the same order (the first trip stores zeros to its own tile, rewritten one
             // trip later; the last trip re-requests its own tile), so that the compiler can count exactly how many younger requests
             // may stay in flight at each LDS write -- with a conditional load or store in the loop it waits for all of them
-            if (AF && !(dbg & 64)) store_packed(wt, p4h, p2h, true);
+            if constexpr (!SCR) { if (AF && !(dbg & 64)) store_packed(wt, p4h, p2h, true); }
         }
         v16i accA[2], accB[2];                                  // channel 0's / channel 1's accumulators
 #pragma unroll
@@ -649,7 +653,8 @@ __global__ __launch_bounds__(D2D_M3_THREADS) void d2d_fir_mfma3_kernel(Mfma2Args
                 else chain(0u, accA[0], accA[1], [&](auto uc) { fast_hook(f, accB[0], accB[1], uc); });
                 if (D2D_M3_STAMPS) asm volatile("" :: "v"(accA[0]), "v"(accA[1]));
                 stamp(1);
-                if (have_prev) {
+                if constexpr (SCR && AF) store_scr(pw, 1, f.res, true);        // (first trip: its own tile, rewritten one trip later)
+                else if (have_prev) {
                     if constexpr (SCR) store_scr(pw, 1, f.res);
                     else {
                         if (!(dbg & 3) && fast_failed(f, pw)) redo(1u, pw, 1, f.res); else merge_extremes(f, 1);
@@ -667,7 +672,7 @@ __global__ __launch_bounds__(D2D_M3_THREADS) void d2d_fir_mfma3_kernel(Mfma2Args
                 write_lds(C1{});
                 if (AF || more) { if constexpr (NPFSET == 2) issue_loads(nxt, C1{}, af); else issue_loads(nxt, C0{}, af); }
             }
-            if constexpr (AF) store_packed(pw, p4, p2, true);
+            if constexpr (AF) { if constexpr (!SCR) store_packed(pw, p4, p2, true); }
             else if (have_prev && !SCR) store_packed(pw, p4, p2);
             wave_sync2();
             stamp(0);
@@ -679,7 +684,7 @@ __global__ __launch_bounds__(D2D_M3_THREADS) void d2d_fir_mfma3_kernel(Mfma2Args
                 else chain(1u, accB[0], accB[1], [&](auto uc) { fast_hook(f, accA[0], accA[1], uc); });
                 if (D2D_M3_STAMPS) asm volatile("" :: "v"(accB[0]), "v"(accB[1]));
                 stamp(1);
-                if constexpr (SCR) store_scr(wt, 0, f.res);
+                if constexpr (SCR) store_scr(wt, 0, f.res, AF);
                 else {
                     if (!(dbg & 3) && fast_failed(f, wt)) redo(0u, wt, 0, f.res); else merge_extremes(f, 0);
 #pragma unroll
@@ -711,14 +716,27 @@ __global__ __launch_bounds__(D2D_M3_THREADS) void d2d_fir_mfma3_kernel(Mfma2Args
         if constexpr (NPFSET == 1) issue_loads(t, C1{}, std::false_type{});
         write_lds(C1{});
         wave_sync2();
-        int32_t o0[8], o1[8];
-        redo(0u, t, 0, o0);
-        redo(1u, t, 1, o1);
-        u32x4 p4[2]; u32x4 p2[2];
-        pack_tile(t, o0, o1, p4, p2);
-        store_packed(t, p4, p2);
+        if constexpr (SCR) {
+            // the exact integers need no careful path: the chain, then every job of the epilogue at once
+            v16i A0, A1;
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                chain((uint32_t)c, A0, A1, no_hook);
+                Fast f;
+                fast_begin(f, t, (uint32_t)c);
+                static_for<0, NJ>([&](auto jc) { fast_job(f, A0, A1, jc); });
+                store_scr(t, (uint32_t)c, f.res);
+            }
+        } else {
+            int32_t o0[8], o1[8];
+            redo(0u, t, 0, o0);
+            redo(1u, t, 1, o1);
+            u32x4 p4[2]; u32x4 p2[2];
+            pack_tile(t, o0, o1, p4, p2);
+            store_packed(t, p4, p2);
+        }
     };
-    if ((fast_layout || il) && MB < 8 && !SCR) {       // (M = 64: the general loop is faster there, 3.01 against 3.18 ms)
+    if ((fast_layout || il) && MB < 8 && (!SCR || D2D_M3_SCR_AF)) {       // (M = 64: the general loop is faster there, 3.01 against 3.18 ms)
         // the tiles [t_lo, t_hi) lie inside the call's full blocks: the loop without the gather path; the few around them one by one
         const int64_t T = (int64_t)M2_TILE * MB;
         auto is_fast = [&](uint32_t w) { const int32_t ab = tile_ab16(w); return ab >= 0 && (uint32_t)ab + 16u * NCHK <= full_bytes; };
