@@ -28,7 +28,8 @@ class Params(C.Structure):
                 ("block_size", C.c_uint32), ("filter", C.c_uint32), ("bit_depth", C.c_uint32),
                 ("dither", C.c_uint32), ("kernel", C.c_uint32), ("device", C.c_int32),
                 ("level_db", C.c_double), ("seed", C.c_uint64),
-                ("channel_first", C.c_uint32), ("channel_count", C.c_uint32)]
+                ("channel_first", C.c_uint32), ("channel_count", C.c_uint32),
+                ("tap_bits", C.c_uint32), ("reserved0", C.c_uint32)]
 
 
 class FileIO(C.Structure):
@@ -116,12 +117,12 @@ class D2DError(Exception):
 
 def make_params(dsd_rate=1, output_rate=352800, channels=2, fmt="I", endianness="M", block_size=4096,
                 filter="E", bit_depth=24, dither="X", level_db=0.0, seed=0, kernel=KERNEL_AUTO, device=0,
-                channel_first=0, channel_count=0):
+                channel_first=0, channel_count=0, tap_bits=0):
     """Argument names and defaults follow the reference CLI (src/main.rs:40-110); channel_first/count
-    select a channel subset (0 = all), see include/dsd2dxd_amd.h."""
+    select a channel subset (0 = all), tap_bits the tap grid (0 / 24, or 32), see include/dsd2dxd_amd.h."""
     return Params(C.sizeof(Params), dsd_rate, output_rate, channels, 1 if fmt.upper() == "P" else 0,
                   1 if endianness.upper() == "M" else 0, block_size, ord(filter.upper()), bit_depth,
-                  ord(dither.upper()), kernel, device, level_db, seed, channel_first, channel_count)
+                  ord(dither.upper()), kernel, device, level_db, seed, channel_first, channel_count, tap_bits, 0)
 
 
 class Engine:

@@ -89,6 +89,13 @@ struct d2d_engine {
     uint8_t* d_planar = nullptr; size_t planar_stride = 0;
     bool deinterleave = false;
     bool coop = false;                    // byte-interleaved 4/8-channel input de-interleaved inside the fp6 kernel's staging (FirArgs::coop)
+    // tap_bits = 32: the FIR runs twice into the scratch (the 24-bit table, then the residual table q32 - 256 q) and d2d_fine_combine_kernel
+    // finishes v = 256 v_hi + v_lo; the second half of the scratch, of the job table and `lo_*` belong to the second pass
+    bool fine = false;
+    std::vector<int32_t> lo_half;
+    d2d_filter_def lo_def{};
+    void* d_fir_tables_lo = nullptr;
+    int mfma_pipe_lo = 0;
     bool il2 = false;                     // byte-interleaved stereo input de-interleaved inside the pipelined frame kernels' staging (FirArgs::il2)
     uint8_t* d_out = nullptr; size_t d_out_cap = 0;
 
@@ -147,6 +154,7 @@ static void free_device(d2d_engine* e) {
     if (e->d_hist[1]) hipFree(e->d_hist[1]);
     if (e->d_peak) hipFree(e->d_peak);
     if (e->d_scratch) hipFree(e->d_scratch);
+    if (e->d_fir_tables_lo) hipFree(e->d_fir_tables_lo);
     for (int i = 0; i < 2; ++i) if (e->d_ns[i]) hipFree(e->d_ns[i]);
     if (e->d_ns_dump) hipFree(e->d_ns_dump);
     if (e->d_ys) hipFree(e->d_ys);
@@ -172,7 +180,7 @@ static int reset_state(d2d_engine* e) {
     HIPCHK(e, hipMemset(e->d_hist[0], idle, hbytes));
     HIPCHK(e, hipMemset(e->d_hist[1], idle, hbytes));
     HIPCHK(e, hipMemset(e->d_peak, 0, sizeof(double) * e->nstreams));
-    if (e->d_scratch) HIPCHK(e, hipMemset(e->d_scratch, 0, sizeof(int32_t) * e->scratch_stride * e->nstreams));
+    if (e->d_scratch) HIPCHK(e, hipMemset(e->d_scratch, 0, sizeof(int32_t) * e->scratch_stride * e->nstreams * (e->fine ? 2u : 1u)));
     for (int i = 0; i < 2; ++i) if (e->d_ns[i]) HIPCHK(e, hipMemset(e->d_ns[i], 0, sizeof(double) * 2 * e->nstreams));
     for (auto& f : e->files) f = FileState{};
     e->hist_cur = 0;
@@ -180,21 +188,22 @@ static int reset_state(d2d_engine* e) {
 }
 
 // the part of a FIR launch's arguments that is fixed when the engine is created
-static void fir_args_static(const d2d_engine* e, FirArgs& a) {
-    a.tables = e->d_fir_tables;
+static void fir_args_static(const d2d_engine* e, FirArgs& a, bool lo_pass = false) {
+    const d2d_filter_def& fd = lo_pass ? e->lo_def : *e->fc.fir;
+    a.tables = lo_pass ? e->d_fir_tables_lo : e->d_fir_tables;
     a.Wb = (uint32_t)e->Wb;
     a.ntab = (uint32_t)e->lut.ntab; a.pad = (uint32_t)e->lut.pad; a.nq = (uint32_t)e->lut.nq;
     a.B = e->B; a.keep = e->keep;
-    a.to_scratch = (e->fc.resamp || e->noise_shape) ? 1u : 0u;
+    a.to_scratch = (e->fc.resamp || e->noise_shape || e->fine) ? 1u : 0u;
     a.ksteps = (uint32_t)e->mfma.ksteps;
     a.scale_bits = e->S;
     a.in_channels = e->Cin;
     uint64_t sa = 0;
-    for (int j = 0; j < e->N; ++j) { const int64_t q = tap_q(*e->fc.fir, j); sa += (uint64_t)(q < 0 ? -q : q); }
+    for (int j = 0; j < e->N; ++j) { const int64_t q = tap_q(fd, j); sa += (uint64_t)(q < 0 ? -q : q); }
     a.sum_abs_q = sa;
     a.epi = e->epi;
-    a.pipelined = (uint32_t)e->mfma_pipe;
-    a.mx_exact = mx_exact(*e->fc.fir) ? 1u : 0u;
+    a.pipelined = (uint32_t)(lo_pass ? e->mfma_pipe_lo : e->mfma_pipe);
+    a.mx_exact = mx_exact(fd) ? 1u : 0u;
     a.coop = e->coop ? 1u : 0u;
     a.il2 = e->il2 ? 1u : 0u;
 }
@@ -209,7 +218,10 @@ int d2d_create(const d2d_params* params, uint32_t n_files, d2d_engine** out) {
     if (out) *out = nullptr;
     if (!params || !out) { g_create_error = "null argument"; return D2D_ERR_PARAM; }
     constexpr size_t legacy_size = offsetof(d2d_params, channel_first);           // ABI 1: no channel subset
-    if (params->struct_size != sizeof(d2d_params) && params->struct_size != legacy_size) { g_create_error = "d2d_params.struct_size mismatch"; return D2D_ERR_PARAM; }
+    constexpr size_t abi3_size = offsetof(d2d_params, tap_bits);                  // ABI 2, 3: no tap grid
+    if (params->struct_size != sizeof(d2d_params) && params->struct_size != legacy_size && params->struct_size != abi3_size) {
+        g_create_error = "d2d_params.struct_size mismatch"; return D2D_ERR_PARAM;
+    }
     if (n_files < 1 || n_files > 65535) { g_create_error = "Invalid file count"; return D2D_ERR_PARAM; }
     d2d_engine* e = new d2d_engine();
     memset(&e->p, 0, sizeof(e->p));
@@ -239,6 +251,14 @@ int d2d_create(const d2d_params* params, uint32_t n_files, d2d_engine** out) {
     if (e->p.dither == 'N') {
         if (e->p.bit_depth == 32) e->epi.dither = 'X';                     // float output: nothing to shape
         else e->noise_shape = true;
+    }
+    if (e->p.tap_bits != 0 && e->p.tap_bits != 24 && e->p.tap_bits != 32) { g_create_error = "Invalid tap grid; must be 24 or 32 bits"; delete e; return D2D_ERR_PARAM; }
+    if (e->p.tap_bits == 32) {
+        if (e->fc.resamp || e->noise_shape) { g_create_error = "32-bit taps serve the 44.1k-family rates with dither T, R, F or X"; delete e; return D2D_ERR_PARAM; }
+        e->fine = true;
+        e->lo_half.resize((size_t)f.ntaps / 2);
+        for (int k = 0; k < f.ntaps / 2; ++k) e->lo_half[(size_t)k] = (int32_t)((int64_t)f.half32[k] - ((int64_t)f.half[k] << 8));
+        e->lo_def = f; e->lo_def.half = e->lo_half.data(); e->lo_def.half32 = nullptr;
     }
     e->epi.sample_bytes = (uint32_t)sample_bytes_of(e->p.bit_depth);
     e->epi.channels = e->C;
@@ -298,13 +318,13 @@ int d2d_create(const d2d_params* params, uint32_t n_files, d2d_engine** out) {
         // kernel's staging de-interleaves (D2D_NO_COOP=1: the pre-pass)
         {
             const char* nocoop = getenv("D2D_NO_COOP");   // (read at every engine creation: the tests switch it inside one process)
-            if (e->deinterleave && e->mfma_pipe == 5 && (e->fc.resamp || e->noise_shape) && e->C == e->Cin && (e->Cin == 8 || e->Cin == 4) &&
+            if (e->deinterleave && e->mfma_pipe == 5 && (e->fc.resamp || e->noise_shape) && !e->fine && e->C == e->Cin && (e->Cin == 8 || e->Cin == 4) &&
                 !(nocoop && atoi(nocoop))) {
                 e->coop = true; e->deinterleave = false; e->B = 1;
             }
             // byte-interleaved stereo (DFF files, the CLI's default -f I) into frames through a pipelined kernel (fp6: M = 32, 64; int8: M = 8, 16):
             // the same, inside one wave
-            if (e->deinterleave && (e->mfma_pipe == 5 || (e->mfma_pipe == 3 && e->M < 64)) && !e->fc.resamp && !e->noise_shape && e->Cin == 2 && e->C == 2 &&
+            if (e->deinterleave && (e->mfma_pipe == 5 || (e->mfma_pipe == 3 && e->M < 64)) && !e->fc.resamp && !e->noise_shape && !e->fine && e->Cin == 2 && e->C == 2 &&
                 !(nocoop && atoi(nocoop))) {
                 e->il2 = true; e->deinterleave = false; e->B = 1;
             }
@@ -314,6 +334,24 @@ int d2d_create(const d2d_params* params, uint32_t n_files, d2d_engine** out) {
         e->fir_table_bytes = t.size();
         CK(hipMalloc(&e->d_fir_tables, e->fir_table_bytes));
         CK(hipMemcpy(e->d_fir_tables, t.data(), e->fir_table_bytes, hipMemcpyHostToDevice));
+        if (e->fine) {
+            // the residual table goes through the same builders; which pipelined kernel serves it is decided on ITS digits
+            if (e->mfma_v2) { FirArgs a{}; fir_args_static(e, a, true); e->mfma_pipe_lo = mfma2_pipelined(a, e->M, e->N); if (e->mfma_pipe_lo == 4) e->mfma_pipe_lo = 3; }
+            const d2d_filter_def& fl = e->lo_def;
+            std::vector<int8_t> tl = e->mfma_pipe_lo == 5 ? build_mx_tables(fl, msb)
+                                   : e->mfma_v2 ? build_mfma2_tables(fl, msb, !e->mfma_pipe_lo) : build_mfma_tables(fl, e->mfma, msb);
+            CK(hipMalloc(&e->d_fir_tables_lo, tl.size()));
+            CK(hipMemcpy(e->d_fir_tables_lo, tl.data(), tl.size(), hipMemcpyHostToDevice));
+        }
+    }
+    if (e->fine) {
+        if (e->kernel == D2D_KERNEL_LUT) {
+            std::vector<double> tl = build_lut_tables(e->lo_def, e->Mb, msb);
+            CK(hipMalloc(&e->d_fir_tables_lo, tl.size() * sizeof(double)));
+            CK(hipMemcpy(e->d_fir_tables_lo, tl.data(), tl.size() * sizeof(double), hipMemcpyHostToDevice));
+        }
+        e->scratch_stride = 4096;
+        CK(hipMalloc((void**)&e->d_scratch, sizeof(int32_t) * e->scratch_stride * e->nstreams * 2));
     }
     if (e->fc.resamp) {
         const std::vector<int8_t> rt = build_resamp2_table(*e->fc.resamp);
@@ -336,8 +374,9 @@ int d2d_create(const d2d_params* params, uint32_t n_files, d2d_engine** out) {
     CK(hipMalloc((void**)&e->d_hist[0], hbytes));
     CK(hipMalloc((void**)&e->d_hist[1], hbytes));
     CK(hipMalloc((void**)&e->d_peak, sizeof(double) * e->nstreams));
-    CK(hipMalloc((void**)&e->d_jobs, sizeof(StreamJob) * e->nstreams));
-    CK(hipHostMalloc((void**)&e->h_jobs, sizeof(StreamJob) * e->nstreams * JOB_SLOTS, hipHostMallocDefault));
+    const size_t njobs = (size_t)e->nstreams * (e->fine ? 2u : 1u);      // (32-bit taps: the second pass's jobs behind the first's)
+    CK(hipMalloc((void**)&e->d_jobs, sizeof(StreamJob) * njobs));
+    CK(hipHostMalloc((void**)&e->h_jobs, sizeof(StreamJob) * njobs * JOB_SLOTS, hipHostMallocDefault));
     for (int i = 0; i < JOB_SLOTS; ++i) CK(hipEventCreateWithFlags(&e->job_ev[i], hipEventDisableTiming));
 #undef CK
     rc = reset_state(e);
@@ -376,7 +415,7 @@ static int grow_scratch(d2d_engine* e, size_t need_stride, hipStream_t s) {
     if (need_stride <= e->scratch_stride) return D2D_OK;
     size_t ns = (std::max(need_stride, e->scratch_stride * 2) + 3) & ~(size_t)3;
     int32_t* nb = nullptr;
-    HIPCHK(e, hipMalloc((void**)&nb, sizeof(int32_t) * ns * e->nstreams));
+    HIPCHK(e, hipMalloc((void**)&nb, sizeof(int32_t) * ns * e->nstreams * (e->fine ? 2u : 1u)));
     const size_t P = (size_t)e->xs_hist;
     if (P) HIPCHK(e, hipMemcpy2DAsync(nb, ns * sizeof(int32_t), e->d_scratch, e->scratch_stride * sizeof(int32_t),
                                       P * sizeof(int32_t), e->nstreams, hipMemcpyDeviceToDevice, s));
@@ -411,7 +450,7 @@ int d2d_translate_batch_device(d2d_engine* e, d2d_file_io* io, uint32_t n_files,
         max_frames = std::max<uint32_t>(max_frames, (uint32_t)frames);
         io[f].frames_out = (size_t)frames;
     }
-    if (e->fc.resamp || e->noise_shape) {
+    if (e->fc.resamp || e->noise_shape || e->fine) {
         int rc = grow_scratch(e, (size_t)e->xs_hist + max_nx, s);
         if (rc) return rc;
     }
@@ -439,7 +478,8 @@ int d2d_translate_batch_device(d2d_engine* e, d2d_file_io* io, uint32_t n_files,
     const int slot = e->job_slot;
     e->job_slot = (slot + 1) % JOB_SLOTS;
     if (e->job_ev_used[slot]) HIPCHK(e, hipEventSynchronize(e->job_ev[slot]));
-    StreamJob* hj = e->h_jobs + (size_t)slot * e->nstreams;
+    const size_t njobs = (size_t)e->nstreams * (e->fine ? 2u : 1u);
+    StreamJob* hj = e->h_jobs + (size_t)slot * njobs;
     const int cur = e->hist_cur;
     for (uint32_t f = 0; f < n_files; ++f) {
         const FileState& st = e->files[f];
@@ -468,7 +508,9 @@ int d2d_translate_batch_device(d2d_engine* e, d2d_file_io* io, uint32_t n_files,
             j.rng_lo0 = (uint32_t)i0;
         }
     }
-    HIPCHK(e, hipMemcpyAsync(e->d_jobs, hj, sizeof(StreamJob) * e->nstreams, hipMemcpyHostToDevice, s));
+    if (e->fine)
+        for (uint32_t i = 0; i < e->nstreams; ++i) { hj[e->nstreams + i] = hj[i]; hj[e->nstreams + i].xs = hj[i].xs + (size_t)e->nstreams * e->scratch_stride; }
+    HIPCHK(e, hipMemcpyAsync(e->d_jobs, hj, sizeof(StreamJob) * njobs, hipMemcpyHostToDevice, s));
     HIPCHK(e, hipEventRecord(e->job_ev[slot], s));
     e->job_ev_used[slot] = true;
 
@@ -508,8 +550,26 @@ int d2d_translate_batch_device(d2d_engine* e, d2d_file_io* io, uint32_t n_files,
             else HIPCHK(e, launch_fir_mfma(a, e->mfma, max_nx, e->nstreams, s));
         }
     }
-    if (pe) HIPCHK(e, hipEventRecord(pe->second, s));
     if (max_nx && d2d_last_launched_kernel) e->launched = d2d_last_launched_kernel;
+    if (e->fine && max_nx) {
+        // second pass: the residual taps, into the second half of the scratch
+        FirArgs al{};
+        al.jobs = e->d_jobs + e->nstreams;
+        fir_args_static(e, al, true);
+        if (e->kernel == D2D_KERNEL_LUT) {
+            const uint32_t per_tile = lut_outputs_per_tile(e->Mb);
+            HIPCHK(e, launch_fir_lut(al, e->Mb, (max_nx + per_tile - 1) / per_tile, e->nstreams, s));
+        } else {
+            if (e->mfma_v2) HIPCHK(e, launch_fir_mfma2(al, e->M, e->N, max_nx, e->nstreams, s));
+            else HIPCHK(e, launch_fir_mfma(al, e->mfma, max_nx, e->nstreams, s));
+        }
+    }
+    if (pe) HIPCHK(e, hipEventRecord(pe->second, s));
+    if (e->fine && max_nx) {
+        // the matrix-core kernels write 2 sum(q b) - 2^S, which is sum(q s) only for a table that sums to 2^S: the residual table sums to 0
+        const int64_t lo_bias = e->kernel == D2D_KERNEL_LUT ? 0 : ((int64_t)1 << e->S);
+        HIPCHK(e, launch_fine_combine(e->d_jobs, e->nstreams, max_nx, (size_t)e->nstreams * e->scratch_stride, lo_bias, e->S + 8, e->epi, s));
+    }
     if (e->fc.resamp) {
         Rs2Args r{};
         r.jobs = e->d_jobs; r.tables = reinterpret_cast<const uint8_t*>(e->d_resamp);
@@ -876,6 +936,7 @@ static TableBlobHeader make_header(const d2d_engine* e) {
 
 int d2d_tables_export_device(d2d_engine* e, void* dst, size_t cap, void* hip_stream) {
     if (!e || !dst) return D2D_ERR_PARAM;
+    if (e->fine) return e->fail(D2D_ERR_STATE, "an engine with 32-bit taps holds two tap tables; the blob format carries one");
     if (cap < d2d_tables_bytes(e)) return e->fail(D2D_ERR_CAPACITY, "table blob buffer too small");
     HIPCHK(e, hipSetDevice(e->p.device));
     hipStream_t s = (hipStream_t)hip_stream;
@@ -892,6 +953,7 @@ int d2d_tables_export_device(d2d_engine* e, void* dst, size_t cap, void* hip_str
 
 int d2d_tables_import_device(d2d_engine* e, const void* src, size_t bytes, void* hip_stream) {
     if (!e || !src) return D2D_ERR_PARAM;
+    if (e->fine) return e->fail(D2D_ERR_STATE, "an engine with 32-bit taps holds two tap tables; the blob format carries one");
     if (bytes < d2d_tables_bytes(e)) return e->fail(D2D_ERR_PARAM, "table blob too small");
     HIPCHK(e, hipSetDevice(e->p.device));
     hipStream_t s = (hipStream_t)hip_stream;

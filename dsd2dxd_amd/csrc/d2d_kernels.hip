@@ -626,6 +626,77 @@ hipError_t launch_noise_shape(const NoiseShapeArgs& a0, hipStream_t s) {
     return hipGetLastError();
 }
 
+// ---- tap_bits = 32 (d2d_params): the FIR ran twice into the scratch, with the 24-bit table q and with the residual table q32 - 256 q;
+// v = sum q32 s = 256 v_hi + v_lo is an exact integer below 2^40, y = v * 2^-(S+8) exactly, and from there the f64 epilogue every
+// other path uses (oracle: orc_use_fine_taps).  A block takes 256 frames of one file: a thread finishes its frame's samples channel by
+// channel (the scratch reads of a channel are consecutive across the block), the frames meet in LDS and leave as 16-byte pieces.
+constexpr uint32_t FC_FRAMES = 256;
+template <int K, int CMAX>        // K chunks of 256 frames per trip (their scratch reads are all requested before the first is used), at most CMAX channels
+__global__ __launch_bounds__(FC_FRAMES) void d2d_fine_combine_kernel(const StreamJob* jobs, size_t lo_off, long long lo_bias, int sbits, Epilogue epi) {
+    extern __shared__ __align__(16) uint8_t fc_lds[];
+    __shared__ unsigned long long pkl[64];                               // per channel: the block's peak (non-negative doubles order like their bits)
+    const uint32_t C = epi.channels, sb = epi.sample_bytes, fb = C * sb;
+    const StreamJob* fj = jobs + (size_t)blockIdx.y * C;
+    const uint32_t nout = fj[0].nout;
+    if (threadIdx.x < 64) pkl[threadIdx.x] = 0ull;
+    __syncthreads();
+    const double ys = ldexp(1.0, -sbits);
+    constexpr uint32_t SPAN = FC_FRAMES * K;
+    for (uint32_t n0 = blockIdx.x * SPAN; n0 < nout; n0 += gridDim.x * SPAN) {      // (block-uniform)
+        int32_t xh[CMAX][K], xl[CMAX][K];
+#pragma unroll
+        for (int c = 0; c < CMAX; ++c)
+            if ((uint32_t)c < C) {
+                const int32_t* xs = fj[c].xs;
+#pragma unroll
+                for (int k = 0; k < K; ++k) {
+                    const uint32_t n = min(n0 + threadIdx.x + FC_FRAMES * k, nout - 1u);
+                    xh[c][k] = xs[n]; xl[c][k] = xs[lo_off + n];
+                }
+            }
+#pragma unroll
+        for (int c = 0; c < CMAX; ++c)
+            if ((uint32_t)c < C) {
+                const StreamJob& job = fj[c];
+                double pk = 0.0;
+#pragma unroll
+                for (int k = 0; k < K; ++k) {
+                    const uint32_t fr = threadIdx.x + FC_FRAMES * k, n = n0 + fr;
+                    if (n < nout) {
+                        const long long v = ((long long)xh[c][k] << 8) + (long long)xl[c][k] + lo_bias;
+                        pk = fmax(pk, emit_sample(epi, job, (double)v * ys, job.n0 + n, fc_lds + fr * fb + job.och * sb));
+                    }
+                }
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) pk = fmax(pk, __shfl_xor(pk, o));
+                if ((threadIdx.x & 63) == 0 && pk > 0.0) atomicMax(&pkl[c], (unsigned long long)__double_as_longlong(pk));
+            }
+        __syncthreads();
+        const uint32_t nbytes = min(SPAN, nout - n0) * fb;
+        uint8_t* out = reinterpret_cast<uint8_t*>(fj[0].out) + (size_t)n0 * fb;     // 16-byte aligned: the buffer is, and 256 frames are a multiple of 16 bytes
+        for (uint32_t i = 16u * threadIdx.x; i < nbytes; i += 16u * FC_FRAMES) {
+            if (i + 16u <= nbytes) *reinterpret_cast<uint4*>(out + i) = *reinterpret_cast<const uint4*>(fc_lds + i);
+            else for (uint32_t k = i; k < nbytes; ++k) out[k] = fc_lds[k];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x < C && pkl[threadIdx.x]) atomicMax(reinterpret_cast<unsigned long long*>(fj[threadIdx.x].peak), pkl[threadIdx.x]);
+}
+
+hipError_t launch_fine_combine(const StreamJob* jobs, uint32_t nstreams, uint32_t max_nout, size_t lo_off, int64_t lo_bias, int sbits,
+                               const Epilogue& epi, hipStream_t s) {
+    const uint32_t nfiles = nstreams / epi.channels;
+    const bool few = epi.channels <= 2;
+    const uint32_t span = FC_FRAMES * (few ? 4u : 1u);
+    uint32_t gx = (max_nout + span - 1u) / span;
+    const uint32_t cap = (8192u + nfiles - 1u) / nfiles;                            // about 8192 blocks in all, each walking its share of the chunks
+    if (gx > cap) gx = cap;
+    const size_t smem = (size_t)span * epi.channels * epi.sample_bytes;            // at most 64 channels x 4 bytes x 256 = 64 KiB
+    if (few) hipLaunchKernelGGL((d2d_fine_combine_kernel<4, 2>), dim3(gx, nfiles), dim3(FC_FRAMES), smem, s, jobs, lo_off, (long long)lo_bias, sbits, epi);
+    else hipLaunchKernelGGL((d2d_fine_combine_kernel<1, 64>), dim3(gx, nfiles), dim3(FC_FRAMES), smem, s, jobs, lo_off, (long long)lo_bias, sbits, epi);
+    return hipGetLastError();
+}
+
 hipError_t launch_history(const StreamJob* jobs, uint32_t nstreams, uint32_t C, uint32_t B, uint32_t keep, hipStream_t s) {
     if (nstreams == 0) return hipSuccess;
     hipLaunchKernelGGL(d2d_history_kernel, dim3(nstreams), dim3(256), 0, s, jobs, C, B, keep);

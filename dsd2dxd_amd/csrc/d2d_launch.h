@@ -63,6 +63,9 @@ hipError_t launch_resample2(Rs2Args& a, const d2d_resamp_def& r, uint32_t max_ou
 std::vector<int8_t> build_resamp2_table(const d2d_resamp_def& r);
 hipError_t launch_deinterleave(const StreamJob* jobs, uint32_t nfiles, uint32_t C, uint32_t streams_per_file, uint32_t max_L, hipStream_t s);
 hipError_t launch_noise_shape(const NoiseShapeArgs& a, hipStream_t s);
+// tap_bits = 32: frames from the two scratch halves, v = 256 v_hi + v_lo + lo_bias, y = v * 2^-sbits (d2d_kernels.hip)
+hipError_t launch_fine_combine(const StreamJob* jobs, uint32_t nstreams, uint32_t max_nout, size_t lo_off, int64_t lo_bias, int sbits,
+                               const Epilogue& epi, hipStream_t s);
 hipError_t launch_history(const StreamJob* jobs, uint32_t nstreams, uint32_t C, uint32_t B, uint32_t keep, hipStream_t s);
 hipError_t launch_xhist(const StreamJob* jobs, uint32_t nstreams, uint32_t P, hipStream_t s);
 

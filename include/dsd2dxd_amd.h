@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define D2D_ABI_VERSION 3   /* 3: the table blob header names the table variant */
+#define D2D_ABI_VERSION 4   /* 3: the table blob header names the table variant; 4: d2d_params.tap_bits */
 
 /* status codes */
 enum {
@@ -76,6 +76,13 @@ typedef struct d2d_params {
      * frames.  channel_count = 0: all channels. */
     uint32_t channel_first;
     uint32_t channel_count;
+    /* Tap grid (ABI 4; a 72-byte struct without these two means 24).  24: the taps are q * 2^-S with 24-bit q -- what every fast
+     * kernel is built on.  32: the same designs on the grid q32 * 2^-(S+8) (filters/filter_tables.inc: half32), for callers who
+     * need integer output closer to an f64-tap reference (DESIGN.md sections 0 and 4.5): the engine runs the FIR twice -- the 24-bit
+     * table, then the small residual table q32 - 256 q -- and combines the two exact integer sums before level, dither and
+     * requantisation; about three times the device time.  44.1k-family rates, dither T / R / F / X. */
+    uint32_t tap_bits;
+    uint32_t reserved0;
 } d2d_params;
 
 typedef struct d2d_engine d2d_engine;

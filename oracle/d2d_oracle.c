@@ -45,6 +45,7 @@ struct orc_ctx {
     /* streaming path (orc_translate_stream): integer byte tables in the stream's own bit order, buffers kept between calls */
     int32_t* ilut;    /* Wb x 256 */
     uint8_t* sbuf; size_t sbuf_cap;
+    int fine;         /* orc_use_fine_taps: the taps are the 32-bit grid's */
 };
 
 static uint8_t bitrev8(uint8_t v) {
@@ -366,7 +367,7 @@ int orc_translate(orc_ctx* c, const uint8_t* dsd, size_t L, void* pcm_out, size_
  * the sums are the exact integers sum q*s, so any order gives the oracle's number), then the identical emit_sample().
  * Integer decimator only (44.1k family, no 'N'); anything else is handed to orc_translate. */
 int orc_translate_stream(orc_ctx* c, const uint8_t* dsd, size_t L, void* pcm_out, size_t cap, size_t* frames_out) {
-    if (c->r || c->p.dither == 'N' || !pcm_out) return orc_translate_f64(c, dsd, L, pcm_out, cap, NULL, frames_out);
+    if (c->r || c->p.dither == 'N' || !pcm_out || c->fine) return orc_translate_f64(c, dsd, L, pcm_out, cap, NULL, frames_out);
     const uint32_t C = c->C;
     const size_t keep = c->keep;
     const int Wb = c->Wb;
@@ -454,6 +455,23 @@ static void build_byte_tables(orc_ctx* c) {
                 acc += (double)(((v >> (7 - m)) & 1) * 2 - 1) * c->taps[c->N / 2 + 8 * i + m];
             c->lut[i * 256 + v] = acc;
         }
+}
+
+/* [own] the optional 32-bit tap grid (filters/filter_tables.inc: half32 = q32, taps q32 * 2^-(S+8); the engine's tap_bits = 32).  Any
+ * +-1-weighted sum of these taps is exact in f64 (dyadic, sum |q32| < 2^40), so the f64 forms below ARE the integer definition
+ * y = (sum q32 s) * 2^-(S+8); level, dither and requantisation as for the 24-bit tables. */
+int orc_use_fine_taps(orc_ctx* c) {
+    if (!c) return -1;
+    if (c->r || c->p.dither == 'N') return -2;   /* 44.1k family, dither T/R/F/X */
+    const double scale = ldexp(1.0, -(c->S + 8));
+    for (int k = 0; k < c->N / 2; ++k) {
+        const double v = (double)c->f->half32[k] * scale;
+        c->taps[c->N / 2 + k] = v;
+        c->taps[c->N / 2 - 1 - k] = v;
+    }
+    build_byte_tables(c);
+    c->fine = 1;
+    return 0;
 }
 
 int orc_set_half_taps(orc_ctx* c, const double* half, int n_half) {

@@ -79,6 +79,7 @@ def _load(path):
     L.orc_tap.argtypes = [C.c_void_p, C.c_int]
     L.orc_tap.restype = C.c_double
     L.orc_set_half_taps.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+    L.orc_use_fine_taps.argtypes = [C.c_void_p]
     L.orc_rng.argtypes = [C.c_uint64, C.c_uint32, C.c_uint64]
     L.orc_rng.restype = C.c_uint32
     _lib = L
@@ -93,7 +94,7 @@ class Oracle:
 
     def __init__(self, dsd_rate=1, output_rate=352800, channels=2, fmt="I", endianness="M",
                  block_size=4096, filter="E", bit_depth=24, dither="X", level_db=0.0, seed=0,
-                 fir_mode=1):
+                 fir_mode=1, tap_bits=24):
         L = lib()
         p = OrcParams(dsd_rate, output_rate, channels, 1 if fmt.upper() == "P" else 0,
                       1 if endianness.upper() == "M" else 0, block_size, ord(filter.upper()),
@@ -107,6 +108,11 @@ class Oracle:
         self.channels = channels
         self.bit_depth = bit_depth
         self.frame_bytes = L.orc_frame_bytes(h)
+        if tap_bits == 32:
+            if L.orc_use_fine_taps(h):
+                raise OracleError("32-bit taps: 44.1k-family rates with dither T, R, F or X")
+        elif tap_bits not in (0, 24):
+            raise OracleError("tap_bits must be 24 or 32")
 
     def close(self):
         if self._h:

@@ -61,7 +61,7 @@ def test_host_driver_abi_exports_and_errors(engine_lib, tmp_path):
 
 
 def test_params_struct_layout(engine_lib):
-    assert C.sizeof(engine_lib.Params) == 72          # 12 x u32/i32 + f64 + u64 + the channel subset (2 x u32)
+    assert C.sizeof(engine_lib.Params) == 80          # 12 x u32/i32 + f64 + u64 + the channel subset (2 x u32) + the tap grid (2 x u32)
     assert C.sizeof(engine_lib.FileIO) == 40
 
 

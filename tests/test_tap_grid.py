@@ -74,3 +74,97 @@ def test_production_kernels_against_the_f64_tap_reference(engine_lib, oracle_mod
     print(f"kernel {kernel} {filt} DSD{64 * dsd_rate}->{out_rate}: float RMS diff {rms:.3e}, 24-bit mismatch {100 * rate:.2f} %, max {worst} LSB")
     assert rms < 1e-6
     assert worst <= 2 and rate < 0.35
+
+
+# ---- the optional 32-bit tap grid (d2d_params.tap_bits = 32, oracle tap_bits = 32) ----
+
+def _tables():
+    with open(os.path.join(ROOT, "filters", "filter_tables.json")) as f:
+        return {fl["name"]: fl for fl in json.load(f)["filters"]}
+
+
+@pytest.mark.parametrize("dsd_rate,out_rate,filt", [(1, 88200, "E"), (1, 352800, "D"), (2, 88200, "C")])
+def test_fine_tap_oracle_is_the_integer_sum_of_the_32_bit_table(oracle_mod, dsd_rate, out_rate, filt):
+    """known answer: y[n] = (sum_j q32[j] s[(n+1) M - N + j]) * 2^-(S+8) in Python integers, on a stream long enough to leave the idle
+    history behind; 24-bit undithered samples = round-half-away(y * 2^23)"""
+    O = oracle_mod
+    nbytes = 4096
+    stream = synth("pink", nbytes, seed=11, amp=0.3, dsd_rate=dsd_rate)
+    kw = dict(dsd_rate=dsd_rate, output_rate=out_rate, channels=1, fmt="P", endianness="L", block_size=4096, filter=filt)
+    o = O.Oracle(bit_depth=24, dither="X", tap_bits=32, **kw)
+    info = o.info()
+    M, N, S = info["M"], info["ntaps"], info["S"]
+    fl = _tables()["%s_M%d" % (filt, M)]
+    assert fl["S"] == S and len(fl["q32"]) == N // 2
+    q32 = [int(v) for v in fl["q32"][::-1]] + [int(v) for v in fl["q32"]]
+    assert sum(q32) == 1 << (S + 8) and all(abs(a - (b << 8)) < 512 for a, b in zip(fl["q32"], fl["q"]))
+    got, frames = o.translate(stream)
+    a = got.reshape(-1, 3).astype(np.int32)
+    iv = a[:, 0] | (a[:, 1] << 8) | (a[:, 2] << 16)
+    iv = np.where(iv >= 1 << 23, iv - (1 << 24), iv)
+    bits = np.unpackbits(stream, bitorder="little").astype(np.int64) * 2 - 1
+    n0 = (N + M - 1) // M                                         # first output whose window lies inside the stream
+    for n in list(range(n0, n0 + 40)) + [frames - 1]:
+        w = bits[(n + 1) * M - N:(n + 1) * M]
+        v = sum(int(q) * int(s) for q, s in zip(q32, w))
+        x = v * 2.0 ** -(S + 8) * 2.0 ** 23                       # exact in f64 (|v| < 2^40)
+        r = int(np.trunc(x + np.copysign(0.5, x)))
+        assert iv[n] == max(-(1 << 23), min((1 << 23) - 1, r)), n
+
+
+@pytest.mark.parametrize("dsd_rate,out_rate,filt", CASES)
+def test_fine_taps_close_most_of_the_gap_to_the_f64_taps(oracle_mod, dsd_rate, out_rate, filt):
+    """what the 24-bit grid costs (test above: 12-29 % of the 24-bit samples off by one) shrinks by the grid's factor 256"""
+    O = oracle_mod
+    buf = _inputs(dsd_rate)
+    kw = dict(dsd_rate=dsd_rate, output_rate=out_rate, channels=2, fmt="P", endianness="L", block_size=4096, filter=filt, seed=3)
+    q32, n = O.Oracle(bit_depth=32, dither="X", tap_bits=32, **kw).translate(buf)
+    r32, _ = _f64_oracle(O, dict(kw, bit_depth=32, dither="X")).translate(buf)
+    q24, _ = O.Oracle(bit_depth=24, dither="T", tap_bits=32, **kw).translate(buf)
+    r24, _ = _f64_oracle(O, dict(kw, bit_depth=24, dither="T")).translate(buf)
+    rms, rate, worst = _stats(q32.view(np.float32), r32.view(np.float32), q24, r24)
+    print(f"32-bit taps, {filt} DSD{64 * dsd_rate}->{out_rate}: float RMS diff {rms:.3e}, 24-bit samples that differ {100 * rate:.3f} %, by at most {worst} LSB")
+    assert rms < 3e-8 and worst <= 1 and rate < 0.004
+
+
+def test_fine_taps_are_refused_where_they_are_not_defined(oracle_mod):
+    for kw in (dict(output_rate=96000), dict(output_rate=88200, dither="N")):
+        with pytest.raises(oracle_mod.OracleError):
+            oracle_mod.Oracle(dsd_rate=1, channels=2, fmt="P", endianness="L", bit_depth=24, tap_bits=32, **kw)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kernel", [1, 2])
+@pytest.mark.parametrize("dsd_rate,out_rate,filt,channels,bits,dither,fmt", [
+    (1, 88200, "E", 2, 24, "T", "P"), (1, 88200, "X", 1, 16, "R", "I"), (1, 352800, "D", 2, 32, "F", "P"), (1, 176400, "E", 3, 20, "T", "I"),
+    (2, 88200, "C", 2, 24, "X", "P"), (4, 88200, "E", 2, 24, "T", "P"), (2, 705600, "E", 2, 32, "X", "P"), (8, 352800, "E", 6, 24, "T", "I"),
+    (1, 88200, "E", 4, 24, "T", "I")])
+def test_engine_with_32_bit_taps_equals_the_oracle(engine_lib, oracle_mod, kernel, dsd_rate, out_rate, filt, channels, bits, dither, fmt):
+    """d2d_params.tap_bits = 32: the FIR twice (24-bit table, residual table) + d2d_fine_combine_kernel == the oracle's 32-bit-tap
+    conversion bit for bit, peaks included; several calls with carried state, every kernel family, a level other than 0 dB"""
+    kw = dict(dsd_rate=dsd_rate, output_rate=out_rate, channels=channels, fmt=fmt, endianness="M" if fmt == "I" else "L",
+              block_size=4096 if fmt == "P" else 1, filter=filt, bit_depth=bits, dither=dither, seed=31, level_db=-1.5 if channels == 3 else 0.0)
+    nbytes = 4096 * 6 * dsd_rate
+    chans = [synth("sine" if c % 2 == 0 else "pink", nbytes, seed=40 + c, dsd_rate=dsd_rate, msb_first=fmt == "I", amp=0.4 if c % 2 == 0 else 0.098)
+             for c in range(channels)]
+    e = engine_lib.Engine(n_files=1, kernel=kernel, tap_bits=32, **kw)
+    o = oracle_mod.Oracle(tap_bits=32, **kw)
+    o24 = oracle_mod.Oracle(**kw)
+    cuts = [0, 4096, 4096 * 3, nbytes]
+    differs = False
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        buf = pack_layout([ch[a:b] for ch in chans], fmt, 4096 if fmt == "P" else 1)
+        g, gf = e.translate(buf)
+        w, wf = o.translate(buf)
+        w24, _ = o24.translate(buf)
+        assert gf == wf and np.array_equal(g, w[:wf * e.frame_bytes]), (a, b)
+        differs = differs or not np.array_equal(w[:wf * e.frame_bytes], w24[:wf * e.frame_bytes])
+    assert differs                                                  # (the finer grid does change samples)
+    assert [e.peak(c) for c in range(channels)] == [o.peak(c) for c in range(channels)]
+
+
+@pytest.mark.gpu
+def test_32_bit_taps_are_refused_where_they_are_not_defined(engine_lib):
+    for kw in (dict(output_rate=96000), dict(output_rate=88200, dither="N"), dict(output_rate=88200, tap_bits=16)):
+        with pytest.raises(engine_lib.D2DError):
+            engine_lib.Engine(**dict(dict(dsd_rate=1, channels=2, fmt="P", endianness="L", bit_depth=24, tap_bits=32), **kw))

@@ -116,6 +116,29 @@ def quantise(h):
     return S, q
 
 
+FINE_BITS = 8      # the optional 32-bit tap grid: q32 * 2^-(S + 8), eight more fraction bits than the 24-bit tables
+
+
+def quantise_fine(half_f64, S, q24):
+    """The same design on the 32-bit grid 2^-(S+8): q32 = 256 q24 + r with a SMALL residual table r (|r| < 512) whose taps sum to
+    zero, so that a conversion with 32-bit taps is the shipped 24-bit FIR plus a second FIR pass over the residuals.
+    `half_f64`: the design's own taps (2nd half, unity DC gain)."""
+    half = np.asarray(half_f64, dtype=np.float64)
+    Sf = S + FINE_BITS
+    q = np.rint(half * 2.0 ** Sf).astype(np.int64)
+    resid = (1 << (Sf - 1)) - int(q.sum())
+    frac = half * 2.0 ** Sf - q
+    order = np.argsort(-frac, kind="stable") if resid > 0 else np.argsort(frac, kind="stable")
+    assert abs(resid) <= len(q), resid
+    for i in range(abs(resid)):
+        q[order[i]] += 1 if resid > 0 else -1
+    assert 2 * int(q.sum()) == 1 << Sf
+    r = q - (np.asarray(q24, dtype=np.int64) << FINE_BITS)
+    assert int(r.sum()) == 0 and np.abs(r).max() < 512, (int(r.sum()), int(np.abs(r).max()))
+    assert np.abs(q).max() < 2 ** 31
+    return q
+
+
 RESAMP_T = 28      # stage-B coefficient grid: G = round(g * 2^28), four balanced int8 limbs in the matrix-core kernel
 
 
@@ -153,6 +176,10 @@ def main():
         resamplers = [dict(r, coef=[float.fromhex(x) for x in r["coef"]]) for r in frozen["resamplers"]]
         for r in resamplers:
             r["q"] = [int(v) for v in quantise_polyphase(np.array(r["coef"]).reshape(r["L"], r["P"])).reshape(-1)]
+        with open(os.path.join(ROOT, "filters", "filter_taps_f64.json")) as f:
+            f64 = json.load(f)
+        for fl in filters:
+            fl["q32"] = [int(v) for v in quantise_fine([float.fromhex(x) for x in f64[fl["name"]]], fl["S"], fl["q"])]
         write_tables(filters, resamplers, None)
         return
     filters = []   # dicts: name, type, M, N, S, q(list), method
@@ -166,7 +193,7 @@ def main():
         full = np.concatenate([q[::-1], q]).astype(np.float64) * 2.0 ** -S
         w, mag = response_db(full, float(M))
         filters.append(dict(name=name, type=ftype, M=M, N=2 * len(q), S=S,
-                            q=[int(v) for v in q], method=method,
+                            q=[int(v) for v in q], q32=[int(v) for v in quantise_fine(0.5 * (hn[len(hn) // 2:] + hn[:len(hn) // 2][::-1]), S, q)], method=method,
                             db_at_0p227=float(mag[np.argmin(abs(w - 0.227))]),
                             db_at_nyq=float(mag[np.argmin(abs(w - 0.5))]),
                             stop_max_db=float(mag[w >= 0.56].max())))
@@ -236,13 +263,14 @@ def write_tables(filters, resamplers, unquantised):
                " * (coef = the f64 design they were rounded from, kept for tests).\n"
                " * Shared DATA for the engine (dsd2dxd_amd/csrc) and the oracle (oracle/). */\n")
     out.append("#ifndef D2D_FILTER_TABLES_INC\n#define D2D_FILTER_TABLES_INC\n#include <stdint.h>\n")
-    out.append("typedef struct { const char* name; char type; int M; int ntaps; int S; const int32_t* half; } d2d_filter_def;\n")
+    out.append("typedef struct { const char* name; char type; int M; int ntaps; int S; const int32_t* half; const int32_t* half32; } d2d_filter_def;\n")
     out.append("typedef struct { const char* name; int out_rate; int L; int Mdn; int P; const double* coef; int T; const int32_t* q; } d2d_resamp_def;\n")
     for i, fl in enumerate(filters):
         out.append(f"static const int32_t d2d_ftab_{i}[{len(fl['q'])}] = {{ {fmt_i32(fl['q'])} }};\n")
+        out.append(f"static const int32_t d2d_ftab32_{i}[{len(fl['q32'])}] = {{ {fmt_i32(fl['q32'])} }};   /* the 32-bit grid: q32 * 2^-(S+8) */\n")
     out.append(f"static const d2d_filter_def D2D_FILTERS[{len(filters)}] = {{\n")
     for i, fl in enumerate(filters):
-        out.append(f"  {{ \"{fl['name']}\", '{fl['type']}', {fl['M']}, {fl['N']}, {fl['S']}, d2d_ftab_{i} }},\n")
+        out.append(f"  {{ \"{fl['name']}\", '{fl['type']}', {fl['M']}, {fl['N']}, {fl['S']}, d2d_ftab_{i}, d2d_ftab32_{i} }},\n")
     out.append("};\n")
     out.append(f"enum {{ D2D_NUM_FILTERS = {len(filters)} }};\n")
     for i, r in enumerate(resamplers):
