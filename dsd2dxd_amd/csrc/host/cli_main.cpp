@@ -85,7 +85,7 @@ int main(int argc, char** argv) {
     std::string out_dir; bool have_out_dir = false;
     size_t channels = 2, bit_depth = 24; char fmt = 'I', filt = 'E', endian = 'M', dither = 0, output = 'S';
     uint32_t block = 4096, rate = 352800, inrate = 1; double level = 0.0; bool append = false, recurse = false, quiet = false;
-    int device = 0; unsigned long long seed = 0;
+    int device = 0; unsigned long long seed = 0; uint32_t tap_bits = 0;
     std::vector<std::string> files;
     for (; ai < argc; ++ai) {
         std::string a = argv[ai];
@@ -109,6 +109,7 @@ int main(int argc, char** argv) {
         else if (a == "-v" || a == "--verbose") {}
         else if (a == "--device") device = atoi(val());
         else if (a == "--seed") seed = strtoull(val(), 0, 10);
+        else if (a == "--tap-bits") tap_bits = (uint32_t)strtoul(val(), 0, 10);
         else files.push_back(a);
     }
     if (files.empty()) files.push_back("-");
@@ -147,7 +148,7 @@ int main(int argc, char** argv) {
             Rdsd2Pcm lib = (!is_stdin && DsdFileFormat::from(path).is_container())
                                ? Rdsd2Pcm::from_container(bit_depth, ot, level, rate, od, dt, fl, append, ".", path)
                                : Rdsd2Pcm::create(bit_depth, ot, level, rate, od, dt, ft, en, inrate, block, channels, fl, append, ".", ip);
-            lib.set_device(device); lib.set_seed(seed);
+            lib.set_device(device); lib.set_seed(seed); lib.set_tap_bits(tap_bits);
             lib.do_conversion(CANCEL_FLAG);
             if (!quiet && !lib.warnings().empty()) fprintf(stderr, "WARNING: %s: %s\n", lib.file_name().c_str(), lib.warnings().c_str());
             if (!quiet && lib.audio_seconds() > 0)

@@ -140,6 +140,7 @@ double Rdsd2Pcm::audio_seconds() const { return p_->audio_s; }
 std::string Rdsd2Pcm::warnings() const { return p_->tag_warning; }
 void Rdsd2Pcm::set_device(int device) { p_->prm.device = device; }
 void Rdsd2Pcm::set_seed(uint64_t seed) { p_->prm.seed = seed; }
+void Rdsd2Pcm::set_tap_bits(uint32_t bits) { p_->prm.tap_bits = bits; }
 void Rdsd2Pcm::set_chunk_bytes(size_t b) { if (b) p_->chunk = b; }
 
 namespace {

@@ -124,6 +124,7 @@ const char* d2dh_output_path(const d2dh_conv* c) { return c ? c->out_path.c_str(
 const char* d2dh_warnings(const d2dh_conv* c) { return c ? c->warnings.c_str() : ""; }
 void d2dh_set_device(d2dh_conv* c, int device) { if (c) c->obj.set_device(device); }
 void d2dh_set_seed(d2dh_conv* c, uint64_t seed) { if (c) c->obj.set_seed(seed); }
+void d2dh_set_tap_bits(d2dh_conv* c, uint32_t bits) { if (c) c->obj.set_tap_bits(bits); }
 
 int d2dh_find_dsd_files(const char* const* paths, size_t n_paths, int recurse, d2dh_path_fn each, void* user) {
     return guarded([&] {

@@ -67,6 +67,7 @@ class Rdsd2Pcm {
     // engine knobs a driver may set before the run
     void set_device(int device);
     void set_seed(uint64_t seed);
+    void set_tap_bits(uint32_t bits);     // 24 (default) or 32: d2d_params.tap_bits (include/dsd2dxd_amd.h); not a reference option
     void set_chunk_bytes(size_t bytes_per_channel);
 
     struct Impl;                              // opaque state (public only so the .cpp's helpers can name it)

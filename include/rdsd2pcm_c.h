@@ -53,6 +53,7 @@ const char* d2dh_output_path(const d2dh_conv* c);    /* "" for stdout; known aft
 const char* d2dh_warnings(const d2dh_conv* c);       /* non-fatal findings of the last run, "" if none */
 void d2dh_set_device(d2dh_conv* c, int device);      /* which GPU: e.g. rayon::current_thread_index() % n_gpus */
 void d2dh_set_seed(d2dh_conv* c, uint64_t seed);
+void d2dh_set_tap_bits(d2dh_conv* c, uint32_t bits);   /* 24 (default) or 32: d2d_params.tap_bits, include/dsd2dxd_amd.h */
 
 int d2dh_find_dsd_files(const char* const* paths, size_t n_paths, int recurse, d2dh_path_fn each, void* user);
 int d2dh_is_container(const char* path);              /* 1 for .dsf / .dff, else 0 */

@@ -267,6 +267,25 @@ def test_dsf_to_wav_respects_sample_count(cli, oracle_mod, tmp_path):
 
 
 @pytest.mark.gpu
+def test_cli_with_32_bit_taps(cli, oracle_mod, tmp_path):
+    """--tap-bits 32 (Rdsd2Pcm::set_tap_bits / d2dh_set_tap_bits -> d2d_params.tap_bits): the whole driver on the finer tap grid"""
+    n = 4096 * 4 + 500
+    chans = [synth("sine", n, seed=3), synth("pink", n, seed=4, amp=0.098)]
+    src = str(tmp_path / "fine.dsf")
+    write_dsf(src, chans, dsd_rate=1, lsb_first=True)
+    out_dir = tmp_path / "out"
+    out_dir.mkdir()
+    subprocess.check_call([cli, "-o", "w", "-r", "88200", "-b", "24", "-d", "T", "-p", str(out_dir), "-q", "--tap-bits", "32", src])
+    fmt, pay = _wav_payload(str(out_dir / "fine.wav"))
+    o = oracle_mod.Oracle(dsd_rate=1, output_rate=88200, channels=2, fmt="P", endianness="L", block_size=4096,
+                          bit_depth=24, dither="T", seed=0, tap_bits=32)
+    r, rf = o.translate(pack_layout(chans, "P", 4096))
+    assert rf == n * 8 // 32 and np.array_equal(pay, r[:rf * 6])
+    p = subprocess.run([cli, "-o", "w", "-r", "96000", "-p", str(out_dir), "-q", "--tap-bits", "32", src], stderr=subprocess.PIPE)
+    assert p.returncode == 1 and b"32-bit taps serve the 44.1k-family rates" in p.stderr
+
+
+@pytest.mark.gpu
 def test_dff_to_aiff_and_raw_stdin_to_stdout(cli, oracle_mod, tmp_path):
     n = 4096 * 4
     chans = [synth("sine", n, seed=3, msb_first=True), synth("pink", n, seed=4, amp=0.098, msb_first=True)]
