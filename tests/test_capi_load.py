@@ -32,7 +32,7 @@ def test_host_driver_abi_exports_and_errors(engine_lib, tmp_path):
     L = C.CDLL(engine_lib.library_path())
     text = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "rdsd2pcm_c.h")).read(), flags=re.S)
     names = sorted(set(re.findall(r"\b(d2dh_[a-z0-9_]+)\s*\(", text)) - {"d2dh_progress_fn", "d2dh_path_fn"})
-    assert len(names) == 14
+    assert len(names) == 15
     for n in names:
         assert hasattr(L, n), n
     L.d2dh_last_error.restype = C.c_char_p
