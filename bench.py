@@ -259,6 +259,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pcie", action="store_true", help="skip the host-resident batch (pinned host in/out, upload/convert/download overlapped) that is reported as the extra pcie_inclusive object, never as value")
     ap.add_argument("--cpu-budget", type=float, default=12.0, help="seconds of CPU-baseline work")
+    ap.add_argument("--level", type=float, default=0.0, help="volume in dB (the reference's -l; its own test scripts use +-4)")
     ap.add_argument("--tap-bits", type=int, default=24, choices=(24, 32), help="tap grid (32: the optional 32-bit taps, two FIR passes and a combining pass; 44.1k-family workloads with dither T/R/F/X)")
     ap.add_argument("--pcie-slice", type=int, default=0, help="bytes per channel per slice of the host-resident batch (0 = the library's default)")
     args = ap.parse_args()
@@ -303,6 +304,8 @@ def main():
               block_size=block, filter="E", bit_depth=bits, dither=dither, seed=206)
     if args.tap_bits == 32:
         kw["tap_bits"] = 32
+    if args.level != 0.0:
+        kw["level_db"] = args.level
     kernel = {"auto": d.KERNEL_AUTO, "lut": d.KERNEL_LUT, "mfma": d.KERNEL_MFMA}[args.kernel]
     ncpu = usable_cpus()
     gen_threads = max(1, min(32, ncpu // max(1, min(world, 8))))
@@ -439,7 +442,7 @@ def main():
         "repetitions": {"n": len(dts), "ms_per_step_min": round(dts_sorted[0] / args.steps * 1e3, 4), "ms_per_step_max": round(dts_sorted[-1] / args.steps * 1e3, 4),
                         "ms_per_step_all": [round(x / args.steps * 1e3, 4) for x in dts]}, "scaling": "weak" if args.shard == "files" and args.scaling == "weak" else "strong",
         "vs_baseline": None, "dtype": "f64", "data": "synthetic (2nd-order 1-bit modulator: 1 kHz-family sines at 0.352 FS and pink noise at ~0.1 RMS; %d distinct files per rank%s)" % (min(args.distinct, args.files), "" if args.distinct >= args.files else " tiled to %d" % args.files),
-        "config": {"workload": f"{args.workload}: {args.files} files/GPU x {blocks * 4096 * 8 / (DSD64 * dsd_rate):.1f} s, {'planar 4096-B LSB-first' if fmt == 'P' else 'byte-interleaved MSB-first'} {channels} ch -> {bits}-bit {out_rate} Hz, dither {dither}, filter E ({eng.info()['ntaps']} taps{', 32-bit grid' if args.tap_bits == 32 else ''}, M={M:g})",
+        "config": {"workload": f"{args.workload}: {args.files} files/GPU x {blocks * 4096 * 8 / (DSD64 * dsd_rate):.1f} s, {'planar 4096-B LSB-first' if fmt == 'P' else 'byte-interleaved MSB-first'} {channels} ch -> {bits}-bit {out_rate} Hz, dither {dither}{', level %g dB' % args.level if args.level else ''}, filter E ({eng.info()['ntaps']} taps{', 32-bit grid' if args.tap_bits == 32 else ''}, M={M:g})",
                    "files_per_gpu": args.files, "seconds_per_file": round(blocks * 4096 * 8 / (DSD64 * dsd_rate), 3),
                    "parallelism": (f"files sharded over {world} GPU(s), no data-path collective" if args.shard == "files" else
                                    f"channels of every file split over {world} GPU(s) ({ch_count} of {channels} on rank 0), no data-path collective"), "kernel": eng.kernel_name()},

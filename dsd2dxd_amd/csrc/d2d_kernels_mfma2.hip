@@ -710,6 +710,7 @@ static bool mfma3_eligible(const FirArgs& a, const Mfma2Args& m, int MB, int NPG
                           a.sum_abs_q != 0 && a.sum_abs_q < (1ull << 31);
     // (M = 8 float frames too since the pipelined kernel stages that shape's frames through LDS: 4.18 against 4.50 ms on the one-group kernel)
     if (float_ok && shape_ok) return true;
+    if (m.gainq && shape_ok && MB < 4) return true;            // another level in dB, M = 8 and 16: the f64 requantiser inside the pipelined epilogue
     return frames_ok && m.intq && shape_ok;
 }
 
@@ -762,6 +763,10 @@ static void mfma2_geometry(const FirArgs& a, int MB, int NPG, Mfma2Args& m, size
     // (the fast form carries v0 = v + 2^S in an int32: 2^S + sum|q| has to stay below 2^31)
     m.intq = (!noint && !a.to_scratch && a.epi.bits != 32 && a.epi.gain == 1.0 && !m.wide && m.fbits > 0 && m.fbits <= 16 &&
               a.sum_abs_q != 0 && (1ull << a.scale_bits) + a.sum_abs_q < (1ull << 31)) ? 1u : 0u;
+    // stereo 16/24-bit (dither T, R, none) or float (no float dither) frames at another level than 0 dB
+    const char* nogain = getenv("D2D_NO_GAINQ");           // (read at every engine creation: the tests switch it inside one process)
+    m.gainq = (!noint && !(nogain && atoi(nogain)) && !a.to_scratch && a.epi.channels == 2 && a.epi.gain != 1.0 && !m.wide && m.qsh == 0 && a.epi.dither != 'F' &&
+               a.epi.dither != 'N' && (a.epi.bits == 32 || (m.fbits > 0 && m.fbits <= 16)) && a.sum_abs_q != 0 && a.sum_abs_q < (1ull << 31)) ? 1u : 0u;
     m.off_waves = (uint32_t)(2 * NPG) * 1024u;
     m.off_out = (uint32_t)m2_stream_bytes(MB, NPG);
     // (only the LDS-staged epilogue needs the output slice)

@@ -90,7 +90,8 @@ __host__ __device__ constexpr int m4_stream_bytes(int MB, int NT) {
 }
 constexpr int M4_FRAG_BYTES = 1280;          // a tap fragment: 64 lanes x 16 compressed int8, then 64 index words
 
-// KIND: 0 no dither, 1 triangular, 2 rectangular.  Stereo, unit gain; SBY = bytes per sample: 3 (24-bit packed frames), 2 (16-bit) or
+// KIND: 0 no dither, 1 triangular, 2 rectangular (unit gain, all-integer requantiser); 4, 5, 6: the same dithers at any level in dB (f64
+// requantiser, M = 8 and 16).  Stereo; SBY = bytes per sample: 3 (24-bit packed frames), 2 (16-bit) or
 // 4 (32-bit float, KIND 0 only: the sample is (float)v * 2^-S, one rounding like the oracle's (float)(double)).
 // NT = 0: the dense chain (tables of build_mfma2_tables); NT = taps: the structured-sparse chain (build_mfma4_tables).
 #ifndef D2D_M3_SCR_AF
@@ -102,6 +103,11 @@ __global__ __launch_bounds__(D2D_M3_THREADS) void d2d_fir_mfma3_kernel(Mfma2Args
     using G = M2Geom<MB>;
     constexpr int RS = G::RS, LSH = G::LSH;
     constexpr bool SP = NT > 0;
+    // KIND = dither kind DK (0 none, 1 triangular, 2 rectangular), + 4 (GN) for any level in dB: the requantiser then follows the f64
+    // definition operation by operation -- x = fl(v * (scale * 2^-S)), q = x + d, round half away, clip -- behind the same chains; it
+    // has no careful path (nothing about it depends on the tile)
+    constexpr int DK = KIND & 3;
+    constexpr bool GN = KIND >= 4;
     constexpr uint32_t FB = 2u * (SBY ? SBY : 1);                   // bytes per stereo frame
     constexpr int TP = SP ? m4_nst(MB, NT) : NPG + MB;              // steps of one chain
     constexpr int NCHK = SP ? m4_chunks(MB, NT) : m2_chunks(MB, NPG);
@@ -370,6 +376,20 @@ __global__ __launch_bounds__(D2D_M3_THREADS) void d2d_fir_mfma3_kernel(Mfma2Args
     // |x| <= qmax - 2 LSB keeps x + d inside the range whatever the dither
     const int32_t kSafe = (int32_t)(((uint32_t)m.qmax_i - 2u) << F_);
     const uint32_t lane_fr = 16u * r + 4u * h;              // the lane's first frame inside a tile
+    // GN: x = fl(v * kCg) is the oracle's y * scale (y = v * 2^-S exactly; the float flavour: y * gain)
+    double kCg = ldexp(a.epi.bits == 32 ? a.epi.gain : a.epi.scale, -a.scale_bits);
+    double kLim = a.epi.bits == 32 ? 1.0 : (double)(1u << (a.epi.bits - 1));
+    if constexpr (GN) asm volatile("" : "+v"(kCg), "+v"(kLim));
+    // the f64 requantiser from the hash word's dither term t (triangular: lo16 + hi16 + 1, rectangular: 2 hi16 + 1), as d2d_device.h: finish_int
+    auto quant_gain = [&](int32_t v, uint32_t t) -> int32_t {
+        const double x = (double)v * kCg;
+        if constexpr (SBY == 4) return __float_as_int((float)x);
+        double q = x;
+        if constexpr (DK == 1) q = x + fma((double)t, 0x1p-16, -1.0);
+        else if constexpr (DK == 2) q = x + fma((double)t, 0x1p-17, -0.5);
+        const double rq = fmax(fmin(trunc(q + copysign(0.5, q)), kLim - 1.0), -kLim);
+        return (int32_t)rq;
+    };
 
     // v = sum q s of sample k of a group's accumulators: (A0 >> 6) + 4*A1 + 2^10*A2 + 2^18*A3 (A0 is a multiple of 128; mod 2^32)
     auto recombine = [&](const v16i& A, int k) -> int32_t {
@@ -389,14 +409,18 @@ __global__ __launch_bounds__(D2D_M3_THREADS) void d2d_fir_mfma3_kernel(Mfma2Args
         const int32_t vh = v >> F;
         const uint32_t vl = (uint32_t)v & ((1u << F) - 1u);
         int32_t rr;
-        if constexpr (KIND == 2) {
+        if constexpr (GN) {
+            uint32_t t = 0;
+            if constexpr (DK != 0) { const uint32_t z = noise(c, nl); t = DK == 1 ? (z & 0xFFFFu) + (z >> 16) + 1u : 2u * (z >> 16) + 1u; }
+            return quant_gain(v, t);
+        } else if constexpr (DK == 2) {
             const uint32_t z = noise(c, nl);
             const int32_t w = (int32_t)(vl << (17 - F)) + (int32_t)(2u * (z >> 16) + 1u) - 65536;
             const int32_t neg = (vh + (w >> 17)) >> 31;
             rr = vh + ((w + 65536 + neg) >> 17);
         } else {
             int32_t w = (int32_t)(vl << (16 - F));
-            if constexpr (KIND == 1) {
+            if constexpr (DK == 1) {
                 const uint32_t z = noise(c, nl);
                 w += (int32_t)((z & 0xFFFFu) + (z >> 16)) - 65535;
             }
@@ -420,23 +444,26 @@ __global__ __launch_bounds__(D2D_M3_THREADS) void d2d_fir_mfma3_kernel(Mfma2Args
         f.zb = first + key_eff + lane_fr;
         f.tmn = 0; f.tmx = 0; f.tie = 0xFFFFu;
     };
-    constexpr int NJ = (KIND == 0 ? 8 : 16);                // jobs per epilogue
+    constexpr int NJ = (DK == 0 ? 8 : 16);                  // jobs per epilogue
     auto fast_job = [&](Fast& f, const v16i& o0, const v16i& o1, auto jc) {
         constexpr int j = decltype(jc)::value;
-        constexpr int i = KIND == 0 ? j : j >> 1;           // sample 0..7: group i >> 2, k = i & 3
-        constexpr bool HASH = KIND != 0 && (j & 1) == 0;
+        constexpr int i = DK == 0 ? j : j >> 1;             // sample 0..7: group i >> 2, k = i & 3
+        constexpr bool HASH = DK != 0 && (j & 1) == 0;
         if constexpr (HASH) {
             uint32_t z = f.zb + (uint32_t)(8 * (i >> 2) + (i & 3));
             z ^= z >> 16; z *= kC1;
             z ^= z >> 15; z *= kC2;
             z ^= z >> 16;
-            if constexpr (KIND == 1) f.T[i] = __builtin_amdgcn_sad_u16(z, 0u, kTm);      // lo16 + hi16 - 32767, units of 2^-16 LSB
+            if constexpr (GN) f.T[i] = DK == 1 ? __builtin_amdgcn_sad_u16(z, 0u, 1u) : ((z >> 15) | 1u);     // lo16 + hi16 + 1; 2 hi16 + 1
+            else if constexpr (KIND == 1) f.T[i] = __builtin_amdgcn_sad_u16(z, 0u, kTm);      // lo16 + hi16 - 32767, units of 2^-16 LSB
             else f.T[i] = z >> kShR;                                                       // (2*hi16 + 1) >> (17 - F)
         } else {
             const v16i& A = (i >> 2) ? o1 : o0;
             const int32_t v = recombine(A, i & 3);
             int32_t s;
-            if constexpr (KIND == 1) {
+            if constexpr (GN) {
+                s = 0;
+            } else if constexpr (KIND == 1) {
                 s = v + ((int32_t)f.T[i] >> kSh);
                 const uint32_t w = (uint32_t)m3_lshl_add(v, kSh, (int32_t)f.T[i]);         // low 16 bits zero: an exact tie
                 if constexpr (i & 1) f.tie = m3_min3_u16(f.tie, f.wprev, w); else f.wprev = w;
@@ -447,7 +474,8 @@ __global__ __launch_bounds__(D2D_M3_THREADS) void d2d_fir_mfma3_kernel(Mfma2Args
             } else {
                 s = v + kHalf + (v >> 31);                                                 // round half away from zero
             }
-            if constexpr (SBY == 4) f.res[i] = __float_as_int((float)v * kFs);
+            if constexpr (GN) f.res[i] = quant_gain(v, DK != 0 ? f.T[i] : 0u);
+            else if constexpr (SBY == 4) f.res[i] = __float_as_int((float)v * kFs);
             else if constexpr (SCR) f.res[i] = v;
             else f.res[i] = s >> kF;
             asm volatile("" : "+v"(f.res[i]));         // keep the whole job on this step (the value is only used after the region)
@@ -468,7 +496,7 @@ __global__ __launch_bounds__(D2D_M3_THREADS) void d2d_fir_mfma3_kernel(Mfma2Args
         const bool full = tile * (uint32_t)M2_TILE + (uint32_t)M2_TILE <= j0.nout;
         if (SCR || (dbg & 8)) return false;                 // (SCR: the integers need no second look; 8: never take the slow path, for timing experiments)
         if (!full || first > 0xFFFFFFFFu - (uint32_t)M2_TILE) return true;
-        if constexpr (SBY == 4) return false;                // float: nothing clips, nothing ties
+        if constexpr (SBY == 4 || GN) return false;          // float: nothing clips, nothing ties; any level: the f64 requantiser is the definition
         const bool bad = (KIND == 1 && (f.tie & 0xFFFFu) == 0) || f.tmx > kSafe || f.tmn < -kSafe;
         return __builtin_amdgcn_ballot_w64(bad) != 0;
     };
@@ -483,7 +511,7 @@ __global__ __launch_bounds__(D2D_M3_THREADS) void d2d_fir_mfma3_kernel(Mfma2Args
         for (int i = 0; i < 8; ++i) {
             const uint32_t nl = nl_base + 8u * (i >> 2) + (i & 3);
             const int32_t v = recombine((i >> 2) ? t1 : t0, i & 3);
-            if constexpr (SBY == 4) out[i] = __float_as_int((float)v * kFs); else out[i] = quant_slow(v, c, nl);
+            if constexpr (SBY == 4 && !GN) out[i] = __float_as_int((float)v * kFs); else out[i] = quant_slow(v, c, nl);
             const uint32_t va = (uint32_t)(v < 0 ? -v : v);
             vmax = max(vmax, full || nl < j0.nout ? va : 0u);
         }
@@ -773,6 +801,7 @@ __global__ __launch_bounds__(D2D_M3_THREADS) void d2d_fir_mfma3_kernel(Mfma2Args
     for (int c = 0; c < 2; ++c) {
         const int32_t dev = max(vmx[c], -vmn[c]);
         double p = fmax(pk[c], ldexp((double)dev, -m.fbits)) * unscale;
+        if constexpr (GN) p = p * a.epi.gain;                          // |y| is exact: one rounding, as the oracle's |y * gain| of the largest sample
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) p = fmax(p, __shfl_xor(p, o));
         if (lane == 0 && p > 0.0)
@@ -904,8 +933,20 @@ static hipError_t launch_mfma3_t(Mfma2Args& m, uint32_t nwt_max, uint32_t nrows,
     return hipGetLastError();
 }
 
+// any level in dB (Mfma2Args::gainq): KIND + 4, compiled for the shapes this kernel serves by default (M = 8, 16)
+template <int MB, int NPG, int NT, int SBY>
+static hipError_t launch_mfma3_gain(Mfma2Args& m, uint32_t nwt_max, uint32_t nrows, hipStream_t s) {
+    if constexpr (MB < 4 && NT == 0 && SBY != 0) {
+        if constexpr (SBY != 4) {
+            if (m.dkind == 1) return launch_mfma3_t<MB, NPG, NT, 5, SBY>(m, nwt_max, nrows, s);
+            if (m.dkind == 2) return launch_mfma3_t<MB, NPG, NT, 6, SBY>(m, nwt_max, nrows, s);
+        }
+        return launch_mfma3_t<MB, NPG, NT, 4, SBY>(m, nwt_max, nrows, s);
+    } else return hipErrorInvalidValue;
+}
 #define K3(mb, npg, nt, sby)                                                                          \
-    { if (m.dkind == 1) return launch_mfma3_t<mb, npg, nt, 1, sby>(m, nwt_max, nrows, s);              \
+    { if (m.gainq) return launch_mfma3_gain<mb, npg, nt, sby>(m, nwt_max, nrows, s);                    \
+      if (m.dkind == 1) return launch_mfma3_t<mb, npg, nt, 1, sby>(m, nwt_max, nrows, s);              \
       if (m.dkind == 2) return launch_mfma3_t<mb, npg, nt, 2, sby>(m, nwt_max, nrows, s);              \
       return launch_mfma3_t<mb, npg, nt, 0, sby>(m, nwt_max, nrows, s); }
 #if D2D_M3_PART == 1
@@ -918,7 +959,7 @@ hipError_t launch_fir_mfma3_scr(Mfma2Args& m, int MB, int NPG, uint32_t nwt_max,
 }
 hipError_t launch_fir_mfma3_s16(Mfma2Args& m, int MB, int NPG, int NT, uint32_t nwt_max, uint32_t nrows, hipStream_t s) {
     if (m.f.epi.sample_bytes == 4) {       // float: no dither (the float dither 'F' stays with the two-group kernel)
-#define X(mb, npg, nt) if (MB == mb && NPG == npg && NT == nt) return launch_mfma3_t<mb, npg, 0, 0, 4>(m, nwt_max, nrows, s);
+#define X(mb, npg, nt) if (MB == mb && NPG == npg && NT == nt) return m.gainq ? launch_mfma3_gain<mb, npg, 0, 4>(m, nwt_max, nrows, s) : launch_mfma3_t<mb, npg, 0, 0, 4>(m, nwt_max, nrows, s);
         D2D_M3_SHAPES(X)
 #undef X
         return hipErrorInvalidValue;

@@ -38,6 +38,7 @@ struct Mfma2Args {
     uint32_t nwaves;      // waves per block
     uint32_t ngroups;     // channel groups per file: 1 for mono/stereo, else one block row per channel PAIR
     uint32_t intq;        // 1: unit gain at an integer depth -- the all-integer requantiser applies
+    uint32_t gainq;       // 1 (pipelined kernels): another level in dB -- the f64 requantiser inside the pipelined epilogue (KIND + 4)
     int32_t  fbits;       // intq: x = v * 2^-fbits LSB (v = sum q s), fbits = S - (bits - 1)
     uint32_t dbg;         // diagnostic ablation mask (make DIAG=1, env D2D_DBG): 1 no chain, 2 no epilogue, 4 no staging
 };

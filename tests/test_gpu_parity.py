@@ -465,3 +465,43 @@ def test_interleaved_stereo_is_deinterleaved_inside_the_fir_kernel(engine_lib, o
                 assert peaks[f] == [o.peak(c) for c in range(2)]
     for f in range(2):
         assert np.array_equal(outs["0"][f], outs["1"][f])
+
+
+@pytest.mark.parametrize("dsd_rate,out_rate", [(1, 352800), (1, 176400), (2, 352800), (2, 705600), (4, 1411200)])
+@pytest.mark.parametrize("bits,dither,level", [(24, "T", -3.0), (16, "R", 4.0), (24, "X", -0.5), (32, "X", -4.0), (16, "T", 20.0), (24, "R", -60.0)])
+def test_level_in_db_inside_the_pipelined_kernel(engine_lib, oracle_mod, monkeypatch, dsd_rate, out_rate, bits, dither, level):
+    """--level other than 0 dB (the reference's own test scripts use +-4 dB, build_test_*.sh): stereo frames at M = 8 and 16 stay on the
+    pipelined kernel, whose epilogue then follows the f64 definition (KIND + 4); + 20 dB clips both rails, - 60 dB leaves a few LSB.
+    Equal to the oracle and to the one-group kernel (D2D_NO_GAINQ=1), samples and peaks, over ragged calls."""
+    nbytes = 4096 * 6 * dsd_rate
+    chans = [synth("sine", nbytes, seed=71, dsd_rate=dsd_rate, amp=0.5), synth("pink", nbytes, seed=72, dsd_rate=dsd_rate, amp=0.2)]
+    kw = dict(dsd_rate=dsd_rate, output_rate=out_rate, channels=2, fmt="P", endianness="L", block_size=4096, filter="E",
+              bit_depth=bits, dither=dither, seed=5, level_db=level)
+    cuts = [0, 4096, 4096 * 2 + 4096 // 2, nbytes]
+    outs = {}
+    for off in ("0", "1"):
+        monkeypatch.setenv("D2D_NO_GAINQ", off)
+        e = engine_lib.Engine(n_files=1, kernel=2, **kw)
+        o = oracle_mod.Oracle(**kw)
+        got = []
+        for a, b in zip(cuts[:-1], cuts[1:]):
+            # (planar blocks: a ragged call ends inside a block group only at the end of the stream -- cut on whole blocks)
+            a4, b4 = a // 4096 * 4096, b // 4096 * 4096 if b != nbytes else b
+            if b4 <= a4:
+                continue
+            buf = pack_layout([ch[a4:b4] for ch in chans], "P", 4096)
+            g, gf = e.translate(buf)
+            w, wf = o.translate(buf)
+            assert gf == wf and np.array_equal(g, w[:wf * e.frame_bytes]), (off, a4, b4)
+            got.append(g)
+        outs[off] = np.concatenate(got)
+        assert [e.peak(c) for c in range(2)] == [o.peak(c) for c in range(2)]
+        name = e.kernel_name()
+        if off == "0":
+            assert "d2d_fir_mfma3_kernel" in name and name.split(",")[-2].strip() in ("4", "5", "6"), name
+        else:
+            assert "d2d_fir_mfma3_kernel" not in name, name
+    assert np.array_equal(outs["0"], outs["1"])
+    if level == 20.0:
+        pcm = decode_pcm(outs["0"], bits, 2)
+        assert pcm.max() == (1 << (bits - 1)) - 1 and pcm.min() == -(1 << (bits - 1))
