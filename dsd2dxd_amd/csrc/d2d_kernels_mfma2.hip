@@ -738,6 +738,8 @@ int mfma2_pipelined(const FirArgs& a, int M, int N) {
     mfma2_geometry(a, MB, NPG, m, smem);
     // the fp6 x fp4 kernel (d2d_kernels_mx.hip) serves what the pipelined int8 kernel serves at M = 32 and 64: 5
     if (!(nomx && atoi(nomx)) && mx_supported(MB, N) && mx_eligible(a, m)) return 5;
+    // ... and stereo frames at another level than 0 dB (its gain flavours)
+    if (!(nomx && atoi(nomx)) && m.gainq && mx_gain_supported(MB, N) && a.mx_exact && a.scale_bits >= 20 && a.scale_bits <= 30 && (a.epi.bits == 32 || a.epi.sample_bytes == 2 || a.epi.sample_bytes == 3)) return 5;
     if (!mfma2_supported(M, N) && !mfma3_supported(MB, NPG, N) && !(a.to_scratch && mfma3_scr_supported(MB, NPG))) return 0;
     if (!mfma3_eligible(a, m, MB, NPG, N)) return 0;
     // the structured-sparse chain issues 27 % fewer MFMAs but 8 % more vector instructions, and the kernel is bound by vector issue:

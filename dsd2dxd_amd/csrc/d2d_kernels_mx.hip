@@ -76,7 +76,8 @@ __device__ __forceinline__ int32_t mx_max3(int32_t x, int32_t y, int32_t z) {
     return d;
 }
 
-// KIND: 0 no dither, 1 triangular, 2 rectangular.  Stereo, unit gain; SBY = bytes per sample: 3 (24-bit packed frames), 2 (16-bit),
+// KIND: 0 no dither, 1 triangular, 2 rectangular (unit gain, all-integer requantiser); 4, 5, 6: the same dithers at any level in dB (the
+// f64 requantiser of the definition inside the pipelined epilogue, no careful path).  Stereo; SBY = bytes per sample: 3 (24-bit packed frames), 2 (16-bit),
 // 4 (32-bit float, KIND 0 only) or 0 (the exact integers y * 2^S to the scratch lines of a channel pair).
 template <int MB, int NT, int G, int KIND, int SBY>
 __global__ __launch_bounds__(D2D_MX_THREADS) void d2d_fir_mx_kernel(Mfma2Args m) {
@@ -90,6 +91,9 @@ __global__ __launch_bounds__(D2D_MX_THREADS) void d2d_fir_mx_kernel(Mfma2Args m)
     constexpr uint32_t FB = 2u * (SBY ? SBY : 1);                   // bytes per stereo frame
     constexpr uint32_t TBL16 = (uint32_t)NF * (MX_FRAG_BYTES / 16); // 16-byte units of one table variant
     constexpr bool SCR = SBY == 0;
+    constexpr int DK = KIND & 3;                                    // the dither kind
+    constexpr bool GN = KIND >= 4;                                  // any level: x = fl(v * (scale * 2^-S)), q = x + d, round half away, clip -- in f64
+    static_assert(!GN || !SCR, "the scratch holds integers");
     constexpr uint32_t dbg = D2D_MX_ABL;                  // compile-time ablation mask: 1 no chain, 2 no epilogue, 4 no staging, 8 never slow, 64 no stores
     const FirArgs& a = m.f;
     extern __shared__ __align__(16) unsigned char smem[];
@@ -287,7 +291,7 @@ __global__ __launch_bounds__(D2D_MX_THREADS) void d2d_fir_mx_kernel(Mfma2Args m)
     // accumulators start from -2^S: the digit-4 rows (weight 2^20) of every sample
     // (EB, the dithered integer depths: the accumulators start from zero instead -- sixteen registers less -- and the -2^S rides in the
     // three-operand add that applies the dither; the extremes are then kept on v + 2^S)
-    constexpr bool EB = (KIND == 1 || KIND == 2) && (SBY == 2 || SBY == 3);
+    constexpr bool EB = ((KIND == 1 || KIND == 2) && (SBY == 2 || SBY == 3)) || GN;
     v16f cinit;
 #pragma unroll
     for (int i = 0; i < 16; ++i) cinit[i] = (!EB && i < 15 && (i % 5) == 4) ? -(float)(1 << (a.scale_bits - 20)) : 0.0f;
@@ -374,13 +378,31 @@ __global__ __launch_bounds__(D2D_MX_THREADS) void d2d_fir_mx_kernel(Mfma2Args m)
         z ^= z >> 16;
         return z;
     };
+    // GN: x = fl(v * kCg) is the oracle's y * scale (y = v * 2^-S exactly; the float flavour: y * gain); then d2d_device.h: finish_int
+    // with the hash word's dither term t (triangular: lo16 + hi16 + 1, rectangular: 2 hi16 + 1)
+    double kCg = ldexp(a.epi.bits == 32 ? a.epi.gain : a.epi.scale, -a.scale_bits);
+    double kLim = a.epi.bits == 32 ? 1.0 : (double)(1u << (a.epi.bits - 1));
+    if constexpr (GN) asm volatile("" : "+v"(kCg), "+v"(kLim));
+    auto quant_gain = [&](int32_t v, uint32_t t) -> int32_t {
+        const double x = (double)v * kCg;
+        if constexpr (SBY == 4) return __float_as_int((float)x);
+        double q = x;
+        if constexpr (DK == 1) q = x + fma((double)t, 0x1p-16, -1.0);
+        else if constexpr (DK == 2) q = x + fma((double)t, 0x1p-17, -0.5);
+        const double rq = fmax(fmin(trunc(q + copysign(0.5, q)), kLim - 1.0), -kLim);
+        return (int32_t)rq;
+    };
     // the general per-sample requantiser (any tile): x = v * 2^-F LSB, dither in 2^-16 (2^-17) LSB, round half away, clip
     auto quant_slow = [&](int32_t v, uint32_t c, uint32_t nl) -> int32_t {
         const int F = m.fbits;
         const int32_t vh = v >> F;
         const uint32_t vl = (uint32_t)v & ((1u << F) - 1u);
         int32_t rr;
-        if constexpr (KIND == 2) {
+        if constexpr (GN) {
+            uint32_t t = 0;
+            if constexpr (DK != 0) { const uint32_t z = noise(c, nl); t = DK == 1 ? (z & 0xFFFFu) + (z >> 16) + 1u : 2u * (z >> 16) + 1u; }
+            return quant_gain(v, t);
+        } else if constexpr (KIND == 2) {
             const uint32_t z = noise(c, nl);
             const int32_t w = (int32_t)(vl << (17 - F)) + (int32_t)(2u * (z >> 16) + 1u) - 65536;
             const int32_t neg = (vh + (w >> 17)) >> 31;
@@ -415,19 +437,20 @@ __global__ __launch_bounds__(D2D_MX_THREADS) void d2d_fir_mx_kernel(Mfma2Args m)
         f.tmn = kBias; f.tmx = kBias; f.tie = 0xFFFFu;
         f.slot = ob + c * TILE + lane_fr;
     };
-    constexpr int JPS = KIND == 0 ? 2 : 3;                  // jobs per sample: [hash,] recombine, finish
+    constexpr int JPS = DK == 0 ? 2 : 3;                    // jobs per sample: [hash,] recombine, finish
     constexpr int NJ = JPS * NS;                            // jobs per epilogue
     constexpr int NSLOT = NF * G;                           // MFMAs of a chain
     auto fast_job = [&](Fast& f, const v16f (&o)[G], auto jc) {
         constexpr int j = decltype(jc)::value;
         constexpr int i = j / JPS;                          // sample 0..NS-1: group i / 3, q = i % 3
-        constexpr int t = j % JPS + (KIND == 0 ? 1 : 0);    // 0 hash, 1 recombine, 2 finish
+        constexpr int t = j % JPS + (DK == 0 ? 1 : 0);      // 0 hash, 1 recombine, 2 finish
         if constexpr (t == 0) {
             uint32_t z = f.zb + (uint32_t)(6 * (i / 3) + (i % 3));
             z ^= z >> 16; z *= kC1;
             z ^= z >> 15; z *= kC2;
             z ^= z >> 16;
-            if constexpr (KIND == 1) f.T = __builtin_amdgcn_sad_u16(z, 0u, kTm);        // lo16 + hi16 - 32767, units of 2^-16 LSB
+            if constexpr (GN) f.T = DK == 1 ? __builtin_amdgcn_sad_u16(z, 0u, 1u) : ((z >> 15) | 1u);      // lo16 + hi16 + 1; 2 hi16 + 1
+            else if constexpr (KIND == 1) f.T = __builtin_amdgcn_sad_u16(z, 0u, kTm);   // lo16 + hi16 - 32767, units of 2^-16 LSB
             else f.T = z >> kShR;                                                         // (2*hi16 + 1) >> (17 - F)
             asm volatile("" : "+v"(f.T));
         } else if constexpr (t == 1) {
@@ -436,7 +459,9 @@ __global__ __launch_bounds__(D2D_MX_THREADS) void d2d_fir_mx_kernel(Mfma2Args m)
         } else {
             const int32_t v = f.v;
             int32_t s;
-            if constexpr (KIND == 1) {
+            if constexpr (GN) {
+                s = 0;
+            } else if constexpr (KIND == 1) {
                 if constexpr (EB) s = v + ((int32_t)f.T >> kSh) + kNegBias; else s = v + ((int32_t)f.T >> kSh);
                 const uint32_t w = (uint32_t)mx_lshl_add(v, kSh, (int32_t)f.T);            // low 16 bits zero: an exact tie
                 if constexpr (i & 1) f.tie = mx_min3_u16(f.tie, f.wprev, w);
@@ -450,7 +475,8 @@ __global__ __launch_bounds__(D2D_MX_THREADS) void d2d_fir_mx_kernel(Mfma2Args m)
                 s = v + kHalf + (v >> 31);                                                 // round half away from zero
             }
             int32_t rv;
-            if constexpr (SBY == 4) rv = __float_as_int((float)v * kFs);
+            if constexpr (GN) rv = quant_gain(v + kNegBias, DK != 0 ? f.T : 0u);
+            else if constexpr (SBY == 4) rv = __float_as_int((float)v * kFs);
             else if constexpr (SCR) rv = v;
             else rv = s >> kF;
             // the sample goes straight into the wave's output slice (the tile that sat there left before this region began); the scratch
@@ -477,7 +503,7 @@ __global__ __launch_bounds__(D2D_MX_THREADS) void d2d_fir_mx_kernel(Mfma2Args m)
         const bool full = tile * (uint32_t)TILE + (uint32_t)TILE <= j0.nout;
         if (SCR || (dbg & 8)) return false;
         if (!full || first > 0xFFFFFFFFu - (uint32_t)TILE) return true;
-        if constexpr (SBY == 4) return false;                // float: nothing clips, nothing ties
+        if constexpr (SBY == 4 || GN) return false;          // float: nothing clips, nothing ties; any level: the f64 requantiser is the definition
         const bool bad = (KIND == 1 && (f.tie & 0xFFFFu) == 0) || f.tmx > kSafe + kBias || f.tmn < kBias - kSafe;
         return __builtin_amdgcn_ballot_w64(bad) != 0;
     };
@@ -490,7 +516,7 @@ __global__ __launch_bounds__(D2D_MX_THREADS) void d2d_fir_mx_kernel(Mfma2Args m)
         for (int i = 0; i < NS; ++i) {
             const uint32_t nl = nl_base + 6u * (i / 3) + (i % 3);
             const int32_t v = recombine(t[i / 3], i % 3) - kBias;
-            if constexpr (SBY == 4) out[i] = __float_as_int((float)v * kFs); else out[i] = quant_slow(v, c, nl);
+            if constexpr (SBY == 4 && !GN) out[i] = __float_as_int((float)v * kFs); else out[i] = quant_slow(v, c, nl);
             const uint32_t va = (uint32_t)(v < 0 ? -v : v);
             vmax = max(vmax, full || nl < j0.nout ? va : 0u);
         }
@@ -769,6 +795,7 @@ __global__ __launch_bounds__(D2D_MX_THREADS) void d2d_fir_mx_kernel(Mfma2Args m)
     for (int c = 0; c < 2; ++c) {
         const int32_t dev = max(vmx[c] - kBias, kBias - vmn[c]);
         double p = fmax(pk[c], ldexp((double)dev, -m.fbits)) * unscale;
+        if constexpr (GN) p = p * a.epi.gain;                          // |y| is exact: one rounding, as the oracle's |y * gain| of the largest sample
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) p = fmax(p, __shfl_xor(p, o));
         if (lane == 0 && p > 0.0)
@@ -794,11 +821,27 @@ __global__ __launch_bounds__(D2D_MX_THREADS) void d2d_fir_mx_kernel(Mfma2Args m)
 #define D2D_MX_SHAPES_3(X) X(8, 1104)
 #endif
 #define D2D_MX_SHAPES(X) D2D_MX_SHAPES_0(X) D2D_MX_SHAPES_1(X) D2D_MX_SHAPES_2(X) D2D_MX_SHAPES_3(X)
+// the gain flavours (KIND + 4: frames at another level than 0 dB) of the shapes that serve frames (not the cascade's A filters), in two
+// more objects (Makefile: -DD2D_MX_GPART=0 / 1, D2D_MX_PART=99)
+#define D2D_MX_GSHAPES_0(X) X(4, 560) X(4, 384) X(4, 512)
+#ifdef D2D_MX_DEV
+#define D2D_MX_GSHAPES_1(X)
+#else
+#define D2D_MX_GSHAPES_1(X) X(8, 1024) X(8, 1104)
+#endif
+hipError_t launch_fir_mx_gain0(Mfma2Args& m, int MB, int NT, uint32_t max_nout, uint32_t nrows, hipStream_t s);
+hipError_t launch_fir_mx_gain1(Mfma2Args& m, int MB, int NT, uint32_t max_nout, uint32_t nrows, hipStream_t s);
 
 #if D2D_MX_PART == 0
 bool mx_supported(int MB, int NT) {
 #define X(mb, nt) if (MB == mb && NT == nt) return true;
     D2D_MX_SHAPES(X)
+#undef X
+    return false;
+}
+bool mx_gain_supported(int MB, int NT) {
+#define X(mb, nt) if (MB == mb && NT == nt) return true;
+    D2D_MX_GSHAPES_0(X) D2D_MX_GSHAPES_1(X)
 #undef X
     return false;
 }
@@ -942,12 +985,38 @@ static hipError_t launch_mx_t(Mfma2Args& m, uint32_t max_nout, uint32_t nrows, h
         shapes(D2D_MX_LAUNCH)                                                                                      \
         return hipErrorInvalidValue;                                                                               \
     }
-#if D2D_MX_PART == 0
+#ifdef D2D_MX_GPART
+#define D2D_MX_GLAUNCH(mb, nt)                                                                                     \
+    if (MB == mb && NT == nt) {                                                                                    \
+        constexpr int G = mx_g(mb);                                                                                \
+        if (m.f.epi.sample_bytes == 4) return launch_mx_t<mb, nt, G, 4, 4>(m, max_nout, nrows, s);                  \
+        if (m.f.epi.sample_bytes == 2) {                                                                           \
+            if (m.dkind == 1) return launch_mx_t<mb, nt, G, 5, 2>(m, max_nout, nrows, s);                           \
+            if (m.dkind == 2) return launch_mx_t<mb, nt, G, 6, 2>(m, max_nout, nrows, s);                           \
+            return launch_mx_t<mb, nt, G, 4, 2>(m, max_nout, nrows, s);                                             \
+        }                                                                                                          \
+        if (m.dkind == 1) return launch_mx_t<mb, nt, G, 5, 3>(m, max_nout, nrows, s);                               \
+        if (m.dkind == 2) return launch_mx_t<mb, nt, G, 6, 3>(m, max_nout, nrows, s);                               \
+        return launch_mx_t<mb, nt, G, 4, 3>(m, max_nout, nrows, s);                                                 \
+    }
+#if D2D_MX_GPART == 0
+hipError_t launch_fir_mx_gain0(Mfma2Args& m, int MB, int NT, uint32_t max_nout, uint32_t nrows, hipStream_t s) {
+    D2D_MX_GSHAPES_0(D2D_MX_GLAUNCH)
+    return hipErrorInvalidValue;
+}
+#else
+hipError_t launch_fir_mx_gain1(Mfma2Args& m, int MB, int NT, uint32_t max_nout, uint32_t nrows, hipStream_t s) {
+    D2D_MX_GSHAPES_1(D2D_MX_GLAUNCH)
+    return hipErrorInvalidValue;
+}
+#endif
+#elif D2D_MX_PART == 0
 D2D_MX_PART_FN(0, D2D_MX_SHAPES_0)
 hipError_t launch_fir_mx_part1(Mfma2Args& m, int MB, int NT, uint32_t max_nout, uint32_t nrows, hipStream_t s);
 hipError_t launch_fir_mx_part2(Mfma2Args& m, int MB, int NT, uint32_t max_nout, uint32_t nrows, hipStream_t s);
 hipError_t launch_fir_mx_part3(Mfma2Args& m, int MB, int NT, uint32_t max_nout, uint32_t nrows, hipStream_t s);
 hipError_t launch_fir_mx(Mfma2Args& m, int MB, int NT, uint32_t max_nout, uint32_t nrows, hipStream_t s) {
+    if (m.gainq && !m.f.to_scratch) return MB == 4 ? launch_fir_mx_gain0(m, MB, NT, max_nout, nrows, s) : launch_fir_mx_gain1(m, MB, NT, max_nout, nrows, s);
 #define X(mb, nt) if (MB == mb && NT == nt) return launch_fir_mx_part0(m, MB, NT, max_nout, nrows, s);
     D2D_MX_SHAPES_0(X)
 #undef X

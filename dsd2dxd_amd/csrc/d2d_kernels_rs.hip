@@ -112,7 +112,6 @@ __global__ __launch_bounds__(512) void d2d_resample_mfma_kernel(Rs2Args a) {
         else if (dkind == 2) { dsh = F - 17; }
         else kconst += (int64_t)1 << (F - 1);
     }
-    const int64_t fmask = ((int64_t)1 << F) - 1;
 
     i32x4_rs pf[RS2_NCOL];
     const D2D_GLOBAL int32_t* xs0 = as_global(jobs[0].xs);
