@@ -57,9 +57,10 @@ WORKLOADS = {
     "dsd512_to_96k_s24_8ch": (8, 96000, 24, "T", 8, 235.2 / 8 + 3),      # config 5: byte-interleaved MSB-first
     "dsd64_to_88k2_s24_stereo_dff": (1, 88200, 24, "T", 2, 32 / 8 + 3),   # the reference CLI's default input format (-f I; DFF files): byte-interleaved MSB-first
     "dsd64_to_352k8_s24_stereo_dff": (1, 352800, 24, "T", 2, 8 / 8 + 3),  # ... at the CLI's default output rate
+    "dsd64_to_96k_s24_stereo_dff": (1, 96000, 24, "T", 2, 29.4 / 8 + 3),  # ... into the 48k cascade
 }
 LAYOUTS = {"dsd512_to_96k_s24_8ch": ("I", "M", 1), "dsd64_to_88k2_s24_stereo_dff": ("I", "M", 1),
-           "dsd64_to_352k8_s24_stereo_dff": ("I", "M", 1)}                # default: planar 4096 LSB-first
+           "dsd64_to_352k8_s24_stereo_dff": ("I", "M", 1), "dsd64_to_96k_s24_stereo_dff": ("I", "M", 1)}                # default: planar 4096 LSB-first
 
 
 REF_SCREENSHOT_MSAMPLES_PER_WORKER = 17.6   # /root/reference/asset/progress.jpg: 50x realtime, stereo 176.4 kHz

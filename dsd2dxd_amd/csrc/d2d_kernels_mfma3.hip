@@ -156,10 +156,10 @@ __global__ __launch_bounds__(D2D_M3_THREADS) void d2d_fir_mfma3_kernel(Mfma2Args
     const uint32_t Bsz = a.B, Lcall = (uint32_t)j0.L;
     const bool pow2B = Bsz >= 16 && (Bsz & (Bsz - 1)) == 0;
     const uint32_t bshift = pow2B ? 31 - __builtin_clz(Bsz) : 0;
-    // IL (a.il2: byte-interleaved stereo -- DFF files, the CLI's default -f I -- both channels converted, frame flavours, M < 64): the
+    // IL (a.il2: byte-interleaved stereo -- DFF files, the CLI's default -f I -- both channels converted, M < 64; the scratch flavour too): the
     // tile's frames come as they lie in memory, 2 NCHK pieces of 16 bytes = eight frames each, slot s of a lane = piece lane + 64 s;
     // one v_perm_b32 per channel and dword pair pulls a channel's eight bytes = its stream dwords 2 g, 2 g + 1 (run_loop below)
-    constexpr bool ILK = !SCR && MB < 8;
+    constexpr bool ILK = MB < 8;
     const bool il = ILK && a.il2 != 0;
     const uint32_t full_bytes = il ? Lcall : pow2B ? (Lcall >> bshift) << bshift : 0;
     uint32_t wil[ILK ? 2 * PF : 1][2];
@@ -764,7 +764,7 @@ __global__ __launch_bounds__(D2D_M3_THREADS) void d2d_fir_mfma3_kernel(Mfma2Args
             store_packed(t, p4, p2);
         }
     };
-    if ((fast_layout || il) && MB < 8 && (!SCR || D2D_M3_SCR_AF)) {       // (M = 64: the general loop is faster there, 3.01 against 3.18 ms)
+    if ((fast_layout || il) && MB < 8 && (!SCR || D2D_M3_SCR_AF || il)) {       // (the scratch flavour: the fixed-order loop only where it saves the de-interleave pass)       // (M = 64: the general loop is faster there, 3.01 against 3.18 ms)
         // the tiles [t_lo, t_hi) lie inside the call's full blocks: the loop without the gather path; the few around them one by one
         const int64_t T = (int64_t)M2_TILE * MB;
         auto is_fast = [&](uint32_t w) { const int32_t ab = tile_ab16(w); return ab >= 0 && (uint32_t)ab + 16u * NCHK <= full_bytes; };
