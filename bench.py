@@ -50,6 +50,8 @@ WORKLOADS = {
     "dsd64_to_352k8_s24_stereo": (1, 352800, 24, "T", 2, 8 / 8 + 3),
     "dsd64_to_352k8_f32_stereo": (1, 352800, 32, "X", 2, 8 / 8 + 4),
     "dsd128_to_88k2_s24_stereo": (2, 88200, 24, "T", 2, 64 / 8 + 3),
+    "dsd256_to_88k2_s24_stereo": (4, 88200, 24, "T", 2, 128 / 8 + 3),      # M = 128 (test_all_44k_mults.sh converts 1kHz_stereo_256.dsf to 88.2 kHz)
+    "dsd256_to_176k4_s24_stereo": (4, 176400, 24, "T", 2, 64 / 8 + 3),
     "dsd128_to_88k2_s24_stereo_ns": (2, 88200, 24, "N", 2, 64 / 8 + 3),   # BASELINE config 3's noise-shaped variant (an extension)
     "dsd64_to_96k_s24_stereo": (1, 96000, 24, "T", 2, 29.4 / 8 + 3),
     "dsd64_to_192k_s24_stereo": (1, 192000, 24, "T", 2, 14.7 / 8 + 3),

@@ -276,7 +276,7 @@ int d2d_create(const d2d_params* params, uint32_t n_files, d2d_engine** out) {
         }
         // M = 8 and 16: the two-group geometry only through the pipelined kernel (stereo 16/24-bit/float frames at 0 dB); every other
         // format of those rates stays on the one-group kernel
-        if (!(v1 && atoi(v1)) && !e->mfma_v2 && e->M < 32 && e->p.kernel != D2D_KERNEL_LUT) {
+        if (!(v1 && atoi(v1)) && !e->mfma_v2 && (e->M < 32 || e->M == 128) && e->p.kernel != D2D_KERNEL_LUT) {
             FirArgs a{}; fir_args_static(e, a);
             if (mfma2_pipelined(a, e->M, e->N)) { e->mfma_v2 = true; mfma_ok = true; mfma_waves = 8; }
         }

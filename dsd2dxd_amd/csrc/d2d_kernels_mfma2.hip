@@ -736,6 +736,19 @@ int mfma2_pipelined(const FirArgs& a, int M, int N) {
     const char* nomx = getenv("D2D_NO_MX");
     Mfma2Args m{}; size_t smem = 0;
     mfma2_geometry(a, MB, NPG, m, smem);
+    // M = 128 (DSD256 -> 88.2 kHz, DSD512 -> 176.4 kHz): only the fp6 kernel has the LDS for that tap table; its conditions are its own
+    // (S = 30: no biased accumulators, and the int8 kernels' limb-sum bound `wide` does not apply)
+    if (MB == 16) {
+        static const char* noint16 = getenv("D2D_NO_INTQ");
+        const bool range_ok = a.scale_bits >= 20 && a.scale_bits <= 30 && a.sum_abs_q != 0 && a.sum_abs_q < (1ull << 31) && a.mx_exact;
+        if ((nomx && atoi(nomx)) || !mx_supported(MB, N) || !range_ok || noint16) return 0;
+        if (a.to_scratch) return a.epi.channels >= 2 && a.epi.channels % 2 == 0 ? 5 : 0;
+        const bool depth_ok = a.epi.bits == 32 ? a.epi.dither != 'F' : ((a.epi.bits == 24 || a.epi.bits == 16) && m.fbits > 0 && m.fbits <= 16 && a.epi.dither != 'F');
+        if (a.epi.channels != 2 || !depth_ok || a.epi.dither == 'N') return 0;
+        if (a.epi.gain == 1.0) return 5;
+        const char* nogain16 = getenv("D2D_NO_GAINQ");
+        return mx_gain_supported(MB, N) && !(nogain16 && atoi(nogain16)) ? 5 : 0;
+    }
     // the fp6 x fp4 kernel (d2d_kernels_mx.hip) serves what the pipelined int8 kernel serves at M = 32 and 64: 5
     if (!(nomx && atoi(nomx)) && mx_supported(MB, N) && mx_eligible(a, m)) return 5;
     // ... and stereo frames at another level than 0 dB (its gain flavours)
@@ -843,6 +856,10 @@ hipError_t launch_fir_mfma2(const FirArgs& a, int M, int N, uint32_t max_nout, u
     size_t smem = 0;
     mfma2_geometry(a, MB, NPG, m, smem);
     const uint32_t nrows = (nstreams / C) * m.ngroups;       // grid rows: one per (file, channel group)
+    if (a.pipelined == 5) {                                  // the fp6 kernel has its own LDS layout (and M = 128 no two-group one at all)
+        if (MB == 16) m.gainq = (!a.to_scratch && a.epi.gain != 1.0) ? 1u : 0u;
+        return launch_fir_mx(m, MB, N, max_nout, nrows, s);
+    }
     if (smem > 160 * 1024) return hipErrorInvalidValue;
     const uint32_t nwt = (max_nout + (M2_TILE - 1)) / M2_TILE;
     // the epilogue flavour: the integers for the stage-A scratch, stereo 24-bit packed in registers, or anything via LDS

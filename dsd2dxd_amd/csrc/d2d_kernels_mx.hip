@@ -291,7 +291,8 @@ __global__ __launch_bounds__(D2D_MX_THREADS) void d2d_fir_mx_kernel(Mfma2Args m)
     // accumulators start from -2^S: the digit-4 rows (weight 2^20) of every sample
     // (EB, the dithered integer depths: the accumulators start from zero instead -- sixteen registers less -- and the -2^S rides in the
     // three-operand add that applies the dither; the extremes are then kept on v + 2^S)
-    constexpr bool EB = ((KIND == 1 || KIND == 2) && (SBY == 2 || SBY == 3)) || GN;
+    // (M = 128: S = 30 and sum |q| > 2^30, v + 2^S does not fit an int32: the accumulators start from -2^S there)
+    constexpr bool EB = MB < 16 && (((KIND == 1 || KIND == 2) && (SBY == 2 || SBY == 3)) || GN);
     v16f cinit;
 #pragma unroll
     for (int i = 0; i < 16; ++i) cinit[i] = (!EB && i < 15 && (i % 5) == 4) ? -(float)(1 << (a.scale_bits - 20)) : 0.0f;
@@ -355,7 +356,7 @@ __global__ __launch_bounds__(D2D_MX_THREADS) void d2d_fir_mx_kernel(Mfma2Args m)
     asm volatile("" : "+v"(kFs));
     uint32_t kF = (uint32_t)F_, kSh = 16u - (uint32_t)F_, kShR = 32u - (uint32_t)F_;
     uint32_t kC1 = 0x7feb352dU, kC2 = 0x846ca68bU, kTm = (uint32_t)-32767;
-    uint32_t k15 = 15u;
+    uint32_t k15 = MB == 16 ? 10u : 15u;
     float k32 = 32.0f, k1024 = 1024.0f;
     int32_t kHalf = 1 << (F_ - 1);
     asm volatile("" : "+v"(kF), "+v"(kSh), "+v"(kShR), "+v"(kC1), "+v"(kC2), "+v"(kTm), "+v"(k15), "+v"(k32), "+v"(k1024), "+v"(kHalf));
@@ -366,9 +367,16 @@ __global__ __launch_bounds__(D2D_MX_THREADS) void d2d_fir_mx_kernel(Mfma2Args m)
 
     // v = sum q s of sample q of a group's accumulators: digits S0..S4 = registers 5q .. 5q+4 (exact integers)
     auto recombine = [&](const v16f& A, int q) -> int32_t {
-        const float lo = __builtin_fmaf(A[5 * q + 2], k1024, __builtin_fmaf(A[5 * q + 1], k32, A[5 * q]));
-        const float hi = __builtin_fmaf(A[5 * q + 4], k32, A[5 * q + 3]);
-        return mx_lshl_add((int32_t)hi, k15, (int32_t)lo);
+        if constexpr (MB == 16) {
+            // 2192 taps: S0 + 32 S1 + 1024 S2 can pass 2^24; split after two digits instead (mx_exact checks this form for M = 128)
+            const float lo = __builtin_fmaf(A[5 * q + 1], k32, A[5 * q]);
+            const float hi = __builtin_fmaf(A[5 * q + 4], k1024, __builtin_fmaf(A[5 * q + 3], k32, A[5 * q + 2]));
+            return mx_lshl_add((int32_t)hi, k15, (int32_t)lo);             // (k15 holds 10 here)
+        } else {
+            const float lo = __builtin_fmaf(A[5 * q + 2], k1024, __builtin_fmaf(A[5 * q + 1], k32, A[5 * q]));
+            const float hi = __builtin_fmaf(A[5 * q + 4], k32, A[5 * q + 3]);
+            return mx_lshl_add((int32_t)hi, k15, (int32_t)lo);
+        }
     };
     auto noise = [&](uint32_t c, uint32_t nl) -> uint32_t {
         const uint32_t nlo = (uint32_t)j0.n0 + nl;
@@ -804,7 +812,7 @@ __global__ __launch_bounds__(D2D_MX_THREADS) void d2d_fir_mx_kernel(Mfma2Args m)
 }
 
 // ---- host side -------------------------------------------------------------------------------
-// (MB, taps) of the filters this kernel serves: X_M32, C_M32, E_M32, A_M32, A_M64, C_M64, E_M64.  The file is compiled in four parts
+// (MB, taps) of the filters this kernel serves: X_M32, C_M32, E_M32, A_M32, A_M64, C_M64, E_M64, E_M128.  The file is compiled in four parts
 // (Makefile: D2D_MX_PART), each with the kernels of some shapes; part 0 also holds the table builder and the dispatcher.
 #ifndef D2D_MX_PART
 #define D2D_MX_PART 0
@@ -818,7 +826,7 @@ __global__ __launch_bounds__(D2D_MX_THREADS) void d2d_fir_mx_kernel(Mfma2Args m)
 #define D2D_MX_SHAPES_0(X) X(4, 560) X(4, 352)
 #define D2D_MX_SHAPES_1(X) X(4, 384) X(4, 512)
 #define D2D_MX_SHAPES_2(X) X(8, 688) X(8, 1024)
-#define D2D_MX_SHAPES_3(X) X(8, 1104)
+#define D2D_MX_SHAPES_3(X) X(8, 1104) X(16, 2192)
 #endif
 #define D2D_MX_SHAPES(X) D2D_MX_SHAPES_0(X) D2D_MX_SHAPES_1(X) D2D_MX_SHAPES_2(X) D2D_MX_SHAPES_3(X)
 // the gain flavours (KIND + 4: frames at another level than 0 dB) of the shapes that serve frames (not the cascade's A filters), in two
@@ -827,7 +835,7 @@ __global__ __launch_bounds__(D2D_MX_THREADS) void d2d_fir_mx_kernel(Mfma2Args m)
 #ifdef D2D_MX_DEV
 #define D2D_MX_GSHAPES_1(X)
 #else
-#define D2D_MX_GSHAPES_1(X) X(8, 1024) X(8, 1104)
+#define D2D_MX_GSHAPES_1(X) X(8, 1024) X(8, 1104) X(16, 2192)
 #endif
 hipError_t launch_fir_mx_gain0(Mfma2Args& m, int MB, int NT, uint32_t max_nout, uint32_t nrows, hipStream_t s);
 hipError_t launch_fir_mx_gain1(Mfma2Args& m, int MB, int NT, uint32_t max_nout, uint32_t nrows, hipStream_t s);
@@ -874,8 +882,10 @@ bool mx_exact(const d2d_filter_def& f) {
     int64_t sa[5] = {0, 0, 0, 0, 0};
     for (int k = 0; k < f.ntaps; ++k)
         for (int l = 0; l < 5; ++l) { const int d = digit32(2 * (int64_t)tap_q(f, k), l); sa[l] += d < 0 ? -d : d; }
-    const int64_t lo = sa[0] + 32 * sa[1] + 1024 * sa[2];
-    const int64_t hi = sa[3] + 32 * (sa[4] + ((int64_t)1 << (f.S - 20)));
+    // the kernel's two f32 parts: digits 0-2 | 3-4 (M = 128: 0-1 | 2-4), the -2^S start value in digit 4
+    const bool s23 = f.M == 128;
+    const int64_t lo = s23 ? sa[0] + 32 * sa[1] : sa[0] + 32 * sa[1] + 1024 * sa[2];
+    const int64_t hi = s23 ? sa[2] + 32 * sa[3] + 1024 * (sa[4] + ((int64_t)1 << (f.S - 20))) : sa[3] + 32 * (sa[4] + ((int64_t)1 << (f.S - 20)));
     // 2 q has to fit five digits: |2q| <= 16 * (32^5 - 1) / 31
     for (int k = 0; k < f.ntaps; ++k) { const int64_t q2 = 2 * (int64_t)tap_q(f, k); if (q2 > 16236247 || q2 < -17318416) return false; }
     return f.S >= 20 && f.S <= 30 && lo < (1 << 24) && hi < (1 << 24);

@@ -53,7 +53,8 @@ __host__ __device__ constexpr int mx_slot(int MB, int NT, int G, int u, int g) {
 #ifndef D2D_MX_G8
 #define D2D_MX_G8 2
 #endif
-__host__ __device__ constexpr int mx_g(int MB) { return MB == 4 ? D2D_MX_G4 : D2D_MX_G8; }
+// M = 128: one group (the fragments of a second one would be held for twelve steps: 84 registers)
+__host__ __device__ constexpr int mx_g(int MB) { return MB == 4 ? D2D_MX_G4 : MB == 16 ? 1 : D2D_MX_G8; }
 
 struct Mfma2Args;
 bool mx_supported(int MB, int NT);                 // is a kernel compiled for this shape?

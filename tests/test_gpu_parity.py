@@ -303,7 +303,7 @@ def test_noise_shaped_many_segments_many_waves(engine_lib, oracle_mod, bits):
                          ids=["fp6_chain", "fp6_chain_16bit", "fp6_chain_float", "dense_chain", "sparse_chain", "dense_chain_16bit", "dense_chain_float"])
 @pytest.mark.parametrize("dither", ["T", "R", "X"])
 @pytest.mark.parametrize("dsd_rate,out_rate,filt", [(1, 88200, "E"), (1, 88200, "X"), (2, 88200, "E"), (2, 176400, "C"), (4, 176400, "E"),
-                                                    (1, 176400, "E"), (1, 352800, "E"), (1, 176400, "X"), (2, 352800, "C"), (1, 352800, "D")])
+                                                    (1, 176400, "E"), (1, 352800, "E"), (1, 176400, "X"), (2, 352800, "C"), (1, 352800, "D"), (4, 88200, "E")])
 def test_pipelined_stereo_kernel_fast_and_careful_tiles(engine_lib, oracle_mod, monkeypatch, dsd_rate, out_rate, filt, dither, chain, bits):
     """Stereo 24-bit (and 16-bit, and float without the float dither) at 0 dB runs a software-pipelined kernel -- d2d_fir_mx_kernel (fp6 x fp4
     matrix-core chain, M = 32 and 64) or d2d_fir_mfma3_kernel (int8 chain; every M up to 64 with D2D_NO_MX=1): the requantiser rides on the next chain in its branch-free form and a
@@ -317,7 +317,9 @@ def test_pipelined_stereo_kernel_fast_and_careful_tiles(engine_lib, oracle_mod, 
     if sparse and (filt != "E" or out_rate // dsd_rate > 88200):
         pytest.skip("the sparse chain is compiled for the E filters at M = 32 and 64 only")
     if chain == "mx" and M < 32:
-        pytest.skip("the fp6 chain serves M = 32 and 64 (at M = 8 and 16 the groups of six phases do not share tap fragments)")
+        pytest.skip("the fp6 chain serves M = 32, 64 and 128 (at M = 8 and 16 the groups of six phases do not share tap fragments)")
+    if chain != "mx" and M == 128:
+        pytest.skip("M = 128: the fp6 kernel only (the int8 kernels' tap table does not fit next to eight waves)")
     monkeypatch.setenv("D2D_SPARSE", str(sparse))
     monkeypatch.setenv("D2D_NO_MX", "0" if chain == "mx" else "1")
     rng = np.random.default_rng(5)
