@@ -46,6 +46,7 @@ struct orc_ctx {
     int32_t* ilut;    /* Wb x 256 */
     uint8_t* sbuf; size_t sbuf_cap;
     int fine;         /* orc_use_fine_taps: the taps are the 32-bit grid's */
+    int rs_f64;       /* orc_use_f64_resamp_coef: stage B with the design's f64 coefficients (what the 2^-28 grid costs) */
 };
 
 static uint8_t bitrev8(uint8_t v) {
@@ -340,6 +341,11 @@ int orc_translate_f64(orc_ctx* c, const uint8_t* dsd, size_t L, void* pcm_out, s
                 int64_t isum = 0;
                 for (int k = 0; k < P; ++k) isum += (int64_t)g[k] * (int64_t)(xp[-k] * xscale);   /* x * 2^S is an integer, exactly */
                 double acc = (double)isum * yscale;
+                if (c->rs_f64) {   /* study mode (orc_use_f64_resamp_coef): the design's own f64 coefficients, summed in f64 in this order */
+                    const double* gd = c->r->coef + (size_t)phi * P;
+                    acc = 0.0;
+                    for (int k = 0; k < P; ++k) acc += gd[k] * xp[-k];
+                }
                 double v = acc * c->gain;
                 double a = fabs(v); if (a > c->peak[ch]) c->peak[ch] = a;
                 if (f64_out) f64_out[o * C + ch] = v;
@@ -471,6 +477,13 @@ int orc_use_fine_taps(orc_ctx* c) {
     }
     build_byte_tables(c);
     c->fine = 1;
+    return 0;
+}
+
+/* [own] study mode for tests/test_tap_grid.py: stage B of the 48k cascade with the f64 coefficients its integer grid was rounded from */
+int orc_use_f64_resamp_coef(orc_ctx* c) {
+    if (!c || !c->r) return -1;
+    c->rs_f64 = 1;
     return 0;
 }
 

@@ -81,6 +81,8 @@ double orc_tap(const orc_ctx* c, int i);
 int    orc_set_half_taps(orc_ctx* c, const double* half, int n_half);
 /* the filter's 32-bit tap grid (q32 * 2^-(S+8)) instead of the 24-bit one: the engine's d2d_params.tap_bits = 32; 44.1k family, T/R/F/X */
 int    orc_use_fine_taps(orc_ctx* c);
+/* study mode: stage B of the 48k cascade with the f64 coefficients the 2^-28 grid was rounded from (tests/test_tap_grid.py) */
+int    orc_use_f64_resamp_coef(orc_ctx* c);
 
 /* The dither generator, exposed so tests can pin it. */
 uint32_t orc_rng(uint64_t seed, uint32_t channel, uint64_t n);

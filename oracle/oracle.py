@@ -80,6 +80,7 @@ def _load(path):
     L.orc_tap.restype = C.c_double
     L.orc_set_half_taps.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
     L.orc_use_fine_taps.argtypes = [C.c_void_p]
+    L.orc_use_f64_resamp_coef.argtypes = [C.c_void_p]
     L.orc_rng.argtypes = [C.c_uint64, C.c_uint32, C.c_uint64]
     L.orc_rng.restype = C.c_uint32
     _lib = L
@@ -129,6 +130,11 @@ class Oracle:
         v = [C.c_int() for _ in range(5)]
         lib().orc_filter_info(self._h, *[C.byref(x) for x in v])
         return dict(M=v[0].value, ntaps=v[1].value, S=v[2].value, L=v[3].value, P=v[4].value)
+
+    def use_f64_resamp_coef(self):
+        """stage B of the 48k cascade with the design's f64 coefficients instead of the 2^-28 grid (a study mode)"""
+        if lib().orc_use_f64_resamp_coef(self._h):
+            raise OracleError("not a 48k-family context")
 
     def set_half_taps(self, half):
         """replace the taps (2nd half, centre outward) -- e.g. by the designs' unquantised f64 taps"""

@@ -168,3 +168,28 @@ def test_32_bit_taps_are_refused_where_they_are_not_defined(engine_lib):
     for kw in (dict(output_rate=96000), dict(output_rate=88200, dither="N"), dict(output_rate=88200, tap_bits=16)):
         with pytest.raises(engine_lib.D2DError):
             engine_lib.Engine(**dict(dict(dsd_rate=1, channels=2, fmt="P", endianness="L", bit_depth=24, tap_bits=32), **kw))
+
+
+# ---- stage B of the 48k cascade: what its 2^-28 coefficient grid costs against the f64 design it was rounded from ----
+
+@pytest.mark.parametrize("dsd_rate,out_rate", [(1, 96000), (1, 192000), (2, 384000), (8, 96000)])
+def test_stage_b_grid_cost_against_its_f64_coefficients(oracle_mod, dsd_rate, out_rate):
+    """round 3 put stage B's polyphase coefficients on a dyadic grid (every phase sums to 1 exactly) so that it runs as an exact integer
+    matrix product; against round 2's definition -- the f64 design, summed in f64 -- the float output must stay inside the north
+    star's 1e-6 RMS, and the 24-bit samples differ by one LSB at most"""
+    O = oracle_mod
+    buf = _inputs(dsd_rate, nbytes=4096 * 12 * dsd_rate)
+    kw = dict(dsd_rate=dsd_rate, output_rate=out_rate, channels=2, fmt="P", endianness="L", block_size=4096, filter="E", seed=3)
+    outs = {}
+    for mode in ("grid", "f64"):
+        for bits, dither in ((32, "X"), (24, "T")):
+            o = O.Oracle(bit_depth=bits, dither=dither, **kw)
+            if mode == "f64":
+                o.use_f64_resamp_coef()
+            outs[mode, bits] = o.translate(buf)[0]
+    rms, rate, worst = _stats(outs["grid", 32].view(np.float32), outs["f64", 32].view(np.float32), outs["grid", 24], outs["f64", 24])
+    print(f"stage B grid, DSD{64 * dsd_rate}->{out_rate}: float RMS diff {rms:.3e}, 24-bit samples that differ {100 * rate:.3f} %, by at most {worst} LSB")
+    # float: 5e-9 .. 9e-8, eleven times and more inside the bound.  The integer depths see more than rounding at L = 160: the grid also makes
+    # every polyphase branch sum to exactly 1, where the f64 design's branches sum to 1 +- 7e-7 (a gain ripple with the period of the
+    # resampler, -123 dB): at half of full scale that is up to 3 LSB of 24 bits (DESIGN.md section 2)
+    assert rms < 1e-6 and worst <= (4 if out_rate == 384000 else 1)
