@@ -388,7 +388,7 @@ __global__ __launch_bounds__(D2D_M3_THREADS) void d2d_fir_mfma3_kernel(Mfma2Args
         if constexpr (DK == 1) q = x + fma((double)t, 0x1p-16, -1.0);
         else if constexpr (DK == 2) q = x + fma((double)t, 0x1p-17, -0.5);
         const double rq = fmax(fmin(trunc(q + copysign(0.5, q)), kLim - 1.0), -kLim);
-        return (int32_t)rq;
+        return (int32_t)rq << m.qsh;                                   // (20-bit samples ride in 24 bits as r << 4)
     };
 
     // v = sum q s of sample k of a group's accumulators: (A0 >> 6) + 4*A1 + 2^10*A2 + 2^18*A3 (A0 is a multiple of 128; mod 2^32)

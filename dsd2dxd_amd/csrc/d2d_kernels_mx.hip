@@ -398,7 +398,7 @@ __global__ __launch_bounds__(D2D_MX_THREADS) void d2d_fir_mx_kernel(Mfma2Args m)
         if constexpr (DK == 1) q = x + fma((double)t, 0x1p-16, -1.0);
         else if constexpr (DK == 2) q = x + fma((double)t, 0x1p-17, -0.5);
         const double rq = fmax(fmin(trunc(q + copysign(0.5, q)), kLim - 1.0), -kLim);
-        return (int32_t)rq;
+        return (int32_t)rq << m.qsh;                                   // (20-bit samples ride in 24 bits as r << 4)
     };
     // the general per-sample requantiser (any tile): x = v * 2^-F LSB, dither in 2^-16 (2^-17) LSB, round half away, clip
     auto quant_slow = [&](int32_t v, uint32_t c, uint32_t nl) -> int32_t {
