@@ -262,6 +262,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pcie", action="store_true", help="skip the host-resident batch (pinned host in/out, upload/convert/download overlapped) that is reported as the extra pcie_inclusive object, never as value")
     ap.add_argument("--cpu-budget", type=float, default=12.0, help="seconds of CPU-baseline work")
+    ap.add_argument("--dither", default="", help="override the workload's dither (T, R, X, F, N)")
     ap.add_argument("--level", type=float, default=0.0, help="volume in dB (the reference's -l; its own test scripts use +-4)")
     ap.add_argument("--tap-bits", type=int, default=24, choices=(24, 32), help="tap grid (32: the optional 32-bit taps, two FIR passes and a combining pass; 44.1k-family workloads with dither T/R/F/X)")
     ap.add_argument("--pcie-slice", type=int, default=0, help="bytes per channel per slice of the host-resident batch (0 = the library's default)")
@@ -299,6 +300,8 @@ def main():
             dist.init_process_group(backend)
 
     dsd_rate, out_rate, bits, dither, channels, bytes_per_sample = WORKLOADS[args.workload]
+    if args.dither:
+        dither = args.dither.upper()
     M = DSD64 * dsd_rate / out_rate
     blocks = max(1, int(round(args.seconds * DSD64 * dsd_rate / 8 / 4096)))
     bpc = blocks * 4096                                   # bytes per channel per file

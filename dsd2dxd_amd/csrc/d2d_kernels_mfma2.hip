@@ -743,9 +743,9 @@ int mfma2_pipelined(const FirArgs& a, int M, int N) {
         const bool range_ok = a.scale_bits >= 20 && a.scale_bits <= 30 && a.sum_abs_q != 0 && a.sum_abs_q < (1ull << 31) && a.mx_exact;
         if ((nomx && atoi(nomx)) || !mx_supported(MB, N) || !range_ok || noint16) return 0;
         if (a.to_scratch) return a.epi.channels >= 2 && a.epi.channels % 2 == 0 ? 5 : 0;
-        const bool depth_ok = a.epi.bits == 32 ? a.epi.dither != 'F' : ((a.epi.bits == 24 || a.epi.bits == 20 || a.epi.bits == 16) && m.fbits > 0 && m.fbits <= 16 && a.epi.dither != 'F');
+        const bool depth_ok = a.epi.bits == 32 ? true : ((a.epi.bits == 24 || a.epi.bits == 20 || a.epi.bits == 16) && m.fbits > 0 && m.fbits <= 16 && a.epi.dither != 'F');
         if (a.epi.channels != 2 || !depth_ok || a.epi.dither == 'N') return 0;
-        if (a.epi.gain == 1.0 && m.qsh == 0) return 5;
+        if (a.epi.gain == 1.0 && m.qsh == 0 && !(a.epi.bits == 32 && a.epi.dither == 'F')) return 5;
         const char* nogain16 = getenv("D2D_NO_GAINQ");
         return mx_gain_supported(MB, N) && !(nogain16 && atoi(nogain16)) ? 5 : 0;
     }
@@ -778,11 +778,11 @@ static void mfma2_geometry(const FirArgs& a, int MB, int NPG, Mfma2Args& m, size
     // (the fast form carries v0 = v + 2^S in an int32: 2^S + sum|q| has to stay below 2^31)
     m.intq = (!noint && !a.to_scratch && a.epi.bits != 32 && a.epi.gain == 1.0 && !m.wide && m.fbits > 0 && m.fbits <= 16 &&
               a.sum_abs_q != 0 && (1ull << a.scale_bits) + a.sum_abs_q < (1ull << 31)) ? 1u : 0u;
-    // stereo 16/24-bit (dither T, R, none) or float (no float dither) frames at another level than 0 dB, and 20-bit frames at any level
+    // stereo 16/24-bit (dither T, R, none) or float (no float dither) frames at another level than 0 dB, and 20-bit frames and the float dither (the CLI's default for -b 32) at any level
     // (the all-integer requantiser has no 20-in-24 form; the f64 one shifts its result)
     const char* nogain = getenv("D2D_NO_GAINQ");           // (read at every engine creation: the tests switch it inside one process)
-    m.gainq = (!noint && !(nogain && atoi(nogain)) && !a.to_scratch && a.epi.channels == 2 && (a.epi.gain != 1.0 || m.qsh != 0) && !m.wide && a.epi.dither != 'F' &&
-               a.epi.dither != 'N' && (a.epi.bits == 32 || (m.fbits > 0 && m.fbits <= 16)) && a.sum_abs_q != 0 && a.sum_abs_q < (1ull << 31)) ? 1u : 0u;
+    m.gainq = (!noint && !(nogain && atoi(nogain)) && !a.to_scratch && a.epi.channels == 2 && (a.epi.gain != 1.0 || m.qsh != 0 || (a.epi.bits == 32 && a.epi.dither == 'F')) && !m.wide &&
+               (a.epi.dither != 'F' || a.epi.bits == 32) && a.epi.dither != 'N' && (a.epi.bits == 32 || (m.fbits > 0 && m.fbits <= 16)) && a.sum_abs_q != 0 && a.sum_abs_q < (1ull << 31)) ? 1u : 0u;
     m.off_waves = (uint32_t)(2 * NPG) * 1024u;
     m.off_out = (uint32_t)m2_stream_bytes(MB, NPG);
     // (only the LDS-staged epilogue needs the output slice)
@@ -858,7 +858,7 @@ hipError_t launch_fir_mfma2(const FirArgs& a, int M, int N, uint32_t max_nout, u
     mfma2_geometry(a, MB, NPG, m, smem);
     const uint32_t nrows = (nstreams / C) * m.ngroups;       // grid rows: one per (file, channel group)
     if (a.pipelined == 5) {                                  // the fp6 kernel has its own LDS layout (and M = 128 no two-group one at all)
-        if (MB == 16) m.gainq = (!a.to_scratch && (a.epi.gain != 1.0 || m.qsh != 0)) ? 1u : 0u;
+        if (MB == 16) m.gainq = (!a.to_scratch && (a.epi.gain != 1.0 || m.qsh != 0 || (a.epi.bits == 32 && a.epi.dither == 'F'))) ? 1u : 0u;
         return launch_fir_mx(m, MB, N, max_nout, nrows, s);
     }
     if (smem > 160 * 1024) return hipErrorInvalidValue;

@@ -383,7 +383,17 @@ __global__ __launch_bounds__(D2D_M3_THREADS) void d2d_fir_mfma3_kernel(Mfma2Args
     // the f64 requantiser from the hash word's dither term t (triangular: lo16 + hi16 + 1, rectangular: 2 hi16 + 1), as d2d_device.h: finish_int
     auto quant_gain = [&](int32_t v, uint32_t t) -> int32_t {
         const double x = (double)v * kCg;
-        if constexpr (SBY == 4) return __float_as_int((float)x);
+        if constexpr (SBY == 4) {
+            if constexpr (DK == 3) {
+                // Airwindows "Dither Float" as d2d_device.h: quantise_f32 states it (t = the raw hash word)
+                const uint32_t fb = __float_as_uint((float)x);
+                const int e = (int)((fb >> 23) & 0xFFu);
+                const int expon = e ? e - 126 : 0;
+                const double tt = ((double)t - 2147483647.0) * 5.5e-36;
+                return __float_as_int((float)(x + ldexp(tt, expon + 62)));
+            }
+            return __float_as_int((float)x);
+        }
         double q = x;
         if constexpr (DK == 1) q = x + fma((double)t, 0x1p-16, -1.0);
         else if constexpr (DK == 2) q = x + fma((double)t, 0x1p-17, -0.5);
@@ -411,7 +421,7 @@ __global__ __launch_bounds__(D2D_M3_THREADS) void d2d_fir_mfma3_kernel(Mfma2Args
         int32_t rr;
         if constexpr (GN) {
             uint32_t t = 0;
-            if constexpr (DK != 0) { const uint32_t z = noise(c, nl); t = DK == 1 ? (z & 0xFFFFu) + (z >> 16) + 1u : 2u * (z >> 16) + 1u; }
+            if constexpr (DK != 0) { const uint32_t z = noise(c, nl); t = DK == 1 ? (z & 0xFFFFu) + (z >> 16) + 1u : DK == 2 ? 2u * (z >> 16) + 1u : z; }
             return quant_gain(v, t);
         } else if constexpr (DK == 2) {
             const uint32_t z = noise(c, nl);
@@ -454,7 +464,7 @@ __global__ __launch_bounds__(D2D_M3_THREADS) void d2d_fir_mfma3_kernel(Mfma2Args
             z ^= z >> 16; z *= kC1;
             z ^= z >> 15; z *= kC2;
             z ^= z >> 16;
-            if constexpr (GN) f.T[i] = DK == 1 ? __builtin_amdgcn_sad_u16(z, 0u, 1u) : ((z >> 15) | 1u);     // lo16 + hi16 + 1; 2 hi16 + 1
+            if constexpr (GN) f.T[i] = DK == 1 ? __builtin_amdgcn_sad_u16(z, 0u, 1u) : DK == 2 ? ((z >> 15) | 1u) : z;     // lo16 + hi16 + 1; 2 hi16 + 1; the float dither's word
             else if constexpr (KIND == 1) f.T[i] = __builtin_amdgcn_sad_u16(z, 0u, kTm);      // lo16 + hi16 - 32767, units of 2^-16 LSB
             else f.T[i] = z >> kShR;                                                       // (2*hi16 + 1) >> (17 - F)
         } else {
@@ -940,6 +950,8 @@ static hipError_t launch_mfma3_gain(Mfma2Args& m, uint32_t nwt_max, uint32_t nro
         if constexpr (SBY != 4) {
             if (m.dkind == 1) return launch_mfma3_t<MB, NPG, NT, 5, SBY>(m, nwt_max, nrows, s);
             if (m.dkind == 2) return launch_mfma3_t<MB, NPG, NT, 6, SBY>(m, nwt_max, nrows, s);
+        } else {
+            if (m.f.epi.dither == 'F') return launch_mfma3_t<MB, NPG, NT, 7, SBY>(m, nwt_max, nrows, s);      // the float dither
         }
         return launch_mfma3_t<MB, NPG, NT, 4, SBY>(m, nwt_max, nrows, s);
     } else return hipErrorInvalidValue;

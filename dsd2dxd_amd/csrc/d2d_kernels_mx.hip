@@ -393,7 +393,17 @@ __global__ __launch_bounds__(D2D_MX_THREADS) void d2d_fir_mx_kernel(Mfma2Args m)
     if constexpr (GN) asm volatile("" : "+v"(kCg), "+v"(kLim));
     auto quant_gain = [&](int32_t v, uint32_t t) -> int32_t {
         const double x = (double)v * kCg;
-        if constexpr (SBY == 4) return __float_as_int((float)x);
+        if constexpr (SBY == 4) {
+            if constexpr (DK == 3) {
+                // Airwindows "Dither Float" as d2d_device.h: quantise_f32 states it (t = the raw hash word)
+                const uint32_t fb = __float_as_uint((float)x);
+                const int e = (int)((fb >> 23) & 0xFFu);
+                const int expon = e ? e - 126 : 0;
+                const double tt = ((double)t - 2147483647.0) * 5.5e-36;
+                return __float_as_int((float)(x + ldexp(tt, expon + 62)));
+            }
+            return __float_as_int((float)x);
+        }
         double q = x;
         if constexpr (DK == 1) q = x + fma((double)t, 0x1p-16, -1.0);
         else if constexpr (DK == 2) q = x + fma((double)t, 0x1p-17, -0.5);
@@ -402,15 +412,16 @@ __global__ __launch_bounds__(D2D_MX_THREADS) void d2d_fir_mx_kernel(Mfma2Args m)
     };
     // the general per-sample requantiser (any tile): x = v * 2^-F LSB, dither in 2^-16 (2^-17) LSB, round half away, clip
     auto quant_slow = [&](int32_t v, uint32_t c, uint32_t nl) -> int32_t {
+        if constexpr (GN) {
+            uint32_t t = 0;
+            if constexpr (DK != 0) { const uint32_t z = noise(c, nl); t = DK == 1 ? (z & 0xFFFFu) + (z >> 16) + 1u : DK == 2 ? 2u * (z >> 16) + 1u : z; }
+            return quant_gain(v, t);
+        }
         const int F = m.fbits;
         const int32_t vh = v >> F;
         const uint32_t vl = (uint32_t)v & ((1u << F) - 1u);
         int32_t rr;
-        if constexpr (GN) {
-            uint32_t t = 0;
-            if constexpr (DK != 0) { const uint32_t z = noise(c, nl); t = DK == 1 ? (z & 0xFFFFu) + (z >> 16) + 1u : 2u * (z >> 16) + 1u; }
-            return quant_gain(v, t);
-        } else if constexpr (KIND == 2) {
+        if constexpr (KIND == 2) {
             const uint32_t z = noise(c, nl);
             const int32_t w = (int32_t)(vl << (17 - F)) + (int32_t)(2u * (z >> 16) + 1u) - 65536;
             const int32_t neg = (vh + (w >> 17)) >> 31;
@@ -457,7 +468,7 @@ __global__ __launch_bounds__(D2D_MX_THREADS) void d2d_fir_mx_kernel(Mfma2Args m)
             z ^= z >> 16; z *= kC1;
             z ^= z >> 15; z *= kC2;
             z ^= z >> 16;
-            if constexpr (GN) f.T = DK == 1 ? __builtin_amdgcn_sad_u16(z, 0u, 1u) : ((z >> 15) | 1u);      // lo16 + hi16 + 1; 2 hi16 + 1
+            if constexpr (GN) f.T = DK == 1 ? __builtin_amdgcn_sad_u16(z, 0u, 1u) : DK == 2 ? ((z >> 15) | 1u) : z;      // lo16 + hi16 + 1; 2 hi16 + 1; the float dither's word
             else if constexpr (KIND == 1) f.T = __builtin_amdgcn_sad_u16(z, 0u, kTm);   // lo16 + hi16 - 32767, units of 2^-16 LSB
             else f.T = z >> kShR;                                                         // (2*hi16 + 1) >> (17 - F)
             asm volatile("" : "+v"(f.T));
@@ -534,6 +545,8 @@ __global__ __launch_bounds__(D2D_MX_THREADS) void d2d_fir_mx_kernel(Mfma2Args m)
     auto redo = [&](uint32_t cbuf, uint32_t tile, uint32_t c, int32_t (&out)[NS]) {
         v16f t[G];
         chain(cbuf, t, no_hook);
+        pin(t);                                     // the chain ends here, its results are complete before the first one is read
+        __builtin_amdgcn_s_sleep(1);
         redo_acc(t, tile, c, out);
     };
     auto tile_full = [&](uint32_t tile) -> bool { return tile * (uint32_t)TILE + (uint32_t)TILE <= j0.nout; };
@@ -754,13 +767,18 @@ __global__ __launch_bounds__(D2D_MX_THREADS) void d2d_fir_mx_kernel(Mfma2Args m)
         issue_loads(t, C1{}, std::false_type{});
         if (il) write_lds_t(C1{}, std::true_type{}); else write_lds(C1{});
         wave_sync2();
-        int32_t o0[NS], o1[NS];
-        redo(0u, t, 0, o0);
-        redo(1u, t, 1, o1);
-        if constexpr (SCR) { store_scr(t, 0, o0); store_scr(t, 1, o1); }
-        else {
-            put_samples(0, o0);
-            put_samples(1, o1);
+        // (one channel at a time, its samples put away before the other channel's chain starts: shorter live ranges)
+        {
+            int32_t o0[NS];
+            redo(0u, t, 0, o0);
+            if constexpr (SCR) store_scr(t, 0, o0); else put_samples(0, o0);
+        }
+        {
+            int32_t o1[NS];
+            redo(1u, t, 1, o1);
+            if constexpr (SCR) store_scr(t, 1, o1); else put_samples(1, o1);
+        }
+        if constexpr (!SCR) {
             wave_sync2();
             store_tile(t);
         }
@@ -999,7 +1017,10 @@ static hipError_t launch_mx_t(Mfma2Args& m, uint32_t max_nout, uint32_t nrows, h
 #define D2D_MX_GLAUNCH(mb, nt)                                                                                     \
     if (MB == mb && NT == nt) {                                                                                    \
         constexpr int G = mx_g(mb);                                                                                \
-        if (m.f.epi.sample_bytes == 4) return launch_mx_t<mb, nt, G, 4, 4>(m, max_nout, nrows, s);                  \
+        if (m.f.epi.sample_bytes == 4) {                                                                           \
+            if (m.f.epi.dither == 'F') return launch_mx_t<mb, nt, G, 7, 4>(m, max_nout, nrows, s);                  \
+            return launch_mx_t<mb, nt, G, 4, 4>(m, max_nout, nrows, s);                                             \
+        }                                                                                                          \
         if (m.f.epi.sample_bytes == 2) {                                                                           \
             if (m.dkind == 1) return launch_mx_t<mb, nt, G, 5, 2>(m, max_nout, nrows, s);                           \
             if (m.dkind == 2) return launch_mx_t<mb, nt, G, 6, 2>(m, max_nout, nrows, s);                           \

@@ -474,9 +474,9 @@ def test_interleaved_stereo_is_deinterleaved_inside_the_fir_kernel(engine_lib, o
 
 @pytest.mark.parametrize("dsd_rate,out_rate", [(1, 352800), (1, 176400), (2, 352800), (2, 705600), (4, 1411200), (1, 88200), (2, 88200), (2, 176400), (4, 176400)])
 @pytest.mark.parametrize("bits,dither,level", [(24, "T", -3.0), (16, "R", 4.0), (24, "X", -0.5), (32, "X", -4.0), (16, "T", 20.0), (24, "R", -60.0),
-                                               (20, "T", 0.0), (20, "R", 20.0), (20, "X", -4.0)])
+                                               (20, "T", 0.0), (20, "R", 20.0), (20, "X", -4.0), (32, "F", 0.0), (32, "F", -4.0)])
 def test_level_in_db_inside_the_pipelined_kernel(engine_lib, oracle_mod, monkeypatch, dsd_rate, out_rate, bits, dither, level):
-    """--level other than 0 dB (the reference's own test scripts use +-4 dB, build_test_*.sh) and 20-bit frames at any level: stereo frames stay on the pipelined
+    """--level other than 0 dB (the reference's own test scripts use +-4 dB, build_test_*.sh) 20-bit frames and the float dither (the CLI's default for -b 32) at any level: stereo frames stay on the pipelined
     kernels (int8 at M = 8, 16; fp6 at M = 32, 64), whose epilogue then follows the f64 definition (KIND + 4); + 20 dB clips both rails, - 60 dB leaves a few LSB.
     Equal to the oracle and to the one-group kernel (D2D_NO_GAINQ=1), samples and peaks, over ragged calls."""
     nbytes = 4096 * 6 * dsd_rate
@@ -505,7 +505,7 @@ def test_level_in_db_inside_the_pipelined_kernel(engine_lib, oracle_mod, monkeyp
         name = e.kernel_name()
         pipelined = "d2d_fir_mx_kernel" if 2822400 * dsd_rate // out_rate >= 32 else "d2d_fir_mfma3_kernel"
         if off == "0":
-            assert pipelined in name and name.split(",")[-2].strip() in ("4", "5", "6"), name
+            assert pipelined in name and name.split(",")[-2].strip() in ("4", "5", "6", "7"), name
         else:
             assert pipelined not in name, name
     assert np.array_equal(outs["0"], outs["1"])
