@@ -17,7 +17,13 @@ if ks:
 shutil.copy(os.path.join(src, "bench_trace.json"), os.path.join(prof, name + "_bench_under_rocprof_trace.json"))
 line = [l for l in open(os.path.join(src, "bench_trace.json")).read().splitlines() if l.startswith("{")][-1]
 bench = json.loads(line)
-workload = bench["config"]["workload"].split(":")[0]
+cfg = bench["config"]["workload"]
+workload = cfg.split(":")[0]
+# a bench line taken with modifiers gets its own key (bench.py only ever cites the plain workload names)
+if "32-bit grid" in cfg:
+    workload += "+taps32"
+if ", level " in cfg:
+    workload += "+level" + cfg.split(", level ")[1].split(" dB")[0]
 fetch, write = defaultdict(list), defaultdict(list)
 for i, dst, cname in ((3, fetch, "FETCH_SIZE"), (4, write, "WRITE_SIZE")):
     for f in glob.glob(os.path.join(src, f"pmc{i}", "**", "*counter_collection.csv"), recursive=True):
