@@ -193,3 +193,35 @@ def test_stage_b_grid_cost_against_its_f64_coefficients(oracle_mod, dsd_rate, ou
     # every polyphase branch sum to exactly 1, where the f64 design's branches sum to 1 +- 7e-7 (a gain ripple with the period of the
     # resampler, -123 dB): at half of full scale that is up to 3 LSB of 24 bits
     assert rms < 1e-6 and worst <= (4 if out_rate == 384000 else 1)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fmt", ["P", "I"])
+def test_batch_of_files_with_32_bit_taps(engine_lib, oracle_mod, fmt):
+    """d2d_translate_batch_device with tap_bits = 32: three files of different length (one of them empty in the second call) through the
+    two scratch passes and the combining pass, device-resident, two calls with carried state"""
+    import torch
+    kw = dict(dsd_rate=1, output_rate=176400, channels=2, fmt=fmt, endianness="M" if fmt == "I" else "L", block_size=4096 if fmt == "P" else 1,
+              filter="E", bit_depth=24, dither="T", seed=9, tap_bits=32)
+    lens = [[4096 * 5, 4096 * 3], [4096 * 2, 0], [4096 * 9, 4096 * 4 + (0 if fmt == "P" else 777)]]
+    chans = [[synth("sine" if c == 0 else "pink", sum(l), seed=90 + 5 * f + c, msb_first=fmt == "I", amp=0.4 if c == 0 else 0.098) for c in range(2)] for f, l in enumerate(lens)]
+    e = engine_lib.Engine(n_files=3, kernel=2, **kw)
+    oracles = [oracle_mod.Oracle(**kw) for _ in lens]
+    fb = e.frame_bytes
+    pos = [0, 0, 0]
+    for call in range(2):
+        bufs = [pack_layout([ch[pos[f]:pos[f] + lens[f][call]] for ch in chans[f]], fmt, kw["block_size"]) for f in range(3)]
+        d_in = [torch.from_numpy(b).cuda() if b.size else torch.zeros(16, dtype=torch.uint8, device="cuda") for b in bufs]
+        d_out = [torch.zeros(e.next_frames(lens[f][call], file=f) * fb + 16, dtype=torch.uint8, device="cuda") for f in range(3)]
+        ios = (engine_lib.FileIO * 3)()
+        for f in range(3):
+            ios[f].dsd = d_in[f].data_ptr(); ios[f].bytes_per_channel = lens[f][call]
+            ios[f].pcm = d_out[f].data_ptr(); ios[f].pcm_capacity_bytes = d_out[f].numel()
+        e.translate_batch_device(ios, torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        for f in range(3):
+            w, wf = oracles[f].translate(bufs[f])
+            assert ios[f].frames_out == wf and np.array_equal(d_out[f][:wf * fb].cpu().numpy(), w[:wf * fb]), (call, f)
+            pos[f] += lens[f][call]
+    for f in range(3):
+        assert [e.peak(c, f) for c in range(2)] == [oracles[f].peak(c) for c in range(2)]
