@@ -39,7 +39,11 @@ def _case(seed):
     return kw, total, cuts
 
 
-@pytest.mark.parametrize("seed", list(range(40)) + [1000 + i for i in range(16)])
+import os
+_EXTRA = int(os.environ.get("D2D_FUZZ_EXTRA", "0"))      # a longer one-off run: D2D_FUZZ_EXTRA=400 adds that many seeds to each family
+
+
+@pytest.mark.parametrize("seed", list(range(40 + _EXTRA)) + [1000 + i for i in range(16 + _EXTRA)])
 def test_random_configuration(engine_lib, oracle_mod, seed):
     kw, total, cuts = _case(seed)
     if seed >= 1000:                                          # the second family of seeds: the 32-bit tap grid where it is defined

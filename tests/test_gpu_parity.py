@@ -513,3 +513,24 @@ def test_level_in_db_inside_the_pipelined_kernel(engine_lib, oracle_mod, monkeyp
         pcm = decode_pcm(outs["0"], bits, 2)
         top = (1 << (bits - 1)) - 1 if bits != 20 else ((1 << 19) - 1) << 4          # (20-bit samples sit in 24 bits as r << 4)
         assert pcm.max() == top and pcm.min() == (-(1 << (bits - 1)) if bits != 20 else -(1 << 23))
+
+
+@pytest.mark.parametrize("dsd_rate,out_rate,bits,dither,level", [(1, 88200, 24, "T", -3.0), (1, 352800, 16, "R", 4.0), (2, 88200, 32, "F", 0.0), (1, 176400, 20, "T", 0.0),
+                                                                 (4, 88200, 24, "R", -1.0), (2, 176400, 32, "X", -6.0)])
+def test_f64_flavour_when_waves_walk_several_tiles(engine_lib, oracle_mod, dsd_rate, out_rate, bits, dither, level):
+    """the pipelined kernels' f64 flavour (other levels, 20-bit, the float dither) on streams long enough for every wave to take several
+    tiles in its fixed-order loop (the short cases of test_level_in_db_inside_the_pipelined_kernel consist of a trip or two)"""
+    M = 2822400 * dsd_rate // out_rate
+    nbytes = 6_000_000 * (4 if M >= 32 else 1)               # 2048 waves: several thousand tiles of 512 (M = 8, 16) / 576 / 384 / 192 outputs
+    chans = [synth("sine", nbytes, seed=81, dsd_rate=dsd_rate, amp=0.5), synth("pink", nbytes, seed=82, dsd_rate=dsd_rate, amp=0.2)]
+    kw = dict(dsd_rate=dsd_rate, output_rate=out_rate, channels=2, fmt="P", endianness="L", block_size=4096, filter="E",
+              bit_depth=bits, dither=dither, seed=6, level_db=level)
+    e = engine_lib.Engine(n_files=1, kernel=2, **kw)
+    o = oracle_mod.Oracle(**kw)
+    n4 = nbytes // 4096 * 4096
+    buf = pack_layout([ch[:n4] for ch in chans], "P", 4096)
+    g, gf = e.translate(buf)
+    w, wf = o.translate(buf)
+    assert e.kernel_name().split(",")[-2].strip() in ("4", "5", "6", "7"), e.kernel_name()
+    assert gf == wf and np.array_equal(g, w[:wf * e.frame_bytes])
+    assert [e.peak(c) for c in range(2)] == [o.peak(c) for c in range(2)]
