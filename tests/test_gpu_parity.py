@@ -534,3 +534,20 @@ def test_f64_flavour_when_waves_walk_several_tiles(engine_lib, oracle_mod, dsd_r
     assert e.kernel_name().split(",")[-2].strip() in ("4", "5", "6", "7"), e.kernel_name()
     assert gf == wf and np.array_equal(g, w[:wf * e.frame_bytes])
     assert [e.peak(c) for c in range(2)] == [o.peak(c) for c in range(2)]
+
+
+@pytest.mark.parametrize("bits,dither", [(24, "T"), (16, "R"), (32, "X")])
+def test_m128_on_the_fp6_kernel_with_several_tiles_per_wave(engine_lib, oracle_mod, bits, dither):
+    """DSD256 -> 88.2 kHz (M = 128, one group per column, accumulators from -2^S): 8000 tiles over 2048 waves, the all-integer flavours"""
+    nbytes = 24_000_000
+    chans = [synth("sine", nbytes, seed=83, dsd_rate=4, amp=0.5), synth("pink", nbytes, seed=84, dsd_rate=4, amp=0.2)]
+    kw = dict(dsd_rate=4, output_rate=88200, channels=2, fmt="P", endianness="L", block_size=4096, filter="E", bit_depth=bits, dither=dither, seed=7)
+    e = engine_lib.Engine(n_files=1, kernel=2, **kw)
+    o = oracle_mod.Oracle(**kw)
+    n4 = nbytes // 4096 * 4096
+    buf = pack_layout([ch[:n4] for ch in chans], "P", 4096)
+    g, gf = e.translate(buf)
+    w, wf = o.translate(buf)
+    assert e.kernel_name().startswith("d2d_fir_mx_kernel<16, 2192, 1,"), e.kernel_name()
+    assert gf == wf and np.array_equal(g, w[:wf * e.frame_bytes])
+    assert [e.peak(c) for c in range(2)] == [o.peak(c) for c in range(2)]
