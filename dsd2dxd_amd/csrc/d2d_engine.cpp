@@ -324,9 +324,8 @@ int d2d_create(const d2d_params* params, uint32_t n_files, d2d_engine** out) {
             }
             // byte-interleaved stereo (DFF files, the CLI's default -f I) into frames through a pipelined kernel (fp6: M = 32, 64; int8: M = 8, 16):
             // the same, inside one wave
-            // (the int8 kernel's scratch flavour too: stereo DFF input into the 48k cascade and the noise shaper)
-            const bool to_scr = e->fc.resamp || e->noise_shape;
-            if (e->deinterleave && ((e->mfma_pipe == 5 && !to_scr) || (e->mfma_pipe == 3 && e->M < 64 && !e->fine)) && e->Cin == 2 && e->C == 2 &&
+            // (the scratch flavours too: stereo DFF input into the 48k cascade and the noise shaper; not the two passes of 32-bit taps)
+            if (e->deinterleave && ((e->mfma_pipe == 5 || (e->mfma_pipe == 3 && e->M < 64)) && !e->fine) && e->Cin == 2 && e->C == 2 &&
                 !(nocoop && atoi(nocoop))) {
                 e->il2 = true; e->deinterleave = false; e->B = 1;
             }

@@ -127,10 +127,10 @@ __global__ __launch_bounds__(D2D_MX_THREADS) void d2d_fir_mx_kernel(Mfma2Args m)
     // FLAT: chunk q at byte 16 q, window dword L at LDS dword L + X0 ----
     const uint32_t X0 = (uint32_t)(first0 >> 2) & 3u;
     constexpr uint32_t DUMMY = SB - 16u;
-    // IL (a.il2: byte-interleaved stereo -- DFF files, the CLI's default -f I -- both channels converted, frame flavours): the tile's
+    // IL (a.il2: byte-interleaved stereo -- DFF files, the CLI's default -f I -- both channels converted): the tile's
     // frames come as they lie in memory, 2 NCHK pieces of 16 bytes = eight frames each, in two halves of PF pieces per lane; one
     // v_perm_b32 per channel and dword pair pulls a channel's bytes (run_loop below).  Piece g holds a channel's bytes 8 g .. 8 g + 7.
-    const bool il = !SCR && a.il2 != 0;
+    const bool il = a.il2 != 0 && !coop;          // (the scratch flavour too: there it is what the fixed-order loop is used for)
     auto pad_addr = [&](int32_t L, uint32_t k) -> uint32_t { return L < 0 ? DUMMY + 4u * k : 4u * ((uint32_t)L + (uint32_t)L / (uint32_t)CS); };
     uint32_t wad[FLAT ? 1 : PF][4];
     if constexpr (!FLAT) {
@@ -768,23 +768,34 @@ __global__ __launch_bounds__(D2D_MX_THREADS) void d2d_fir_mx_kernel(Mfma2Args m)
         if (il) write_lds_t(C1{}, std::true_type{}); else write_lds(C1{});
         wave_sync2();
         // (one channel at a time, its samples put away before the other channel's chain starts: shorter live ranges)
-        {
-            int32_t o0[NS];
-            redo(0u, t, 0, o0);
-            if constexpr (SCR) store_scr(t, 0, o0); else put_samples(0, o0);
-        }
-        {
-            int32_t o1[NS];
-            redo(1u, t, 1, o1);
-            if constexpr (SCR) store_scr(t, 1, o1); else put_samples(1, o1);
-        }
-        if constexpr (!SCR) {
+        if constexpr (SCR) {
+            // the exact integers need no careful path: the chain, then every job of the epilogue at once
+            static_for<0, 2>([&](auto cc) {
+                constexpr uint32_t c = decltype(cc)::value;
+                v16f acc[G];
+                chain(c, acc, no_hook);
+                pin(acc);
+                Fast f;
+                fast_begin(f, t, c);
+                static_for<0, NJ>([&](auto jc) { fast_job(f, acc, jc); });
+                store_scr(t, c, f.res);
+            });
+        } else {
+            {
+                int32_t o0[NS];
+                redo(0u, t, 0, o0);
+                put_samples(0, o0);
+            }
+            {
+                int32_t o1[NS];
+                redo(1u, t, 1, o1);
+                put_samples(1, o1);
+            }
             wave_sync2();
             store_tile(t);
         }
     };
-    if constexpr (SCR) run_loop(0u, nwt, std::false_type{}, std::false_type{});
-    else if (fast_layout || il) {
+    if (SCR ? il : (fast_layout || il)) {
         // the tiles [t_lo, t_hi) lie inside the call's full blocks: the loop without the gather path; the few around them one by one
         const int64_t T = (int64_t)TILE * MB;
         auto is_fast = [&](uint32_t w) { const int32_t ab = tile_ab16(w); return ab >= 0 && (uint32_t)ab + 16u * NCHK <= full_bytes; };
@@ -799,7 +810,7 @@ __global__ __launch_bounds__(D2D_MX_THREADS) void d2d_fir_mx_kernel(Mfma2Args m)
         }
         { const uint32_t nfull = j0.nout / (uint32_t)TILE; if (t_hi > nfull) t_hi = nfull > t_lo ? nfull : t_lo; }     // whole tiles only
         if (il) run_loop(t_lo, t_hi, std::true_type{}, std::true_type{});
-        else run_loop(t_lo, t_hi, std::true_type{}, std::false_type{});
+        else if constexpr (!SCR) run_loop(t_lo, t_hi, std::true_type{}, std::false_type{});
         const uint32_t n_edge = t_lo + (nwt - t_hi);
         for (uint32_t i = wv; i < n_edge; i += wstride) slow_tile(i < t_lo ? i : t_hi + (i - t_lo));
     } else {
