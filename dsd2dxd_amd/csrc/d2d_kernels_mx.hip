@@ -846,28 +846,47 @@ __global__ __launch_bounds__(D2D_MX_THREADS) void d2d_fir_mx_kernel(Mfma2Args m)
 #ifndef D2D_MX_PART
 #define D2D_MX_PART 0
 #endif
-#ifdef D2D_MX_DEV
+// one shape per object (Makefile: -DD2D_MX_PART=0..7), so that a clean build spreads over the cores; part 0 also holds the table
+// builder and the dispatcher
 #define D2D_MX_SHAPES_0(X) X(4, 560)
+#ifdef D2D_MX_DEV
 #define D2D_MX_SHAPES_1(X)
 #define D2D_MX_SHAPES_2(X)
 #define D2D_MX_SHAPES_3(X)
+#define D2D_MX_SHAPES_4(X)
+#define D2D_MX_SHAPES_5(X)
+#define D2D_MX_SHAPES_6(X)
+#define D2D_MX_SHAPES_7(X)
 #else
-#define D2D_MX_SHAPES_0(X) X(4, 560) X(4, 352)
-#define D2D_MX_SHAPES_1(X) X(4, 384) X(4, 512)
-#define D2D_MX_SHAPES_2(X) X(8, 688) X(8, 1024)
-#define D2D_MX_SHAPES_3(X) X(8, 1104) X(16, 2192)
+#define D2D_MX_SHAPES_1(X) X(4, 352)
+#define D2D_MX_SHAPES_2(X) X(4, 384)
+#define D2D_MX_SHAPES_3(X) X(4, 512)
+#define D2D_MX_SHAPES_4(X) X(8, 688)
+#define D2D_MX_SHAPES_5(X) X(8, 1024)
+#define D2D_MX_SHAPES_6(X) X(8, 1104)
+#define D2D_MX_SHAPES_7(X) X(16, 2192)
 #endif
-#define D2D_MX_SHAPES(X) D2D_MX_SHAPES_0(X) D2D_MX_SHAPES_1(X) D2D_MX_SHAPES_2(X) D2D_MX_SHAPES_3(X)
-// the gain flavours (KIND + 4: frames at another level than 0 dB) of the shapes that serve frames (not the cascade's A filters), in two
-// more objects (Makefile: -DD2D_MX_GPART=0 / 1, D2D_MX_PART=99)
-#define D2D_MX_GSHAPES_0(X) X(4, 560) X(4, 384) X(4, 512)
+#define D2D_MX_SHAPES(X) D2D_MX_SHAPES_0(X) D2D_MX_SHAPES_1(X) D2D_MX_SHAPES_2(X) D2D_MX_SHAPES_3(X) D2D_MX_SHAPES_4(X) D2D_MX_SHAPES_5(X) D2D_MX_SHAPES_6(X) D2D_MX_SHAPES_7(X)
+// the f64 flavours (KIND + 4: other levels, 20-bit, the float dither) of the shapes that serve frames (not the cascade's A filters), one
+// object each too (Makefile: -DD2D_MX_GPART=0..5, D2D_MX_PART=99)
+#define D2D_MX_GSHAPES_0(X) X(4, 560)
 #ifdef D2D_MX_DEV
 #define D2D_MX_GSHAPES_1(X)
+#define D2D_MX_GSHAPES_2(X)
+#define D2D_MX_GSHAPES_3(X)
+#define D2D_MX_GSHAPES_4(X)
+#define D2D_MX_GSHAPES_5(X)
 #else
-#define D2D_MX_GSHAPES_1(X) X(8, 1024) X(8, 1104) X(16, 2192)
+#define D2D_MX_GSHAPES_1(X) X(4, 384)
+#define D2D_MX_GSHAPES_2(X) X(4, 512)
+#define D2D_MX_GSHAPES_3(X) X(8, 1024)
+#define D2D_MX_GSHAPES_4(X) X(8, 1104)
+#define D2D_MX_GSHAPES_5(X) X(16, 2192)
 #endif
-hipError_t launch_fir_mx_gain0(Mfma2Args& m, int MB, int NT, uint32_t max_nout, uint32_t nrows, hipStream_t s);
-hipError_t launch_fir_mx_gain1(Mfma2Args& m, int MB, int NT, uint32_t max_nout, uint32_t nrows, hipStream_t s);
+#define D2D_MX_GSHAPES(X) D2D_MX_GSHAPES_0(X) D2D_MX_GSHAPES_1(X) D2D_MX_GSHAPES_2(X) D2D_MX_GSHAPES_3(X) D2D_MX_GSHAPES_4(X) D2D_MX_GSHAPES_5(X)
+#define D2D_MX_DECL(n) hipError_t launch_fir_mx_part##n(Mfma2Args& m, int MB, int NT, uint32_t max_nout, uint32_t nrows, hipStream_t s); \
+                       hipError_t launch_fir_mx_gain##n(Mfma2Args& m, int MB, int NT, uint32_t max_nout, uint32_t nrows, hipStream_t s);
+D2D_MX_DECL(0) D2D_MX_DECL(1) D2D_MX_DECL(2) D2D_MX_DECL(3) D2D_MX_DECL(4) D2D_MX_DECL(5) D2D_MX_DECL(6) D2D_MX_DECL(7)
 
 #if D2D_MX_PART == 0
 bool mx_supported(int MB, int NT) {
@@ -878,7 +897,7 @@ bool mx_supported(int MB, int NT) {
 }
 bool mx_gain_supported(int MB, int NT) {
 #define X(mb, nt) if (MB == mb && NT == nt) return true;
-    D2D_MX_GSHAPES_0(X) D2D_MX_GSHAPES_1(X)
+    D2D_MX_GSHAPES(X)
 #undef X
     return false;
 }
@@ -1041,38 +1060,45 @@ static hipError_t launch_mx_t(Mfma2Args& m, uint32_t max_nout, uint32_t nrows, h
         if (m.dkind == 2) return launch_mx_t<mb, nt, G, 6, 3>(m, max_nout, nrows, s);                               \
         return launch_mx_t<mb, nt, G, 4, 3>(m, max_nout, nrows, s);                                                 \
     }
+#define D2D_MX_GPART_FN(n, shapes)                                                                                 \
+    hipError_t launch_fir_mx_gain##n(Mfma2Args& m, int MB, int NT, uint32_t max_nout, uint32_t nrows, hipStream_t s) { \
+        shapes(D2D_MX_GLAUNCH)                                                                                     \
+        return hipErrorInvalidValue;                                                                               \
+    }
 #if D2D_MX_GPART == 0
-hipError_t launch_fir_mx_gain0(Mfma2Args& m, int MB, int NT, uint32_t max_nout, uint32_t nrows, hipStream_t s) {
-    D2D_MX_GSHAPES_0(D2D_MX_GLAUNCH)
-    return hipErrorInvalidValue;
-}
+D2D_MX_GPART_FN(0, D2D_MX_GSHAPES_0)
+#elif D2D_MX_GPART == 1
+D2D_MX_GPART_FN(1, D2D_MX_GSHAPES_1)
+#elif D2D_MX_GPART == 2
+D2D_MX_GPART_FN(2, D2D_MX_GSHAPES_2)
+#elif D2D_MX_GPART == 3
+D2D_MX_GPART_FN(3, D2D_MX_GSHAPES_3)
+#elif D2D_MX_GPART == 4
+D2D_MX_GPART_FN(4, D2D_MX_GSHAPES_4)
 #else
-hipError_t launch_fir_mx_gain1(Mfma2Args& m, int MB, int NT, uint32_t max_nout, uint32_t nrows, hipStream_t s) {
-    D2D_MX_GSHAPES_1(D2D_MX_GLAUNCH)
-    return hipErrorInvalidValue;
-}
+D2D_MX_GPART_FN(5, D2D_MX_GSHAPES_5)
 #endif
 #elif D2D_MX_PART == 0
 D2D_MX_PART_FN(0, D2D_MX_SHAPES_0)
-hipError_t launch_fir_mx_part1(Mfma2Args& m, int MB, int NT, uint32_t max_nout, uint32_t nrows, hipStream_t s);
-hipError_t launch_fir_mx_part2(Mfma2Args& m, int MB, int NT, uint32_t max_nout, uint32_t nrows, hipStream_t s);
-hipError_t launch_fir_mx_part3(Mfma2Args& m, int MB, int NT, uint32_t max_nout, uint32_t nrows, hipStream_t s);
 hipError_t launch_fir_mx(Mfma2Args& m, int MB, int NT, uint32_t max_nout, uint32_t nrows, hipStream_t s) {
-    if (m.gainq && !m.f.to_scratch) return MB == 4 ? launch_fir_mx_gain0(m, MB, NT, max_nout, nrows, s) : launch_fir_mx_gain1(m, MB, NT, max_nout, nrows, s);
-#define X(mb, nt) if (MB == mb && NT == nt) return launch_fir_mx_part0(m, MB, NT, max_nout, nrows, s);
-    D2D_MX_SHAPES_0(X)
-#undef X
+#define D2D_MX_ROUTE(list, fn) { auto route = [&]() -> int { list(X) return 0; }; if (route()) return fn(m, MB, NT, max_nout, nrows, s); }
+#define X(mb, nt) if (MB == mb && NT == nt) return 1;
+    if (m.gainq && !m.f.to_scratch) {
+        D2D_MX_ROUTE(D2D_MX_GSHAPES_0, launch_fir_mx_gain0)
 #ifndef D2D_MX_DEV
-#define X(mb, nt) if (MB == mb && NT == nt) return launch_fir_mx_part1(m, MB, NT, max_nout, nrows, s);
-    D2D_MX_SHAPES_1(X)
-#undef X
-#define X(mb, nt) if (MB == mb && NT == nt) return launch_fir_mx_part2(m, MB, NT, max_nout, nrows, s);
-    D2D_MX_SHAPES_2(X)
-#undef X
-#define X(mb, nt) if (MB == mb && NT == nt) return launch_fir_mx_part3(m, MB, NT, max_nout, nrows, s);
-    D2D_MX_SHAPES_3(X)
-#undef X
+        D2D_MX_ROUTE(D2D_MX_GSHAPES_1, launch_fir_mx_gain1) D2D_MX_ROUTE(D2D_MX_GSHAPES_2, launch_fir_mx_gain2) D2D_MX_ROUTE(D2D_MX_GSHAPES_3, launch_fir_mx_gain3)
+        D2D_MX_ROUTE(D2D_MX_GSHAPES_4, launch_fir_mx_gain4) D2D_MX_ROUTE(D2D_MX_GSHAPES_5, launch_fir_mx_gain5)
 #endif
+        return hipErrorInvalidValue;
+    }
+    D2D_MX_ROUTE(D2D_MX_SHAPES_0, launch_fir_mx_part0)
+#ifndef D2D_MX_DEV
+    D2D_MX_ROUTE(D2D_MX_SHAPES_1, launch_fir_mx_part1) D2D_MX_ROUTE(D2D_MX_SHAPES_2, launch_fir_mx_part2) D2D_MX_ROUTE(D2D_MX_SHAPES_3, launch_fir_mx_part3)
+    D2D_MX_ROUTE(D2D_MX_SHAPES_4, launch_fir_mx_part4) D2D_MX_ROUTE(D2D_MX_SHAPES_5, launch_fir_mx_part5) D2D_MX_ROUTE(D2D_MX_SHAPES_6, launch_fir_mx_part6)
+    D2D_MX_ROUTE(D2D_MX_SHAPES_7, launch_fir_mx_part7)
+#endif
+#undef X
+#undef D2D_MX_ROUTE
     return hipErrorInvalidValue;
 }
 int mx_groups(int MB) { return mx_g(MB); }
@@ -1089,8 +1115,16 @@ void mx_debug_stamps(unsigned long long out[8]) { for (int i = 0; i < 8; ++i) ou
 D2D_MX_PART_FN(1, D2D_MX_SHAPES_1)
 #elif D2D_MX_PART == 2
 D2D_MX_PART_FN(2, D2D_MX_SHAPES_2)
-#else
+#elif D2D_MX_PART == 3
 D2D_MX_PART_FN(3, D2D_MX_SHAPES_3)
+#elif D2D_MX_PART == 4
+D2D_MX_PART_FN(4, D2D_MX_SHAPES_4)
+#elif D2D_MX_PART == 5
+D2D_MX_PART_FN(5, D2D_MX_SHAPES_5)
+#elif D2D_MX_PART == 6
+D2D_MX_PART_FN(6, D2D_MX_SHAPES_6)
+#else
+D2D_MX_PART_FN(7, D2D_MX_SHAPES_7)
 #endif
 
 }  // namespace d2d
