@@ -22,6 +22,7 @@
 #include "d2d_launch.h"
 #include "d2d_mfma.h"
 #include "d2d_mx.h"
+#include "d2d_px.h"
 
 using namespace d2d;
 
@@ -96,6 +97,10 @@ struct d2d_engine {
     d2d_filter_def lo_def{};
     void* d_fir_tables_lo = nullptr;
     int mfma_pipe_lo = 0;
+    // DSD64 / DSD128 -> 48k multiples: one polyphase pass over the bits (d2d_kernels_px.hip); fc.fir / fc.resamp only count frames then
+    const d2d_poly_def* poly = nullptr;
+    bool poly_plain = false;              // ... through the bit-by-bit kernel (D2D_KERNEL_LUT engines)
+    bool cascade() const { return fc.resamp && !poly; }      // the two-kernel 48k path (DSD256 / DSD512 input)
     bool il2 = false;                     // byte-interleaved stereo input de-interleaved inside the pipelined frame kernels' staging (FirArgs::il2)
     uint8_t* d_out = nullptr; size_t d_out_cap = 0;
 
@@ -194,7 +199,7 @@ static void fir_args_static(const d2d_engine* e, FirArgs& a, bool lo_pass = fals
     a.Wb = (uint32_t)e->Wb;
     a.ntab = (uint32_t)e->lut.ntab; a.pad = (uint32_t)e->lut.pad; a.nq = (uint32_t)e->lut.nq;
     a.B = e->B; a.keep = e->keep;
-    a.to_scratch = (e->fc.resamp || e->noise_shape || e->fine) ? 1u : 0u;
+    a.to_scratch = (e->cascade() || e->noise_shape || e->fine) ? 1u : 0u;
     a.ksteps = (uint32_t)e->mfma.ksteps;
     a.scale_bits = e->S;
     a.in_channels = e->Cin;
@@ -262,6 +267,7 @@ int d2d_create(const d2d_params* params, uint32_t n_files, d2d_engine** out) {
     }
     e->epi.sample_bytes = (uint32_t)sample_bytes_of(e->p.bit_depth);
     e->epi.channels = e->C;
+    e->poly = e->fc.poly;
     e->lut = lut_layout(e->Mb, e->Wb);
     e->mfma = mfma_layout(e->M, e->N);
     uint32_t mfma_waves = 0;
@@ -284,10 +290,20 @@ int d2d_create(const d2d_params* params, uint32_t n_files, d2d_engine** out) {
     // AUTO: the matrix-core kernel whenever a full 4-wave block fits in LDS (it works per channel pair,
     // so only an extremely long window can fail this; then the LUT kernel)
     e->kernel = e->p.kernel == D2D_KERNEL_AUTO ? (mfma_ok && mfma_waves >= 4 ? D2D_KERNEL_MFMA : D2D_KERNEL_LUT) : e->p.kernel;
+    if (e->poly) {
+        // the matrix-core form wherever a kernel is compiled for the table and its digit sums are exact in f32 (all six shipped tables)
+        const bool px_ok = px_supported(*e->poly) && px_exact(*e->poly);
+        e->kernel = e->p.kernel == D2D_KERNEL_AUTO ? (px_ok ? D2D_KERNEL_MFMA : D2D_KERNEL_LUT) : e->p.kernel;
+        mfma_ok = px_ok;
+        e->poly_plain = e->kernel == D2D_KERNEL_LUT;
+        e->mfma_v2 = false;
+    }
     if (e->kernel == D2D_KERNEL_MFMA && !mfma_ok) {
         g_create_error = "MFMA kernel does not support this configuration (decimation or LDS budget)"; delete e; return D2D_ERR_PARAM;
     }
     e->keep = (uint32_t)(e->Wb + e->Mb);
+    // (direct polyphase: the oldest bit an output of the next call can need lies NP - D + M bits before the call's first byte)
+    if (e->poly) e->keep = std::max<uint32_t>(e->keep, (uint32_t)((e->poly->NP - e->poly->D + e->M + 7) / 8 + 2));
     e->keep = (e->keep + 15u) & ~15u;
 
     // ---- device side: fail loudly when there is no GPU ----
@@ -307,7 +323,18 @@ int d2d_create(const d2d_params* params, uint32_t n_files, d2d_engine** out) {
     CK(hipSetDevice(e->p.device));
     CK(hipStreamCreateWithFlags(&e->own_stream, hipStreamNonBlocking));
     const bool msb = e->p.endianness == D2D_MSB_FIRST;
-    if (e->kernel == D2D_KERNEL_LUT) {
+    if (e->poly) {
+        if (e->poly_plain) {
+            e->fir_table_bytes = (size_t)e->poly->Lp * e->poly->NP * sizeof(int32_t);
+            CK(hipMalloc(&e->d_fir_tables, e->fir_table_bytes));
+            CK(hipMemcpy(e->d_fir_tables, e->poly->q, e->fir_table_bytes, hipMemcpyHostToDevice));
+        } else {
+            const std::vector<int8_t> t = build_px_tables(*e->poly);
+            e->fir_table_bytes = t.size();
+            CK(hipMalloc(&e->d_fir_tables, e->fir_table_bytes));
+            CK(hipMemcpy(e->d_fir_tables, t.data(), e->fir_table_bytes, hipMemcpyHostToDevice));
+        }
+    } else if (e->kernel == D2D_KERNEL_LUT) {
         std::vector<double> t = build_lut_tables(f, e->Mb, msb);
         e->fir_table_bytes = t.size() * sizeof(double);
         CK(hipMalloc(&e->d_fir_tables, e->fir_table_bytes));
@@ -354,7 +381,7 @@ int d2d_create(const d2d_params* params, uint32_t n_files, d2d_engine** out) {
         e->scratch_stride = 4096;
         CK(hipMalloc((void**)&e->d_scratch, sizeof(int32_t) * e->scratch_stride * e->nstreams * 2));
     }
-    if (e->fc.resamp) {
+    if (e->cascade()) {
         const std::vector<int8_t> rt = build_resamp2_table(*e->fc.resamp);
         e->resamp_bytes = rt.size();
         CK(hipMalloc((void**)&e->d_resamp, e->resamp_bytes));
@@ -364,7 +391,7 @@ int d2d_create(const d2d_params* params, uint32_t n_files, d2d_engine** out) {
         CK(hipMalloc((void**)&e->d_scratch, sizeof(int32_t) * e->scratch_stride * e->nstreams));
     }
     if (e->noise_shape) {
-        if (!e->fc.resamp) {
+        if (!e->cascade()) {
             e->scratch_stride = 4096;
             CK(hipMalloc((void**)&e->d_scratch, sizeof(int32_t) * e->scratch_stride * e->nstreams));
         }
@@ -451,11 +478,11 @@ int d2d_translate_batch_device(d2d_engine* e, d2d_file_io* io, uint32_t n_files,
         max_frames = std::max<uint32_t>(max_frames, (uint32_t)frames);
         io[f].frames_out = (size_t)frames;
     }
-    if (e->fc.resamp || e->noise_shape || e->fine) {
-        int rc = grow_scratch(e, (size_t)e->xs_hist + max_nx, s);
+    if (e->cascade() || e->noise_shape || e->fine) {
+        int rc = grow_scratch(e, (size_t)e->xs_hist + (e->poly ? max_frames : max_nx), s);
         if (rc) return rc;
     }
-    if (e->noise_shape && e->fc.resamp && (size_t)max_frames + 8 > e->ys_stride) {
+    if (e->noise_shape && e->cascade() && (size_t)max_frames + 8 > e->ys_stride) {
         HIPCHK(e, hipStreamSynchronize(s));
         if (e->d_ys) HIPCHK(e, hipFree(e->d_ys));
         e->d_ys = nullptr; e->ys_stride = 0;
@@ -498,6 +525,7 @@ int d2d_translate_batch_device(d2d_engine* e, d2d_file_io* io, uint32_t n_files,
             j.e0 = (int64_t)((st.nfir + 1) * (uint64_t)e->Mb) - (int64_t)st.pos;
             j.n0 = st.nfir;
             j.nout = (uint32_t)(nfir1[f] - st.nfir);
+            if (e->poly) { j.e0 = (int64_t)st.pos; j.n0 = st.nres; j.nout = (uint32_t)(nres1[f] - st.nres); }   // (PxArgs::jobs)
             j.ch = e->c0 + c;
             j.och = c;
             j.m0 = st.nres;
@@ -542,7 +570,15 @@ int d2d_translate_batch_device(d2d_engine* e, d2d_file_io* io, uint32_t n_files,
         pe = &e->prof_pool[e->prof_used++];
         HIPCHK(e, hipEventRecord(pe->first, s));
     }
-    if (max_nx) {
+    if (e->poly) {
+        PxArgs px{};
+        px.jobs = e->d_jobs; px.tables = e->d_fir_tables;
+        px.in_channels = e->Cin; px.B = e->B; px.keep = e->keep; px.msb = e->p.endianness == D2D_MSB_FIRST ? 1u : 0u;
+        px.to_scratch = e->noise_shape ? 1u : 0u;
+        px.epi = e->epi;
+        if (e->poly_plain) HIPCHK(e, launch_poly_plain(px, *e->poly, max_frames, e->nstreams, s));
+        else HIPCHK(e, launch_fir_px(px, *e->poly, max_frames, n_files, s));
+    } else if (max_nx) {
         if (e->kernel == D2D_KERNEL_LUT) {
             const uint32_t per_tile = lut_outputs_per_tile(e->Mb);
             HIPCHK(e, launch_fir_lut(a, e->Mb, (max_nx + per_tile - 1) / per_tile, e->nstreams, s));
@@ -551,7 +587,7 @@ int d2d_translate_batch_device(d2d_engine* e, d2d_file_io* io, uint32_t n_files,
             else HIPCHK(e, launch_fir_mfma(a, e->mfma, max_nx, e->nstreams, s));
         }
     }
-    if (max_nx && d2d_last_launched_kernel) e->launched = d2d_last_launched_kernel;
+    if ((e->poly ? max_frames : max_nx) && d2d_last_launched_kernel) e->launched = d2d_last_launched_kernel;
     if (e->fine && max_nx) {
         // second pass: the residual taps, into the second half of the scratch
         FirArgs al{};
@@ -571,7 +607,7 @@ int d2d_translate_batch_device(d2d_engine* e, d2d_file_io* io, uint32_t n_files,
         const int64_t lo_bias = e->kernel == D2D_KERNEL_LUT ? 0 : ((int64_t)1 << e->S);
         HIPCHK(e, launch_fine_combine(e->d_jobs, e->nstreams, max_nx, (size_t)e->nstreams * e->scratch_stride, lo_bias, e->S + 8, e->epi, s));
     }
-    if (e->fc.resamp) {
+    if (e->cascade()) {
         Rs2Args r{};
         r.jobs = e->d_jobs; r.tables = reinterpret_cast<const uint8_t*>(e->d_resamp);
         r.S = e->S; r.epi = e->epi;
@@ -582,9 +618,20 @@ int d2d_translate_batch_device(d2d_engine* e, d2d_file_io* io, uint32_t n_files,
     if (e->noise_shape) {
         NoiseShapeArgs ns{};
         ns.jobs = e->d_jobs; ns.state = e->d_ns[e->ns_cur]; ns.state_next = e->d_ns[e->ns_cur ^ 1]; ns.dump = e->d_ns_dump;
-        ns.scale_bits = e->S; ns.nstreams = e->nstreams; ns.max_nout = e->fc.resamp ? max_frames : max_nx; ns.epi = e->epi;
-        if (e->fc.resamp) { ns.ys = e->d_ys; ns.ys_stride = (uint32_t)e->ys_stride; ns.res = 1; }
-        { static const char* noint = getenv("D2D_NO_INTQ"); FirArgs fa{}; fir_args_static(e, fa); ns.intq = (!noint && fa.sum_abs_q + (1ull << 24) < (1ull << 31)) ? 1u : 0u; }
+        ns.scale_bits = e->poly ? e->poly->S : e->S; ns.nstreams = e->nstreams; ns.max_nout = e->fc.resamp ? max_frames : max_nx; ns.epi = e->epi;
+        if (e->cascade()) { ns.ys = e->d_ys; ns.ys_stride = (uint32_t)e->ys_stride; ns.res = 1; }
+        {
+            static const char* noint = getenv("D2D_NO_INTQ");
+            uint64_t sa = 0;
+            if (e->poly) {
+                for (int ph = 0; ph < e->poly->Lp; ++ph) {
+                    uint64_t sp = 0;
+                    for (int j = 0; j < e->poly->NP; ++j) { const int64_t q = e->poly->q[(size_t)ph * e->poly->NP + j]; sp += (uint64_t)(q < 0 ? -q : q); }
+                    sa = std::max(sa, sp);
+                }
+            } else { FirArgs fa{}; fir_args_static(e, fa); sa = fa.sum_abs_q; }
+            ns.intq = (!noint && sa + (1ull << 24) < (1ull << 31)) ? 1u : 0u;
+        }
         // a stream whose call ends exactly on a segment boundary, or feeds nothing, writes no state: start the next buffer from the current one
         HIPCHK(e, hipMemcpyAsync(e->d_ns[e->ns_cur ^ 1], e->d_ns[e->ns_cur], sizeof(double) * 2 * e->nstreams, hipMemcpyDeviceToDevice, s));
         HIPCHK(e, launch_noise_shape(ns, s));
@@ -692,10 +739,10 @@ int d2d_translate_batch_host(d2d_engine* e, d2d_file_io* io, uint32_t n_files, s
         // one call for the whole batch: every file below the per-call limit, and the cascade's / noise shaper's scratch for all of
         // it at once (4 B per stage-A sample, 8 more per output where the two combine) within half of the free device memory
         bool direct = max_L < (1ull << 31);
-        if (direct && (e->fc.resamp || e->noise_shape)) {
+        if (direct && (e->cascade() || e->noise_shape)) {
             size_t free_b = 0, total_b = 0;
             HIPCHK(e, hipMemGetInfo(&free_b, &total_b));
-            const double per_stream = (double)max_L / (double)e->Mb * (e->fc.resamp && e->noise_shape ? 12.0 : 4.0);
+            const double per_stream = (double)max_L / (double)e->Mb * (e->cascade() && e->noise_shape ? 12.0 : 4.0);
             direct = per_stream * (double)e->nstreams < 0.5 * (double)free_b;
         }
         for (uint32_t f = 0; f < n_files && direct; ++f) {
@@ -930,7 +977,8 @@ static TableBlobHeader make_header(const d2d_engine* e) {
     TableBlobHeader h{};
     h.magic = 0x54443244u; h.abi = D2D_ABI_VERSION; h.kernel = e->kernel; h.endianness = e->p.endianness;
     h.ntaps = (uint32_t)e->N; h.M = (uint32_t)e->M; h.scale_bits = (uint32_t)e->S; h.filter_type = (uint32_t)e->fc.fir->type;
-    h.table_variant = e->kernel == D2D_KERNEL_MFMA && e->mfma_v2 ? (e->mfma_pipe ? (uint32_t)e->mfma_pipe : 2u) : 0u;
+    h.table_variant = e->poly ? (e->poly_plain ? 7u : 6u) : e->kernel == D2D_KERNEL_MFMA && e->mfma_v2 ? (e->mfma_pipe ? (uint32_t)e->mfma_pipe : 2u) : 0u;
+    if (e->poly) { h.ntaps = (uint32_t)e->poly->NP; h.M = (uint32_t)e->poly->Mp; h.scale_bits = (uint32_t)e->poly->S; h.filter_type = (uint32_t)'P'; }
     h.fir_bytes = e->fir_table_bytes; h.resamp_bytes = e->resamp_bytes;
     return h;
 }
@@ -975,8 +1023,12 @@ int d2d_get_info(const d2d_engine* e, d2d_info* out) {
     memset(out, 0, sizeof(*out));
     out->decimation = (uint32_t)e->M; out->ntaps = (uint32_t)e->N; out->scale_bits = (uint32_t)e->S;
     if (e->fc.resamp) { out->resamp_L = e->fc.resamp->L; out->resamp_M = e->fc.resamp->Mdn; out->resamp_P = e->fc.resamp->P; }
+    if (e->poly) {      // one polyphase filter: Lp outputs per Mp bits, NP taps per phase
+        out->decimation = 0; out->ntaps = (uint32_t)e->poly->NP; out->scale_bits = (uint32_t)e->poly->S;
+        out->resamp_L = (uint32_t)e->poly->Lp; out->resamp_M = (uint32_t)e->poly->Mp; out->resamp_P = (uint32_t)e->poly->NP;
+    }
     out->kernel = e->kernel; out->abi_version = D2D_ABI_VERSION;
-    strncpy(out->filter_name, e->fc.fir->name, sizeof(out->filter_name) - 1);
+    strncpy(out->filter_name, e->poly ? e->poly->name : e->fc.fir->name, sizeof(out->filter_name) - 1);
     return D2D_OK;
 }
 
@@ -988,6 +1040,15 @@ void d2d_debug_stamps3(unsigned long long* out8) { hipDeviceSynchronize(); mfma3
 const char* d2d_kernel_name(const d2d_engine* e) {
     if (!e) return "";
     if (!e->launched.empty()) return e->launched.c_str();      // what the last call launched; before the first call: what the dispatch will choose
+    if (e->poly) {
+        if (e->poly_plain) return "d2d_poly_plain_kernel";
+        d2d_engine* m = const_cast<d2d_engine*>(e);
+        const bool intq = e->epi.gain == 1.0 && (e->epi.bits == 24 || e->epi.bits == 16) && e->epi.dither != 'F';
+        const int kind = e->noise_shape ? 4 : !intq ? 3 : e->epi.dither == 'T' ? 1 : e->epi.dither == 'R' ? 2 : 0;
+        m->kname = "d2d_fir_px_kernel<" + std::to_string(e->poly->Lp) + ", " + std::to_string(e->poly->Mp) + ", " + std::to_string(e->poly->NP) + ", " +
+                   std::to_string(px_groups(*e->poly)) + ", " + std::to_string(kind) + ">";
+        return m->kname.c_str();
+    }
     if (e->kernel == D2D_KERNEL_MFMA && e->mfma_v2) {
         d2d_engine* m = const_cast<d2d_engine*>(e);
         if (e->mfma_pipe == 5) {

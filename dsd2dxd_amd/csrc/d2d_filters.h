@@ -20,6 +20,9 @@ namespace d2d {
 struct FilterChoice {
     const d2d_filter_def* fir = nullptr;     // integer decimator (the only stage for 44.1k multiples)
     const d2d_resamp_def* resamp = nullptr;  // stage B for 48k multiples, else null
+    // DSD64 / DSD128 -> 48k multiples: the two stages composed into ONE polyphase filter on the bits (d2d_kernels_px.hip).  `fir` and
+    // `resamp` then only say how many frames a call yields (an output exists as soon as the two-stage form would have produced it).
+    const d2d_poly_def* poly = nullptr;
 };
 
 inline int choose_filters(const d2d_params& p, FilterChoice& out, std::string& err) {
@@ -51,6 +54,8 @@ inline int choose_filters(const d2d_params& p, FilterChoice& out, std::string& e
         type = 'A';
         for (int i = 0; i < D2D_NUM_RESAMPLERS; ++i)
             if ((uint32_t)D2D_RESAMPLERS[i].out_rate == o) out.resamp = &D2D_RESAMPLERS[i];
+        for (int i = 0; i < D2D_NUM_POLYS; ++i)
+            if ((uint32_t)D2D_POLYS[i].out_rate == o && (uint32_t)D2D_POLYS[i].dsd_rate == p.dsd_rate) out.poly = &D2D_POLYS[i];
     } else {
         err = "Invalid output rate";
         return D2D_ERR_RATE;

@@ -45,6 +45,10 @@ struct orc_ctx {
     /* streaming path (orc_translate_stream): integer byte tables in the stream's own bit order, buffers kept between calls */
     int32_t* ilut;    /* Wb x 256 */
     uint8_t* sbuf; size_t sbuf_cap;
+    /* DSD64 / DSD128 -> 96 / 192 / 384 kHz: the cascade composed into one polyphase filter on the bits (f and r then only count samples) */
+    const d2d_poly_def* poly;
+    int cascade_mode; /* orc_use_cascade: the two-stage definition these rates had before (study mode) */
+    double* taps_f64; /* orc_set_half_taps on a cascade context: stage A's f64 taps (study mode) */
     int fine;         /* orc_use_fine_taps: the taps are the 32-bit grid's */
     int rs_f64;       /* orc_use_f64_resamp_coef: stage B with the design's f64 coefficients (what the 2^-28 grid costs) */
 };
@@ -82,9 +86,9 @@ uint32_t orc_rng(uint64_t seed, uint32_t channel, uint64_t n) {
 
 /* Which (filter, dsd rate, output rate) combinations exist: src/main.rs:62-67,85-92;
  * README.md:129-134,146-152; test_all_44k_mults.sh, test_all_48k_mults.sh. */
-static int select_filters(const orc_params* p, const d2d_filter_def** f, const d2d_resamp_def** r,
+static int select_filters(const orc_params* p, const d2d_filter_def** f, const d2d_resamp_def** r, const d2d_poly_def** pl,
                           const char** err) {
-    *f = NULL; *r = NULL;
+    *f = NULL; *r = NULL; *pl = NULL;
     if (p->dsd_rate != 1 && p->dsd_rate != 2 && p->dsd_rate != 4 && p->dsd_rate != 8) {
         *err = "Invalid DSD rate; must be 1, 2, 4 or 8"; return -1;
     }
@@ -107,6 +111,9 @@ static int select_filters(const orc_params* p, const d2d_filter_def** f, const d
         type = 'A';
         for (int i = 0; i < D2D_NUM_RESAMPLERS; ++i)
             if ((uint32_t)D2D_RESAMPLERS[i].out_rate == o) *r = &D2D_RESAMPLERS[i];
+        /* [own] DSD64 / DSD128 input: the two stages composed into ONE polyphase filter on the bits (filters/filter_tables.inc: D2D_POLYS) */
+        for (int i = 0; i < D2D_NUM_POLYS; ++i)
+            if ((uint32_t)D2D_POLYS[i].out_rate == o && (uint32_t)D2D_POLYS[i].dsd_rate == p->dsd_rate) *pl = &D2D_POLYS[i];
     } else { *err = "Invalid output rate"; return -2; }
     if (type != 'E' && type != 'X' && type != 'D' && type != 'C' && type != 'A') { *err = "Invalid filter type"; return -3; }
     for (int i = 0; i < D2D_NUM_FILTERS; ++i)
@@ -123,11 +130,11 @@ int orc_create(const orc_params* p, orc_ctx** out, const char** err) {
     if (p->dither != 'T' && p->dither != 'R' && p->dither != 'F' && p->dither != 'X' && p->dither != 'N') { *err = "Invalid dither type; must be T, R, F, or X"; return -6; } /* src/main.rs:176-180 */
     if (p->fmt > 1) { *err = "Invalid format; must be I (interleaved) or P (planar)"; return -7; }  /* src/main.rs:187-190 */
     if (p->fmt == 1 && p->block_size == 0) { *err = "Invalid block size"; return -8; }
-    const d2d_filter_def* f; const d2d_resamp_def* r;
-    int rc = select_filters(p, &f, &r, err);
+    const d2d_filter_def* f; const d2d_resamp_def* r; const d2d_poly_def* pl;
+    int rc = select_filters(p, &f, &r, &pl, err);
     if (rc) return rc;
     orc_ctx* c = (orc_ctx*)calloc(1, sizeof(*c));
-    c->p = *p; c->f = f; c->r = r;
+    c->p = *p; c->f = f; c->r = r; c->poly = pl;
     c->M = f->M; c->Mb = f->M / 8; c->N = f->ntaps; c->Wb = f->ntaps / 8; c->S = f->S;
     c->C = p->channels;
     c->B = p->fmt == 0 ? 1u : p->block_size;   /* README.md:9: block size 1 for interleaved */
@@ -151,6 +158,10 @@ int orc_create(const orc_params* p, orc_ctx** out, const char** err) {
             c->lut[i * 256 + v] = acc;
         }
     c->keep = (size_t)c->Wb + (size_t)c->Mb;
+    if (pl) {   /* the oldest bit an output of the next call can need lies NP - D + M bits before the call's first byte */
+        size_t k = (size_t)(pl->NP - pl->D + c->M + 7) / 8 + 2;
+        if (k > c->keep) c->keep = k;
+    }
     c->hist_raw = (uint8_t*)malloc(c->keep * c->C);
     memset(c->hist_raw, p->endianness ? IDLE_BYTE : bitrev8(IDLE_BYTE), c->keep * c->C);
     if (r) c->xhist = (double*)calloc((size_t)r->P * c->C, sizeof(double));
@@ -162,7 +173,7 @@ int orc_create(const orc_params* p, orc_ctx** out, const char** err) {
 
 void orc_destroy(orc_ctx* c) {
     if (!c) return;
-    free(c->taps); free(c->lut); free(c->hist_raw); free(c->xhist); free(c->peak); free(c->ns_err); free(c->ilut); free(c->sbuf); free(c);
+    free(c->taps_f64); free(c->taps); free(c->lut); free(c->hist_raw); free(c->xhist); free(c->peak); free(c->ns_err); free(c->ilut); free(c->sbuf); free(c);
 }
 
 size_t orc_frame_bytes(const orc_ctx* c) {
@@ -308,6 +319,34 @@ int orc_translate_f64(orc_ctx* c, const uint8_t* dsd, size_t L, void* pcm_out, s
             uint8_t cb = c->p.endianness ? raw[j] : bitrev8(raw[j]);  /* canonical = MSB first in time */
             canon[j] = cb; canon_rev[j] = bitrev8(cb);
         }
+        if (c->poly && !c->cascade_mode) {
+            /* a4 [own]: y[m] = sum_j c[rho][j] s[q + D - j],  Mp m = Lp q + rho,  c = Q * 2^-S: the exact integer sum Q s, converted once.
+             * An output exists as soon as the two-stage form of these rates would have produced it (nres counts ceil(n_x L / 147)); its
+             * newest bit q + D (D < 0) then lies inside the bytes fed so far. */
+            const d2d_poly_def* pl = c->poly;
+            const double yscale = ldexp(1.0, -pl->S);
+            for (size_t o = 0; o < nframes; ++o) {
+                const uint64_t m = c->nres + o;
+                const uint64_t t = m * (uint64_t)pl->Mp;
+                const int64_t q = (int64_t)(t / (uint64_t)pl->Lp); const int rho = (int)(t % (uint64_t)pl->Lp);
+                const int32_t* g = pl->q + (size_t)rho * (size_t)pl->NP;
+                /* bit b of the stream is bit b - 8 (pos - keep) of raw[] */
+                const int64_t b0 = q + pl->D - 8 * ((int64_t)c->pos - (int64_t)keep);
+                int64_t isum = 0;
+                for (int j = 0; j < pl->NP; ++j) {
+                    const int64_t b = b0 - j;
+                    const int bit = b >= 0 ? raw_bit(raw, (size_t)b, (int)c->p.endianness) : 0;   /* (never taken: keep covers the window) */
+                    isum += bit ? (int64_t)g[j] : -(int64_t)g[j];
+                }
+                const double acc = (double)isum * yscale;      /* exact: |isum| < 2^31 */
+                const double v = acc * c->gain;
+                const double a = fabs(v); if (a > c->peak[ch]) c->peak[ch] = a;
+                if (f64_out) f64_out[o * C + ch] = v;
+                if (pcm_out) emit_sample(c, acc, ch, m, (uint8_t*)pcm_out + o * fb + ch * sb);
+            }
+            memcpy(c->hist_raw + (size_t)ch * keep, raw + L, keep);
+            continue;
+        }
         /* raw[keep + j] is stream byte pos + j;  output n ends at stream byte (n+1)*Mb */
         double* xs = x + (c->r ? (size_t)c->r->P : 0);
         for (size_t i = 0; i < nx; ++i) {
@@ -339,7 +378,7 @@ int orc_translate_f64(orc_ctx* c, const uint8_t* dsd, size_t L, void* pcm_out, s
                 /* absolute index im -> xs[im - nfir]; history below */
                 const double* xp = xs + (ptrdiff_t)(im - c->nfir);
                 int64_t isum = 0;
-                for (int k = 0; k < P; ++k) isum += (int64_t)g[k] * (int64_t)(xp[-k] * xscale);   /* x * 2^S is an integer, exactly */
+                if (!c->rs_f64) for (int k = 0; k < P; ++k) isum += (int64_t)g[k] * (int64_t)(xp[-k] * xscale);   /* x * 2^S is an integer, exactly */
                 double acc = (double)isum * yscale;
                 if (c->rs_f64) {   /* study mode (orc_use_f64_resamp_coef): the design's own f64 coefficients, summed in f64 in this order */
                     const double* gd = c->r->coef + (size_t)phi * P;
@@ -487,9 +526,19 @@ int orc_use_f64_resamp_coef(orc_ctx* c) {
     return 0;
 }
 
+/* [own] study mode: DSD64 / DSD128 -> 96 / 192 / 384 kHz the way they were defined before the stages were composed (stage A to 352.8 kHz, stage B
+ * polyphase L/147, both on their integer grids); with orc_use_f64_resamp_coef and orc_set_half_taps on top it is the f64 design of that cascade,
+ * which tests/test_tap_grid.py measures the composed tables against. */
+int orc_use_cascade(orc_ctx* c) {
+    if (!c || !c->r) return -1;
+    if (c->pos) return -2;
+    c->cascade_mode = 1;
+    return 0;
+}
+
 int orc_set_half_taps(orc_ctx* c, const double* half, int n_half) {
     if (!c || !half || n_half != c->N / 2) return -1;
-    if (c->r) return -2;   /* stage B sums the exact stage-A integers: the f64-tap study mode is for the integer decimators only */
+    if (c->r && !(c->cascade_mode && c->rs_f64)) return -2;   /* stage B sums the exact stage-A integers: f64 taps only in the all-f64 study mode */
     for (int k = 0; k < n_half; ++k) {
         c->taps[c->N / 2 + k] = half[k];
         c->taps[c->N / 2 - 1 - k] = half[k];

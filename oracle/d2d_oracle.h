@@ -83,6 +83,9 @@ int    orc_set_half_taps(orc_ctx* c, const double* half, int n_half);
 int    orc_use_fine_taps(orc_ctx* c);
 /* study mode: stage B of the 48k cascade with the f64 coefficients the 2^-28 grid was rounded from (tests/test_tap_grid.py) */
 int    orc_use_f64_resamp_coef(orc_ctx* c);
+/* study mode: DSD64 / DSD128 -> 96 / 192 / 384 kHz through the two-stage cascade they were defined by before the stages were composed into
+ * one polyphase table (call before the first translate); with orc_use_f64_resamp_coef and then orc_set_half_taps: that cascade's f64 design */
+int    orc_use_cascade(orc_ctx* c);
 
 /* The dither generator, exposed so tests can pin it. */
 uint32_t orc_rng(uint64_t seed, uint32_t channel, uint64_t n);

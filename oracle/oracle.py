@@ -81,6 +81,7 @@ def _load(path):
     L.orc_set_half_taps.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
     L.orc_use_fine_taps.argtypes = [C.c_void_p]
     L.orc_use_f64_resamp_coef.argtypes = [C.c_void_p]
+    L.orc_use_cascade.argtypes = [C.c_void_p]
     L.orc_rng.argtypes = [C.c_uint64, C.c_uint32, C.c_uint64]
     L.orc_rng.restype = C.c_uint32
     _lib = L
@@ -135,6 +136,11 @@ class Oracle:
         """stage B of the 48k cascade with the design's f64 coefficients instead of the 2^-28 grid (a study mode)"""
         if lib().orc_use_f64_resamp_coef(self._h):
             raise OracleError("not a 48k-family context")
+
+    def use_cascade(self):
+        """DSD64 / DSD128 -> 48k multiples through the two-stage cascade of the earlier definition (a study mode)"""
+        if lib().orc_use_cascade(self._h):
+            raise OracleError("not a fresh 48k-family context")
 
     def set_half_taps(self, half):
         """replace the taps (2nd half, centre outward) -- e.g. by the designs' unquantised f64 taps"""

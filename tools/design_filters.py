@@ -163,6 +163,80 @@ def quantise_polyphase(poly):
     return out
 
 
+POLY_TRIM = 8      # direct 48k tables: leading / trailing taps that stay within this many grid units in every phase are dropped
+
+
+def stage_b_dense(out_rate, L, P, dens):
+    """Stage B's Kaiser design sampled `dens` times as densely: dens*N - (dens-1) taps whose every dens-th sample IS the frozen design
+    (same sinc, same window positions), normalised so that those samples sum to L."""
+    fi = 352800.0
+    fup = fi * L
+    fo = float(out_rate)
+    fp, fst = 0.227 * min(fo, fi), 0.55 * min(fo, fi)
+    beta = 0.1102 * (120.0 - 8.7)
+    N = P * L
+    g = sg.firwin(dens * N - (dens - 1), 0.5 * (fp + fst), window=("kaiser", beta), fs=fup * dens)
+    return g / g[::dens].sum() * L
+
+
+def compose_polyphase(dsd_rate, r, hA_half):
+    """The 48k cascade composed into ONE polyphase filter on the DSD bits (DSD64 / DSD128 input).
+
+    Stage A (hA, at the bit rate) and stage B (its prototype g at 352.8 kHz * L) are two LTI filters; without the sampling at 352.8 kHz
+    between them their cascade is the single filter p = g (*) upsample(hA) on the fine grid of Lp ticks per bit
+    (Lp / Mp = out_rate / bit rate in lowest terms), and output m is
+
+        y[m] = sum_j c[rho][j] * s[q + D - j],   Mp * m = Lp * q + rho,   c[rho][j] = p[Lp * j + rho] / MA
+
+    (the sampling between the stages only adds what stage A lets through around the multiples of 352.8 kHz -- its stop band, -150 dB --
+    folded onto stage B's stop band).  Where the fine grid is denser than stage B's own (DSD128 -> 96 kHz: 2x) the same Kaiser design is
+    sampled more densely.  Every phase is normalised to unity DC gain and rounded to the 24-bit dyadic grid of the decimators."""
+    MA = 8 * dsd_rate
+    out_rate, L, P = r["out_rate"], r["L"], r["P"]
+    from math import gcd
+    fbit = 2822400 * dsd_rate
+    gg = gcd(out_rate, fbit)
+    Lp, Mp = out_rate // gg, fbit // gg
+    dens = Lp * MA // L
+    assert dens * L == Lp * MA and dens >= 1
+    g = stage_b_dense(out_rate, L, P, dens)
+    frozen = np.array(r["coef"], dtype=np.float64).reshape(L, P).T.reshape(-1)        # g[k * L + phase]
+    assert np.abs(g[::dens] - frozen).max() < 1e-15, "the dense design must contain the frozen stage-B design"
+    g = np.concatenate([g, np.zeros(dens * L * P - len(g))])
+    hA = np.concatenate([hA_half[::-1], hA_half])
+    NA = len(hA)
+    up = np.zeros(Lp * (NA - 1) + 1)
+    up[::Lp] = hA
+    p = np.convolve(g, up)
+    NP = MA * P + NA - 1
+    assert len(p) == Lp * NP
+    c = p.reshape(NP, Lp).T.copy()                          # c[rho][j]
+    c /= c.sum(1)[:, None]
+    S = int(np.floor(np.log2((2 ** 23 - 2 ** 16) / np.abs(c).max())))
+    q0 = np.rint(c * 2.0 ** S).astype(np.int64)
+    keep = np.nonzero(np.abs(q0).max(0) > POLY_TRIM)[0]
+    lo, hi = int(keep[0]), int(keep[-1])
+    c = c[:, lo:hi + 1]
+    c = c / c.sum(1)[:, None]
+    q = np.zeros(c.shape, dtype=np.int64)
+    for ph in range(Lp):
+        qq = np.rint(c[ph] * 2.0 ** S).astype(np.int64)
+        resid = (1 << S) - int(qq.sum())
+        frac = c[ph] * 2.0 ** S - qq
+        order = np.argsort(-frac, kind="stable") if resid > 0 else np.argsort(frac, kind="stable")
+        assert abs(resid) < len(qq)
+        for i in range(abs(resid)):
+            qq[order[i]] += 1 if resid > 0 else -1
+        assert int(qq.sum()) == 1 << S
+        q[ph] = qq
+    assert np.abs(q).max() < 2 ** 23 - 2 ** 15 and int(np.abs(q).sum(1).max()) < 2 ** 31 - 2 ** 26
+    D = MA - 1 - lo                                          # newest bit of output m: q_m + D (never ahead of the cascade's newest bit)
+    assert D < 0
+    return dict(name=f"P_{dsd_rate}_{out_rate}", dsd_rate=dsd_rate, out_rate=out_rate, Lp=Lp, Mp=Mp, NP=int(c.shape[1]), D=int(D), S=S,
+                q=[int(v) for v in q.reshape(-1)], coef=[float(v) for v in c.reshape(-1)],
+                method=f"A_M{MA} (*) B_{out_rate} on {Lp} ticks per bit, 24-bit grid, taps within {POLY_TRIM} units dropped at both ends")
+
+
 def fmt_i32(q):
     return ", ".join(str(int(v)) for v in q)
 
@@ -180,7 +254,8 @@ def main():
             f64 = json.load(f)
         for fl in filters:
             fl["q32"] = [int(v) for v in quantise_fine([float.fromhex(x) for x in f64[fl["name"]]], fl["S"], fl["q"])]
-        write_tables(filters, resamplers, None)
+        polys = [compose_polyphase(rate, r, np.array([float.fromhex(x) for x in f64[f"A_M{8 * rate}"]])) for rate in (1, 2) for r in resamplers]
+        write_tables(filters, resamplers, None, polys)
         return
     filters = []   # dicts: name, type, M, N, S, q(list), method
 
@@ -240,10 +315,11 @@ def main():
                                method=f"kaiser 120dB pass {fp:.0f} stop {fst:.0f} Hz"))
         print(f"B_{out_rate} L={L} P={P} N={N}", file=sys.stderr)
 
-    write_tables(filters, resamplers, unquantised)
+    polys = [compose_polyphase(rate, r, np.array([float.fromhex(x) for x in unquantised[f"A_M{8 * rate}"]])) for rate in (1, 2) for r in resamplers]
+    write_tables(filters, resamplers, unquantised, polys)
 
 
-def write_tables(filters, resamplers, unquantised):
+def write_tables(filters, resamplers, unquantised, polys):
     os.makedirs(os.path.join(ROOT, "filters"), exist_ok=True)
     # test data only (oracle/, tests/): what the 24-bit tap grid costs against the designs' f64 taps
     if unquantised is not None:
@@ -252,7 +328,8 @@ def write_tables(filters, resamplers, unquantised):
     with open(os.path.join(ROOT, "filters", "filter_tables.json"), "w") as f:
         json.dump(dict(filters=filters,
                        resamplers=[{k: (v if k != "coef" else [x.hex() for x in v])
-                                    for k, v in r.items()} for r in resamplers]), f, indent=0)
+                                    for k, v in r.items()} for r in resamplers],
+                       polys=[{k: (v if k != "coef" else [x.hex() for x in v]) for k, v in pl.items()} for pl in polys]), f, indent=0)
 
     out = []
     out.append("/* GENERATED by tools/design_filters.py -- do not edit.\n"
@@ -261,6 +338,8 @@ def write_tables(filters, resamplers, unquantised):
                " * (as /root/reference/README.md:252 describes), sum(all taps) == 1 exactly.\n"
                " * Stage B of the 48k cascade: coefficient [phase][k] = q * 2^-T, every phase sums to 1 exactly\n"
                " * (coef = the f64 design they were rounded from, kept for tests).\n"
+               " * Direct 48k tables (DSD64 / DSD128 input): the cascade's two designs composed into one polyphase filter on the bits,\n"
+               " * y[m] = sum_j q[rho][j] 2^-S s[qm + D - j], Mp m = Lp qm + rho; every phase sums to 2^S exactly.\n"
                " * Shared DATA for the engine (dsd2dxd_amd/csrc) and the oracle (oracle/). */\n")
     out.append("#ifndef D2D_FILTER_TABLES_INC\n#define D2D_FILTER_TABLES_INC\n#include <stdint.h>\n")
     out.append("typedef struct { const char* name; char type; int M; int ntaps; int S; const int32_t* half; const int32_t* half32; } d2d_filter_def;\n")
@@ -281,7 +360,15 @@ def write_tables(filters, resamplers, unquantised):
     for i, r in enumerate(resamplers):
         out.append(f"  {{ \"{r['name']}\", {r['out_rate']}, {r['L']}, {r['Mdn']}, {r['P']}, d2d_rtab_{i}, {RESAMP_T}, d2d_rqtab_{i} }},\n")
     out.append("};\n")
-    out.append(f"enum {{ D2D_NUM_RESAMPLERS = {len(resamplers)} }};\n#endif\n")
+    out.append(f"enum {{ D2D_NUM_RESAMPLERS = {len(resamplers)} }};\n")
+    out.append("typedef struct { const char* name; int dsd_rate; int out_rate; int Lp; int Mp; int NP; int D; int S; const int32_t* q; } d2d_poly_def;\n")
+    for i, pl in enumerate(polys):
+        out.append(f"static const int32_t d2d_ptab_{i}[{len(pl['q'])}] = {{ {fmt_i32(pl['q'])} }};\n")
+    out.append(f"static const d2d_poly_def D2D_POLYS[{len(polys)}] = {{\n")
+    for i, pl in enumerate(polys):
+        out.append(f"  {{ \"{pl['name']}\", {pl['dsd_rate']}, {pl['out_rate']}, {pl['Lp']}, {pl['Mp']}, {pl['NP']}, {pl['D']}, {pl['S']}, d2d_ptab_{i} }},\n")
+    out.append("};\n")
+    out.append(f"enum {{ D2D_NUM_POLYS = {len(polys)} }};\n#endif\n")
     with open(os.path.join(ROOT, "filters", "filter_tables.inc"), "w") as f:
         f.write("".join(out))
 
