@@ -47,6 +47,9 @@ __device__ __forceinline__ uint32_t px_lsb_first(uint32_t w) { return __builtin_
 #ifndef D2D_PX_PART
 #define D2D_PX_PART 0
 #endif
+#ifndef D2D_PX_ABL
+#define D2D_PX_ABL 0        // compile-time ablation mask of A/B builds (tools/ab_build.sh px): 1 no chain, 2 no epilogue arithmetic, 4 no staging loads, 8 no stores
+#endif
 
 // KIND: 0 no dither, 1 triangular, 2 rectangular (unit gain, 16 / 24 bits: the all-integer requantiser); 3: every other format through the
 // f64 epilogue of d2d_device.h; 4: the exact integers to the scratch (noise-shaped dither)
@@ -57,6 +60,7 @@ __global__ __launch_bounds__(PX_THREADS) void d2d_fir_px_kernel(PxArgs a) {
     constexpr int NCHK = px_chunks(LP, MP, NP, G), PF = (NCHK + 63) / 64;
     constexpr uint32_t SB = (uint32_t)px_stream_bytes(LP, MP, NP, G);
     static_assert((5 * G) % LP == 0, "a column is a whole number of cycles");
+    constexpr uint32_t dbg = D2D_PX_ABL;
     extern __shared__ __align__(16) unsigned char smem[];
     const uint32_t tid = threadIdx.x, lane = tid & 63;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -106,44 +110,81 @@ __global__ __launch_bounds__(PX_THREADS) void d2d_fir_px_kernel(PxArgs a) {
     uint32_t vmax[2] = {0u, 0u};
     const uint32_t SBY = a.epi.sample_bytes, fb = SBY * C;
 
-    const uint32_t wstride = gridDim.x * a.nwaves;
-    for (uint32_t t = blockIdx.x * a.nwaves + wave; t < ntiles; t += wstride) {
-        const uint64_t mT = (T0 + t) * (uint32_t)TILE;                // first output of the tile: a multiple of LP
-        const int64_t br = (int64_t)(mT / (uint32_t)LP * (uint32_t)MP) + a.D - (NP - 1) - 8 * j0.e0;     // first bit of column 0's window, call-relative
-        const int32_t a0 = (int32_t)((br >> 3) & ~(int64_t)15);      // the staged image starts at this (16-aligned) byte of the call
-        const uint32_t obit = (uint32_t)(br - 8 * (int64_t)a0);      // 0 .. 127
-        const int64_t nl0 = (int64_t)(mT - m0);                       // the tile's first output, relative to the call's (may be negative)
-
-        // ---- staging: 16-byte chunks of every channel of the group, as they lie in the call's buffer ----
-        wave_sync2();
-        for (uint32_t c = 0; c < cwn; ++c) {
-            uint8_t* buf = wbase + c * SB;
-            const uint32_t chf = jobs[c].ch;
+    // a tile's staged image starts at the 16-aligned byte a0 of the call, its column 0 at bit `obit` of the image
+    auto tile_br = [&](uint32_t t) -> int64_t {          // first bit of column 0's window, call-relative
+        const uint64_t mT = (T0 + t) * (uint32_t)TILE;    // first output of the tile: a multiple of LP
+        return (int64_t)(mT / (uint32_t)LP * (uint32_t)MP) + a.D - (NP - 1) - 8 * j0.e0;
+    };
+    // staging: 16-byte chunks of every channel of the group, as they lie in the call's buffer, requested a whole tile ahead
+    u32x4 pf[2][PF];
+    const uint32_t chf[2] = {(uint32_t)__builtin_amdgcn_readfirstlane((int)jobs[0].ch), (uint32_t)__builtin_amdgcn_readfirstlane((int)jobs[cwn - 1].ch)};
+    // dither keys of the group's channels (uniform; read once: a load inside the tile loop would wait for the prefetch in front of it)
+    uint32_t rkeys[2], rsteps[2], rlo0s[2];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        const StreamJob* jc = jobs + ((uint32_t)c < cwn ? c : 0);
+        rkeys[c] = (uint32_t)__builtin_amdgcn_readfirstlane((int)jc->rng_key);
+        rsteps[c] = (uint32_t)__builtin_amdgcn_readfirstlane((int)jc->rng_kstep);
+        rlo0s[c] = (uint32_t)__builtin_amdgcn_readfirstlane((int)jc->rng_lo0);
+    }
+    auto tile_a0 = [&](uint32_t t) -> int32_t { return (int32_t)((tile_br(t) >> 3) & ~(int64_t)15); };
+    // FAST tiles: every chunk lies inside the call's full power-of-two blocks -- one straight block of 16-byte loads into the prefetch
+    // registers, nothing else (a gather path that met this one at a join made the compiler copy the registers, i.e. wait, right there)
+    auto is_fast = [&](uint32_t t) -> bool { const int32_t a0 = tile_a0(t); return fast_layout && a0 >= 0 && (uint32_t)a0 + 16u * (uint32_t)NCHK <= full_bytes; };
+    auto issue = [&](uint32_t t) {
+        const uint32_t a0 = (uint32_t)tile_a0(t);
+        // (channel 1 of a mono group re-reads channel 0's bytes; nothing is written from them)
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
 #pragma unroll
             for (int i = 0; i < PF; ++i) {
                 const uint32_t ck = lane + 64u * i;
-                if (ck >= (uint32_t)NCHK) continue;
-                const int32_t jb = a0 + (int32_t)(16u * ck);
-                u32x4 v;
-                if (fast_layout && jb >= 0 && (uint32_t)jb + 16u <= full_bytes) {
-                    const uint32_t blk = (uint32_t)jb >> bshift, off = (uint32_t)jb & (Bsz - 1);
-                    v = *reinterpret_cast<D2D_GLOBAL const u32x4*>(as_global(j0.in) + (((uint64_t)blk * Ct + chf) << bshift) + off);
-                } else {
-                    v = gather_chunk(jobs + c, Ct, a.B, a.keep, jb);
-                }
-                if (a.msb) v = u32x4{px_lsb_first(v.x), px_lsb_first(v.y), px_lsb_first(v.z), px_lsb_first(v.w)};
-                *reinterpret_cast<u32x4*>(buf + 16u * ck) = v;
+                const uint32_t jb = a0 + 16u * (ck < (uint32_t)NCHK ? ck : (uint32_t)NCHK - 1u);      // (lanes past the last chunk re-read it; their writes are masked)
+                const uint32_t blk = jb >> bshift, off = jb & (Bsz - 1);
+                if (dbg & 4) pf[c][i] = u32x4{0u, 0u, 0u, 0u};
+                else pf[c][i] = *reinterpret_cast<D2D_GLOBAL const u32x4*>(as_global(j0.in) + (((uint64_t)blk * Ct + chf[c]) << bshift) + off);
             }
+    };
+    auto put = [&](uint32_t c, uint32_t ck, u32x4 v) {
+        if (a.msb) v = u32x4{px_lsb_first(v.x), px_lsb_first(v.y), px_lsb_first(v.z), px_lsb_first(v.w)};
+        *reinterpret_cast<u32x4*>(wbase + c * SB + 16u * ck) = v;
+    };
+    auto commit = [&]() {
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            if ((uint32_t)c >= cwn) continue;
+#pragma unroll
+            for (int i = 0; i < PF; ++i) if (lane + 64u * i < (uint32_t)NCHK) put((uint32_t)c, lane + 64u * i, pf[c][i]);
         }
-        wave_sync2();
+    };
+    // any other tile (the carried history in front, ragged or odd-sized blocks, the call's last bytes): gathered byte by byte, straight to LDS
+    auto gather_tile = [&](uint32_t t) {
+        const int32_t a0 = tile_a0(t);
+#pragma unroll 1
+        for (uint32_t c = 0; c < cwn; ++c)
+#pragma unroll 1
+            for (uint32_t ck = lane; ck < (uint32_t)NCHK; ck += 64) put(c, ck, gather_chunk(jobs + c, Ct, a.B, a.keep, a0 + (int32_t)(16u * ck)));
+    };
+
+    // One tile from its staged image: the chains of the group's channels, their epilogues, the frames
+    auto convert_tile = [&](uint32_t t) {
+        const uint64_t mT = (T0 + t) * (uint32_t)TILE;
+        const int64_t br = tile_br(t);
+        const uint32_t obit = (uint32_t)(br - 8 * (int64_t)tile_a0(t));      // column 0 starts at this bit (0 .. 127) of the image
+        const int64_t nl0 = (int64_t)(mT - m0);                               // the tile's first output, relative to the call's (may be negative)
 
         const uint32_t cbit = obit + (uint32_t)SBITS * n;             // the lane's column starts at this bit of the image
         const uint32_t shn = cbit & 31u;
-        for (uint32_t c = 0; c < cwn; ++c) {
+        static_for<0, 2>([&](auto cc) {
+            constexpr uint32_t c = (uint32_t)decltype(cc)::value;
+            if (c >= cwn) return;
             // ---- the chain: TP steps of 64 stream bits; group g takes part in steps u0(g) .. u1(g) ----
             const uint8_t* rb = wbase + c * SB + 4u * ((cbit >> 5) + kh);
             px_v16f acc[G];
-            {
+            if constexpr ((dbg & 1) != 0) {
+#pragma unroll
+                for (int g = 0; g < G; ++g) { acc[g] = cinit + (float)(lane + g); asm volatile("" : "+v"(acc[g])); }
+            } else {
                 // LDS reads are issued ahead of their use (stream dwords AW steps, tap fragments AF matrix instructions) and every matrix
                 // instruction is fenced, so that the compiler neither hoists all the fragment reads (258 registers) nor sinks them
                 constexpr int AW = 2, AF = 3;
@@ -181,8 +222,7 @@ __global__ __launch_bounds__(PX_THREADS) void d2d_fir_px_kernel(PxArgs a) {
             }
 
             // ---- epilogue: the lane's samples of this channel: outputs 3 kh + i of every group (half 1 owns two) ----
-            const StreamJob& jc = jobs[c];
-            const uint32_t rkey = jc.rng_key, rstep = jc.rng_kstep, rlo0 = jc.rng_lo0;
+            const uint32_t rkey = rkeys[c], rstep = rsteps[c], rlo0 = rlo0s[c];
             uint32_t vm = 0;
             static_for<0, G>([&](auto gc) {
                 constexpr int g = decltype(gc)::value;
@@ -198,7 +238,7 @@ __global__ __launch_bounds__(PX_THREADS) void d2d_fir_px_kernel(PxArgs a) {
                     const uint32_t va = (uint32_t)(v < 0 ? -v : v);
                     vm = max(vm, live ? va : 0u);
                     int32_t rv;
-                    if constexpr (KIND == 4) {
+                    if constexpr (KIND == 4 || (dbg & 2) != 0) {
                         rv = v;
                     } else {
                         uint32_t z = 0;
@@ -234,11 +274,12 @@ __global__ __launch_bounds__(PX_THREADS) void d2d_fir_px_kernel(PxArgs a) {
                 }
             });
             vmax[c] = max(vmax[c], vm);
-        }
+        });
         wave_sync2();
 
         // ---- the tile's samples out of the slice ----
-        if constexpr (KIND == 4) {
+        if constexpr ((dbg & 8) != 0) {
+        } else if constexpr (KIND == 4) {
             for (uint32_t c = 0; c < cwn; ++c) {
                 D2D_GLOBAL int32_t* xs = as_global(jobs[c].xs);
                 for (uint32_t i = lane; i < (uint32_t)TILE; i += 64) {
@@ -297,6 +338,38 @@ __global__ __launch_bounds__(PX_THREADS) void d2d_fir_px_kernel(PxArgs a) {
                 }
             }
         }
+    };
+
+    const uint32_t wstride = gridDim.x * a.nwaves, wv = blockIdx.x * a.nwaves + wave;
+    // the fast tiles are a range [t_lo, t_hi) (a tile's first byte grows with its index)
+    uint32_t t_lo = 0, t_hi = 0;
+    if (fast_layout) {
+        const int64_t c0 = tile_br(0), K = (int64_t)(TILE / LP) * MP;                 // stream bits between two tiles
+        t_lo = c0 >= 0 ? 0u : (uint32_t)((-c0 + K - 1) / K);
+        if (t_lo > ntiles) t_lo = ntiles;
+        const int64_t room = 8 * ((int64_t)full_bytes - 16 * NCHK + 15) - c0;
+        t_hi = room < 0 ? t_lo : (uint32_t)std::min<int64_t>(room / K + 1, (int64_t)ntiles);
+        if (t_hi < t_lo) t_hi = t_lo;
+        while (t_hi > t_lo && !is_fast(t_hi - 1)) --t_hi;
+        while (t_hi < ntiles && is_fast(t_hi)) ++t_hi;
+        while (t_lo < t_hi && !is_fast(t_lo)) ++t_lo;
+    }
+    for (uint32_t t = wv; t < ntiles; t += wstride) {
+        if (t >= t_lo && t < t_hi) continue;
+        wave_sync2();
+        gather_tile(t);
+        wave_sync2();
+        convert_tile(t);
+    }
+    uint32_t t = wv;
+    while (t < t_lo) t += wstride;
+    if (t < t_hi) issue(t);
+    for (; t < t_hi; t += wstride) {
+        wave_sync2();
+        commit();
+        if (t + wstride < t_hi) issue(t + wstride);       // the next tile's bytes are on their way while this one is converted
+        wave_sync2();
+        convert_tile(t);
     }
     if constexpr (KIND == 4) return;                                   // (the noise-shaping pass keeps the peaks)
     // peak meter: |y * gain| of the largest |v| (y = v 2^-S exactly; the product rounds once, as the oracle's)

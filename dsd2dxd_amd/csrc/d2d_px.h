@@ -19,7 +19,10 @@
 namespace d2d {
 
 constexpr int PX_FRAG_BYTES = 1536;          // a tap fragment: 64 lanes x 16 bytes, then 64 lanes x 8 bytes (32 e2m3 codes per lane)
-constexpr int PX_THREADS = 512;
+#ifndef D2D_PX_THREADS
+#define D2D_PX_THREADS 512     // waves per block x 64: 512 = two waves per SIMD; 768 = three (at most 168 registers), an A/B build
+#endif
+constexpr int PX_THREADS = D2D_PX_THREADS;
 
 // first bit (relative to the column's first output) of output o's window: floor(o Mp / Lp)
 __host__ __device__ constexpr int px_q(int LP, int MP, int o) { return (int)(((long long)o * MP) / LP); }

@@ -38,6 +38,11 @@ CASES = [
     ("dsd64_s20_352k8_dsd2pcm", dict(dsd_rate=1, output_rate=352800, channels=1, fmt="P", endianness="L", block_size=4096, filter="D", bit_depth=20, dither="T", seed=3, level_db=4.0)),
     ("dsd128_f32_176k4_cheby_fpd", dict(dsd_rate=2, output_rate=176400, channels=2, fmt="P", endianness="L", block_size=4096, filter="C", bit_depth=32, dither="F", seed=4)),
     ("dsd256_s24_192k", dict(dsd_rate=4, output_rate=192000, channels=2, fmt="P", endianness="L", block_size=4096, filter="E", bit_depth=24, dither="T", seed=6)),
+    # DSD64 / DSD128 -> 48k multiples: the composed polyphase tables (round 4)
+    ("dsd64_s24_96k_tpdf", dict(dsd_rate=1, output_rate=96000, channels=2, fmt="P", endianness="L", block_size=4096, filter="E", bit_depth=24, dither="T", seed=7)),
+    ("dsd64_f32_192k_dff", dict(dsd_rate=1, output_rate=192000, channels=2, fmt="I", endianness="M", block_size=1, filter="E", bit_depth=32, dither="F", seed=8, level_db=-3.0)),
+    ("dsd128_s16_384k_mono", dict(dsd_rate=2, output_rate=384000, channels=1, fmt="P", endianness="L", block_size=4096, filter="E", bit_depth=16, dither="R", seed=9)),
+    ("dsd128_s24_96k_ns_3ch", dict(dsd_rate=2, output_rate=96000, channels=3, fmt="P", endianness="M", block_size=512, filter="E", bit_depth=24, dither="N", seed=10)),
     ("dsd256_s24_1411k2", dict(dsd_rate=4, output_rate=1411200, channels=2, fmt="P", endianness="M", block_size=512, filter="E", bit_depth=24, dither="X", seed=0)),
 ]
 

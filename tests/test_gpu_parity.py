@@ -461,7 +461,8 @@ def test_interleaved_stereo_is_deinterleaved_inside_the_fir_kernel(engine_lib, o
         if nocoop == "0":
             M = 2822400 * dsd_rate // out_rate if out_rate % 44100 == 0 else 8 * dsd_rate          # (48k family: stage A decimates to 352.8 kHz)
             M = min(M, 64)
-            assert ("d2d_fir_mx_kernel" if M >= 32 and "D2D_NO_MX" not in os.environ else "d2d_fir_mfma3_kernel") in e.kernel_name()
+            composed = out_rate % 48000 == 0 and dsd_rate <= 2          # DSD64 / DSD128 -> 48k multiples: one polyphase pass (d2d_kernels_px.hip)
+            assert ("d2d_fir_px_kernel" if composed else "d2d_fir_mx_kernel" if M >= 32 and "D2D_NO_MX" not in os.environ else "d2d_fir_mfma3_kernel") in e.kernel_name()
             for f in range(2):
                 o = oracle_mod.Oracle(**kw)
                 want = []

@@ -24,11 +24,11 @@ def _free_port():
     return p
 
 
-def _run_ranks(mode, world, tmp_path):
+def _run_ranks(mode, world, tmp_path, env=None):
     port = _free_port()
     outs = [str(tmp_path / f"{mode}_{r}.npz") for r in range(world)]
     procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "shard_worker.py"), mode, str(r), str(world), str(port), outs[r]],
-                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(world)]
+                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=dict(os.environ, **(env or {}))) for r in range(world)]
     for p in procs:
         so, se = p.communicate(timeout=240)
         assert p.returncode == 0, se[-3000:]
@@ -72,18 +72,24 @@ def test_two_engine_processes_split_one_stream_by_channel(engine_lib, oracle_mod
         assert list(parts[r]["peaks"][0]) == [full.peak(first + c) for c in range(count)] == [o.peak(first + c) for c in range(count)]
 
 
-def test_uneven_channel_shards_keep_their_own_tables(engine_lib, oracle_mod, tmp_path):
-    """six channels over four ranks = 2, 2, 1, 1: the two-channel ranks run a pipelined stereo kernel, the one-channel ranks the
+@pytest.mark.parametrize("rate", [88200, 96000])
+def test_uneven_channel_shards_keep_their_own_tables(engine_lib, oracle_mod, tmp_path, rate):
+    """six channels over four ranks = 2, 2, 1, 1.  At 88.2 kHz the two-channel ranks run a pipelined stereo kernel, the one-channel ranks the
     two-group kernel with ANOTHER tap-table variant of the same size: the blob's header names the variant, the import
-    is refused, the rank keeps the tables it built -- and the union is still the oracle's conversion"""
+    is refused, the rank keeps the tables it built.  At 96 kHz one composed polyphase table serves every channel count: every rank adopts
+    rank 0's.  Either way the union is the oracle's conversion"""
     import shard_worker as W
     from dsd2dxd_amd.shard import merge_channel_frames, shard_channels
-    parts = _run_ranks("channels", 4, tmp_path)
+    parts = _run_ranks("channels", 4, tmp_path, env={"D2D_SHARD_RATE": str(rate)})
     counts = [shard_channels(W.CHN, 4, r)[1] for r in range(4)]
     assert counts == [2, 2, 1, 1]
-    assert [bool(p["adopted"]) for p in parts] == [True, True, False, False]
-    assert str(parts[0]["kernel"]) != str(parts[2]["kernel"])
+    if rate == 88200:
+        assert [bool(p["adopted"]) for p in parts] == [True, True, False, False]
+        assert str(parts[0]["kernel"]) != str(parts[2]["kernel"])
+    else:
+        assert all(bool(p["adopted"]) for p in parts)
+        assert all("d2d_fir_px_kernel" in str(p["kernel"]) for p in parts)
     buf = W.stream_bytes()
-    want, fr = oracle_mod.Oracle(**W.KW_CHANNELS).translate(buf)
+    want, fr = oracle_mod.Oracle(**dict(W.KW_CHANNELS, output_rate=rate)).translate(buf)
     merged = merge_channel_frames([(*shard_channels(W.CHN, 4, r), parts[r]["pcm0"]) for r in range(4)], 3)
     assert np.array_equal(merged, want[:fr * W.CHN * 3])

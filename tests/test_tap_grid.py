@@ -172,7 +172,7 @@ def test_32_bit_taps_are_refused_where_they_are_not_defined(engine_lib):
 
 # ---- stage B of the 48k cascade: what its 2^-28 coefficient grid costs against the f64 design it was rounded from ----
 
-@pytest.mark.parametrize("dsd_rate,out_rate", [(1, 96000), (1, 192000), (2, 384000), (8, 96000)])
+@pytest.mark.parametrize("dsd_rate,out_rate", [(1, 96000), (1, 192000), (2, 384000), (4, 192000), (4, 384000), (8, 96000)])
 def test_stage_b_grid_cost_against_its_f64_coefficients(oracle_mod, dsd_rate, out_rate):
     """round 3 put stage B's polyphase coefficients on a dyadic grid (every phase sums to 1 exactly) so that it runs as an exact integer
     matrix product; against round 2's definition -- the f64 design, summed in f64 -- the float output must stay inside the north
@@ -184,6 +184,8 @@ def test_stage_b_grid_cost_against_its_f64_coefficients(oracle_mod, dsd_rate, ou
     for mode in ("grid", "f64"):
         for bits, dither in ((32, "X"), (24, "T")):
             o = O.Oracle(bit_depth=bits, dither=dither, **kw)
+            if dsd_rate <= 2:
+                o.use_cascade()           # (DSD64 / DSD128: the two-stage form is the study mode since round 4, tests/test_poly48k.py)
             if mode == "f64":
                 o.use_f64_resamp_coef()
             outs[mode, bits] = o.translate(buf)[0]
