@@ -265,6 +265,7 @@ def main():
     ap.add_argument("--dither", default="", help="override the workload's dither (T, R, X, F, N)")
     ap.add_argument("--level", type=float, default=0.0, help="volume in dB (the reference's -l; its own test scripts use +-4)")
     ap.add_argument("--tap-bits", type=int, default=24, choices=(24, 32), help="tap grid (32: the optional 32-bit taps, two FIR passes and a combining pass; 44.1k-family workloads with dither T/R/F/X)")
+    ap.add_argument("--debug", type=lambda v: int(v, 0), default=0, help="d2d_params.debug_flags (include/dsd2dxd_amd.h: D2D_DBG_*), e.g. 2 = the older kernels for levels other than 0 dB; the line then names the flags and cites no counter traffic")
     ap.add_argument("--pcie-slice", type=int, default=0, help="bytes per channel per slice of the host-resident batch (0 = the library's default)")
     args = ap.parse_args()
 
@@ -335,7 +336,7 @@ def main():
         kw.update(channel_first=ch_first, channel_count=ch_count)
     # file shards differ per rank; a channel shard reads the same files on every rank
     files = make_files(args.files, bpc, dsd_rate, args.distinct, rank if args.shard == "files" else 0, gen_threads, channels, fmt, endian, block)
-    eng = d.Engine(n_files=args.files, kernel=kernel, device=local_dev, **kw)
+    eng = d.Engine(n_files=args.files, kernel=kernel, device=local_dev, debug=args.debug, **kw)
     stream = torch.cuda.current_stream().cuda_stream
 
     # the shared filter tables: rank 0's copy is broadcast over RCCL and adopted by the others
@@ -462,6 +463,8 @@ def main():
         sustained["value"] = round(total_samples / args.steps * sustained["steps"] / sustained["seconds"] / 1e6, 3)
         out["sustained"] = sustained
     # a development library (D2D_AMD_LIB, tools/ab_*.sh) is named in the line, and no counter traffic is cited for it
+    if args.debug:
+        out["config"]["debug_flags"] = args.debug
     alt_lib = os.environ.get("D2D_AMD_LIB")
     if alt_lib:
         with open(alt_lib, "rb") as fl:
@@ -472,7 +475,7 @@ def main():
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as fjs:
             pmc = json.load(fjs)
         ent = pmc.get(eng.kernel_name() if scope == "kernel" else "step", {}).get(args.workload)      # "step": every kernel of the step, summed
-        if (ent and not alt_lib and ent.get("kernel_src_sha16") == kernel_source_hash() and ent.get("files_per_gpu") == args.files
+        if (ent and not alt_lib and not args.debug and ent.get("kernel_src_sha16") == kernel_source_hash() and ent.get("files_per_gpu") == args.files
                 and abs(ent.get("seconds_per_file", 0) - out["config"]["seconds_per_file"]) < 1e-3):
             out["roofline"]["traffic"] = ent["hbm_bytes_per_launch"]
     except Exception:
@@ -482,7 +485,8 @@ def main():
         # end-to-end from pinned host memory: d2d_translate_batch_host (three streams, double-buffered
         # staging), every rank at once on its own GPU and link.  A separate engine so the timed engine's
         # state is untouched.
-        e2 = d.Engine(n_files=args.files, kernel=kernel, device=local_dev, **kw)
+        e2 = d.Engine(n_files=args.files, kernel=kernel, device=local_dev, debug=args.debug, **kw)
+        e3 = d.Engine(n_files=args.files, kernel=kernel, device=local_dev, debug=args.debug | d.DBG_HOST_STAGED, **kw)    # the same through the staged pipeline
         h_in = {}
         for b in files:
             if id(b) not in h_in:
@@ -494,7 +498,7 @@ def main():
             hios[f].bytes_per_channel = bpc
             hios[f].pcm = h_out[f].data_ptr()
             hios[f].pcm_capacity_bytes = frames * fb
-        def host_pass():
+        def host_pass(e2):
             e2.reset()
             e2.translate_batch_host(hios, args.pcie_slice)       # warm-up (allocates what the route needs)
             reps = 2
@@ -511,22 +515,17 @@ def main():
             return dth
         hb = args.files * (bpc * channels + frames * fb)
         up_b, down_b = args.files * bpc * channels, args.files * frames * fb
-        forced = os.environ.get("D2D_HOST_STAGED")
-        dth = host_pass()                                        # pinned buffers: the kernels address them directly (one pass, no staging)
-        os.environ["D2D_HOST_STAGED"] = "1"
-        dts_ = host_pass()                                       # the sliced upload / convert / download pipeline (what pageable buffers get)
-        if forced is None:
-            del os.environ["D2D_HOST_STAGED"]
-        else:
-            os.environ["D2D_HOST_STAGED"] = forced
+        forced = bool(args.debug & d.DBG_HOST_STAGED)
+        dth = host_pass(e2)                                      # pinned buffers: the kernels address them directly (one pass, no staging)
+        dts_ = host_pass(e3)                                     # the sliced upload / convert / download pipeline (what pageable buffers get)
         out["pcie_inclusive"] = {"value": round(total_samples / args.steps / dth / 1e6, 3), "unit": "Msamples/s", "ms_per_step": round(dth * 1e3, 3),
                                  "host_bytes_per_step_per_gpu": int(hb), "link_GBps_both_ways_per_gpu": round(hb / dth / 1e9, 2),
                                  "link_GBps_up_per_gpu": round(up_b / dth / 1e9, 2), "link_GBps_down_per_gpu": round(down_b / dth / 1e9, 2),
-                                 "route": "staged pipeline (D2D_HOST_STAGED)" if forced not in (None, "", "0") else "kernels read and write the pinned host buffers in place",
+                                 "route": "staged pipeline (D2D_DBG_HOST_STAGED)" if forced else "kernels read and write the pinned host buffers in place",
                                  "staged_pipeline": {"ms_per_step": round(dts_ * 1e3, 3), "link_GBps_both_ways_per_gpu": round(hb / dts_ / 1e9, 2),
                                                      "link_GBps_up_per_gpu": round(up_b / dts_ / 1e9, 2), "link_GBps_down_per_gpu": round(down_b / dts_ / 1e9, 2)},
                                  "note": "pinned host buffers -> pinned host buffers through d2d_translate_batch_host, all %d GPU(s) at once; never the reported value" % world}
-        del e2
+        del e2, e3
 
     if rank == 0 and not args.no_cpu_baseline:
         threads = max(1, ncpu // 2)

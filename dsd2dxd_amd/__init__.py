@@ -5,4 +5,5 @@ dsd2dxd_amd/csrc for gfx950.  This package is only the thin ctypes binding the t
 drive it through; there is no Python or CPU implementation of the conversion behind it.
 """
 from ._capi import (D2DError, Engine, FileIO, Params, lib, library_path, build_library,  # noqa: F401
-                    KERNEL_AUTO, KERNEL_LUT, KERNEL_MFMA)
+                    KERNEL_AUTO, KERNEL_LUT, KERNEL_MFMA,
+                    DBG_NO_MX, DBG_NO_GAINQ, DBG_NO_COOP, DBG_HOST_STAGED, DBG_NO_PIPE, DBG_MFMA_V1, DBG_NO_INTQ, DBG_NS_GENERAL, dbg_waves)

@@ -6,6 +6,14 @@ import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 KERNEL_AUTO, KERNEL_LUT, KERNEL_MFMA = 0, 1, 2
+# d2d_params.debug_flags (include/dsd2dxd_amd.h: D2D_DBG_*): diagnostic dispatch switches, 0 in production
+DBG_NO_MX, DBG_NO_GAINQ, DBG_NO_COOP, DBG_HOST_STAGED, DBG_NO_PIPE, DBG_MFMA_V1, DBG_NO_INTQ, DBG_NS_GENERAL = (1 << i for i in range(8))
+
+
+def dbg_waves(n):
+    """debug_flags bits 8..15: waves per block of the matrix-core kernels"""
+    return (int(n) & 0xFF) << 8
+
 
 
 def library_path():
@@ -29,7 +37,7 @@ class Params(C.Structure):
                 ("dither", C.c_uint32), ("kernel", C.c_uint32), ("device", C.c_int32),
                 ("level_db", C.c_double), ("seed", C.c_uint64),
                 ("channel_first", C.c_uint32), ("channel_count", C.c_uint32),
-                ("tap_bits", C.c_uint32), ("reserved0", C.c_uint32)]
+                ("tap_bits", C.c_uint32), ("debug_flags", C.c_uint32)]
 
 
 class FileIO(C.Structure):
@@ -117,12 +125,12 @@ class D2DError(Exception):
 
 def make_params(dsd_rate=1, output_rate=352800, channels=2, fmt="I", endianness="M", block_size=4096,
                 filter="E", bit_depth=24, dither="X", level_db=0.0, seed=0, kernel=KERNEL_AUTO, device=0,
-                channel_first=0, channel_count=0, tap_bits=0):
+                channel_first=0, channel_count=0, tap_bits=0, debug=0):
     """Argument names and defaults follow the reference CLI (src/main.rs:40-110); channel_first/count
     select a channel subset (0 = all), tap_bits the tap grid (0 / 24, or 32), see include/dsd2dxd_amd.h."""
     return Params(C.sizeof(Params), dsd_rate, output_rate, channels, 1 if fmt.upper() == "P" else 0,
                   1 if endianness.upper() == "M" else 0, block_size, ord(filter.upper()), bit_depth,
-                  ord(dither.upper()), kernel, device, level_db, seed, channel_first, channel_count, tap_bits, 0)
+                  ord(dither.upper()), kernel, device, level_db, seed, channel_first, channel_count, tap_bits, debug)
 
 
 class Engine:

@@ -211,6 +211,7 @@ static void fir_args_static(const d2d_engine* e, FirArgs& a, bool lo_pass = fals
     a.mx_exact = mx_exact(fd) ? 1u : 0u;
     a.coop = e->coop ? 1u : 0u;
     a.il2 = e->il2 ? 1u : 0u;
+    a.dbg_flags = e->p.debug_flags;
 }
 
 namespace d2d { thread_local const char* d2d_last_launched_kernel = nullptr; }
@@ -223,7 +224,7 @@ int d2d_create(const d2d_params* params, uint32_t n_files, d2d_engine** out) {
     if (out) *out = nullptr;
     if (!params || !out) { g_create_error = "null argument"; return D2D_ERR_PARAM; }
     constexpr size_t legacy_size = offsetof(d2d_params, channel_first);           // ABI 1: no channel subset
-    constexpr size_t abi3_size = offsetof(d2d_params, tap_bits);                  // ABI 2, 3: no tap grid
+    constexpr size_t abi3_size = offsetof(d2d_params, tap_bits);                  // ABI 2, 3: no tap grid (ABI 4 and 5 have today's size: reserved0 became debug_flags)
     if (params->struct_size != sizeof(d2d_params) && params->struct_size != legacy_size && params->struct_size != abi3_size) {
         g_create_error = "d2d_params.struct_size mismatch"; return D2D_ERR_PARAM;
     }
@@ -274,15 +275,15 @@ int d2d_create(const d2d_params* params, uint32_t n_files, d2d_engine** out) {
     bool mfma_ok = mfma_supported(e->M, e->N) &&
                    mfma_smem_bytes(e->mfma, e->C, e->epi.sample_bytes, &mfma_waves) <= 160 * 1024;
     {   // the two-group kernel wherever its shape is compiled and four waves fit in LDS (D2D_MFMA_V1=1: the older one)
-        static const char* v1 = getenv("D2D_MFMA_V1");
+        const bool v1 = (e->p.debug_flags & D2D_DBG_MFMA_V1) != 0;
         uint32_t w2 = 0;
-        if (!(v1 && atoi(v1)) && mfma2_supported(e->M, e->N) &&
+        if (!v1 && mfma2_supported(e->M, e->N) &&
             mfma2_smem_bytes(e->M, e->N, e->C, e->epi.sample_bytes, &w2) <= 160 * 1024 && w2 >= 4) {
             e->mfma_v2 = true; mfma_ok = true; mfma_waves = w2;
         }
         // M = 8 and 16: the two-group geometry only through the pipelined kernel (stereo 16/24-bit/float frames at 0 dB); every other
         // format of those rates stays on the one-group kernel
-        if (!(v1 && atoi(v1)) && !e->mfma_v2 && (e->M < 32 || e->M == 128) && e->p.kernel != D2D_KERNEL_LUT) {
+        if (!v1 && !e->mfma_v2 && (e->M < 32 || e->M == 128) && e->p.kernel != D2D_KERNEL_LUT) {
             FirArgs a{}; fir_args_static(e, a);
             if (mfma2_pipelined(a, e->M, e->N)) { e->mfma_v2 = true; mfma_ok = true; mfma_waves = 8; }
         }
@@ -329,6 +330,8 @@ int d2d_create(const d2d_params* params, uint32_t n_files, d2d_engine** out) {
             CK(hipMalloc(&e->d_fir_tables, e->fir_table_bytes));
             CK(hipMemcpy(e->d_fir_tables, e->poly->q, e->fir_table_bytes, hipMemcpyHostToDevice));
         } else {
+            // byte-interleaved stereo (DFF files, the CLI's default -f I): de-interleaved inside the kernel's staging, no planar copy (D2D_NO_COOP=1: the pre-pass)
+            if (e->deinterleave && e->Cin == 2 && e->C == 2 && !(e->p.debug_flags & D2D_DBG_NO_COOP)) { e->il2 = true; e->deinterleave = false; e->B = 1; }
             const std::vector<int8_t> t = build_px_tables(*e->poly);
             e->fir_table_bytes = t.size();
             CK(hipMalloc(&e->d_fir_tables, e->fir_table_bytes));
@@ -342,29 +345,29 @@ int d2d_create(const d2d_params* params, uint32_t n_files, d2d_engine** out) {
     } else {
         if (e->mfma_v2) { FirArgs a{}; fir_args_static(e, a); e->mfma_pipe = mfma2_pipelined(a, e->M, e->N); }
         // byte-interleaved 4- or 8-channel input into the scratch (48k family, noise shaping) through the fp6 kernel: no planar copy, the
-        // kernel's staging de-interleaves (D2D_NO_COOP=1: the pre-pass)
+        // kernel's staging de-interleaves (D2D_DBG_NO_COOP: the pre-pass)
         {
-            const char* nocoop = getenv("D2D_NO_COOP");   // (read at every engine creation: the tests switch it inside one process)
+            const bool nocoop = (e->p.debug_flags & D2D_DBG_NO_COOP) != 0;
             if (e->deinterleave && e->mfma_pipe == 5 && (e->fc.resamp || e->noise_shape) && !e->fine && e->C == e->Cin && (e->Cin == 8 || e->Cin == 4) &&
-                !(nocoop && atoi(nocoop))) {
+                !nocoop) {
                 e->coop = true; e->deinterleave = false; e->B = 1;
             }
             // byte-interleaved stereo (DFF files, the CLI's default -f I) into frames through a pipelined kernel (fp6: M = 32, 64; int8: M = 8, 16):
             // the same, inside one wave
             // (the scratch flavours too: stereo DFF input into the 48k cascade and the noise shaper; not the two passes of 32-bit taps)
             if (e->deinterleave && ((e->mfma_pipe == 5 || (e->mfma_pipe == 3 && e->M < 64)) && !e->fine) && e->Cin == 2 && e->C == 2 &&
-                !(nocoop && atoi(nocoop))) {
+                !nocoop) {
                 e->il2 = true; e->deinterleave = false; e->B = 1;
             }
         }
-        std::vector<int8_t> t = e->mfma_pipe == 5 ? build_mx_tables(f, msb) : e->mfma_pipe == 4 ? build_mfma4_tables(f, msb)
+        std::vector<int8_t> t = e->mfma_pipe == 5 ? build_mx_tables(f, msb)
                               : e->mfma_v2 ? build_mfma2_tables(f, msb, !e->mfma_pipe) : build_mfma_tables(f, e->mfma, msb);
         e->fir_table_bytes = t.size();
         CK(hipMalloc(&e->d_fir_tables, e->fir_table_bytes));
         CK(hipMemcpy(e->d_fir_tables, t.data(), e->fir_table_bytes, hipMemcpyHostToDevice));
         if (e->fine) {
             // the residual table goes through the same builders; which pipelined kernel serves it is decided on ITS digits
-            if (e->mfma_v2) { FirArgs a{}; fir_args_static(e, a, true); e->mfma_pipe_lo = mfma2_pipelined(a, e->M, e->N); if (e->mfma_pipe_lo == 4) e->mfma_pipe_lo = 3; }
+            if (e->mfma_v2) { FirArgs a{}; fir_args_static(e, a, true); e->mfma_pipe_lo = mfma2_pipelined(a, e->M, e->N); }
             const d2d_filter_def& fl = e->lo_def;
             std::vector<int8_t> tl = e->mfma_pipe_lo == 5 ? build_mx_tables(fl, msb)
                                    : e->mfma_v2 ? build_mfma2_tables(fl, msb, !e->mfma_pipe_lo) : build_mfma_tables(fl, e->mfma, msb);
@@ -575,6 +578,7 @@ int d2d_translate_batch_device(d2d_engine* e, d2d_file_io* io, uint32_t n_files,
         px.jobs = e->d_jobs; px.tables = e->d_fir_tables;
         px.in_channels = e->Cin; px.B = e->B; px.keep = e->keep; px.msb = e->p.endianness == D2D_MSB_FIRST ? 1u : 0u;
         px.to_scratch = e->noise_shape ? 1u : 0u;
+        px.il2 = e->il2 ? 1u : 0u;
         px.epi = e->epi;
         if (e->poly_plain) HIPCHK(e, launch_poly_plain(px, *e->poly, max_frames, e->nstreams, s));
         else HIPCHK(e, launch_fir_px(px, *e->poly, max_frames, n_files, s));
@@ -621,7 +625,7 @@ int d2d_translate_batch_device(d2d_engine* e, d2d_file_io* io, uint32_t n_files,
         ns.scale_bits = e->poly ? e->poly->S : e->S; ns.nstreams = e->nstreams; ns.max_nout = e->fc.resamp ? max_frames : max_nx; ns.epi = e->epi;
         if (e->cascade()) { ns.ys = e->d_ys; ns.ys_stride = (uint32_t)e->ys_stride; ns.res = 1; }
         {
-            static const char* noint = getenv("D2D_NO_INTQ");
+            const bool noint = (e->p.debug_flags & D2D_DBG_NO_INTQ) != 0;
             uint64_t sa = 0;
             if (e->poly) {
                 for (int ph = 0; ph < e->poly->Lp; ++ph) {
@@ -631,6 +635,7 @@ int d2d_translate_batch_device(d2d_engine* e, d2d_file_io* io, uint32_t n_files,
                 }
             } else { FirArgs fa{}; fir_args_static(e, fa); sa = fa.sum_abs_q; }
             ns.intq = (!noint && sa + (1ull << 24) < (1ull << 31)) ? 1u : 0u;
+            ns.general = (e->p.debug_flags & D2D_DBG_NS_GENERAL) ? 1u : 0u;
         }
         // a stream whose call ends exactly on a segment boundary, or feeds nothing, writes no state: start the next buffer from the current one
         HIPCHK(e, hipMemcpyAsync(e->d_ns[e->ns_cur ^ 1], e->d_ns[e->ns_cur], sizeof(double) * 2 * e->nstreams, hipMemcpyDeviceToDevice, s));
@@ -677,7 +682,7 @@ static bool device_view(const void* p, void** dev) {
     }
     return false;
 }
-static bool host_staged_forced() { const char* v = getenv("D2D_HOST_STAGED"); return v && *v && *v != '0'; }
+static bool host_staged_forced(const d2d_engine* e) { return (e->p.debug_flags & D2D_DBG_HOST_STAGED) != 0; }
 
 int d2d_translate(d2d_engine* e, const uint8_t* dsd, size_t L, void* pcm, size_t cap, size_t* frames_out) {
     if (!e) return D2D_ERR_PARAM;
@@ -692,7 +697,7 @@ int d2d_translate(d2d_engine* e, const uint8_t* dsd, size_t L, void* pcm, size_t
     const size_t in_bytes = L * e->Cin;
     hipStream_t s = e->own_stream;
     void *vin = nullptr, *vout = nullptr;
-    if (in_bytes && out_bytes && !host_staged_forced() && device_view(dsd, &vin) && device_view(pcm, &vout)) {
+    if (in_bytes && out_bytes && !host_staged_forced(e) && device_view(dsd, &vin) && device_view(pcm, &vout)) {
         d2d_file_io io{};
         io.dsd = vin; io.bytes_per_channel = L; io.pcm = vout; io.pcm_capacity_bytes = cap;
         int rc = d2d_translate_batch_device(e, &io, 1, s);
@@ -734,15 +739,16 @@ int d2d_translate_batch_host(d2d_engine* e, d2d_file_io* io, uint32_t n_files, s
         io[f].frames_out = 0;
     }
     if (max_L == 0) return D2D_OK;
-    if (!host_staged_forced()) {
+    if (!host_staged_forced(e)) {
         std::vector<d2d_file_io> vio(io, io + n_files);
-        // one call for the whole batch: every file below the per-call limit, and the cascade's / noise shaper's scratch for all of
-        // it at once (4 B per stage-A sample, 8 more per output where the two combine) within half of the free device memory
+        // one call for the whole batch: every file below the per-call limit, and the cascade's / noise shaper's / 32-bit taps' scratch for all
+        // of it at once (4 B per stage-A sample, 8 more per output where the two combine; two int32 halves with 32-bit taps) within half of
+        // the free device memory -- otherwise the sliced pipeline below, which needs one slice of scratch
         bool direct = max_L < (1ull << 31);
-        if (direct && (e->cascade() || e->noise_shape)) {
+        if (direct && (e->cascade() || e->noise_shape || e->fine)) {
             size_t free_b = 0, total_b = 0;
             HIPCHK(e, hipMemGetInfo(&free_b, &total_b));
-            const double per_stream = (double)max_L / (double)e->Mb * (e->cascade() && e->noise_shape ? 12.0 : 4.0);
+            const double per_stream = (double)max_L / (double)e->Mb * (e->cascade() && e->noise_shape ? 12.0 : e->fine ? 8.0 : 4.0);
             direct = per_stream * (double)e->nstreams < 0.5 * (double)free_b;
         }
         for (uint32_t f = 0; f < n_files && direct; ++f) {
@@ -876,7 +882,7 @@ int d2d_convert_stream(d2d_engine* e, d2d_read_fn read, void* ru, d2d_write_fn w
     }
     // the kernels read and write the pinned buffers themselves when the GPU can address them (they are hipHostMalloc'ed: it can)
     void* vin[2] = {nullptr, nullptr}; void* vout[2] = {nullptr, nullptr};
-    const bool direct = !host_staged_forced() && device_view(pin.in[0], &vin[0]) && device_view(pin.in[1], &vin[1]) &&
+    const bool direct = !host_staged_forced(e) && device_view(pin.in[0], &vin[0]) && device_view(pin.in[1], &vin[1]) &&
                         device_view(pin.out[0], &vout[0]) && device_view(pin.out[1], &vout[1]);
     int rc = D2D_OK;
     if (!direct) {

@@ -67,6 +67,7 @@ struct FirArgs {
     uint32_t il2;              // 1 (pipelined frame kernels): byte-interleaved STEREO input (DFF, -f I), both channels converted: the kernel's staging
                                // pulls the channels apart (one v_perm_b32 per channel and eight input bytes); B = 1, no planar copy
     uint32_t mx_exact;         // 1: the table's base-32 digit sums recombine exactly in f32 (d2d_mx.h: mx_exact)
+    uint32_t dbg_flags;        // d2d_params.debug_flags (D2D_DBG_*), fixed when the engine was created
     Epilogue epi;
 };
 
@@ -86,6 +87,7 @@ struct NoiseShapeArgs {
     const double* ys;
     uint32_t ys_stride;
     uint32_t res;
+    uint32_t general;          // 1 (D2D_DBG_NS_GENERAL): the general kernel for stereo frames too
     Epilogue epi;
 };
 

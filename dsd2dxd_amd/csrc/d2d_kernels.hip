@@ -608,8 +608,7 @@ hipError_t launch_noise_shape(const NoiseShapeArgs& a0, hipStream_t s) {
     const uint32_t fb = a.epi.sample_bytes * C;
     const size_t smem = (size_t)waves * spw * (NS_FRAMES * fb + 4);
     const uint32_t nfiles = a.nstreams / C;
-    static const char* gen = getenv("D2D_NS_GENERAL");                          // diagnostic: the general kernel for stereo too
-    if (C == 2 && (a.epi.bits == 16 || a.epi.bits == 24) && !(gen && atoi(gen)) && !a.res) {
+    if (C == 2 && (a.epi.bits == 16 || a.epi.bits == 24) && !a.general && !a.res) {      // (general: D2D_DBG_NS_GENERAL, the general kernel for stereo too)
         const int F = a.scale_bits - ((int)a.epi.bits - 1);
         const bool intq = a.intq && a.epi.gain == 1.0 && F >= 1 && F <= 16;
         const dim3 grid((max_seg + waves * 32 - 1) / (waves * 32), nfiles);

@@ -724,10 +724,12 @@ static void mfma_geometry(const FirArgs& a, const MfmaLayout& g, MfmaArgs& m, si
     m.off_out = ((C + 1) / 2) * m.ppair;
     m.off_pk = m.off_out + ((256u * C * a.epi.sample_bytes + 15u) & ~15u);
     m.wave_lds = m.off_pk + C * 64u * 8u + ((C * 16u + 15u) & ~15u);   // peaks + per-channel dither keys
-    { static const char* e = getenv("D2D_DBG"); m.dbg = e ? (uint32_t)atoi(e) : 0u; }
+#if D2D_DIAG
+    { static const char* e = getenv("D2D_DBG"); m.dbg = e ? (uint32_t)atoi(e) : 0u; }          // (make DIAG=1 builds only: never the shipped library)
     { static const char* e = getenv("D2D_STAGGER"); m.stagger = e ? (uint32_t)atoi(e) : 0u; }
-    static const char* wenv = getenv("D2D_MFMA_WAVES");   // diagnostic override
-    m.nwaves = wenv ? (uint32_t)atoi(wenv) : 12u;
+#endif
+    const uint32_t wdbg = (a.dbg_flags >> 8) & 0xFFu;      // diagnostic override (d2d_params.debug_flags bits 8..15)
+    m.nwaves = wdbg ? wdbg : 12u;
     if (m.nwaves < 1 || m.nwaves > 12) m.nwaves = 12;
     // largest block that fits the CU's LDS, keeping the waves evenly spread over the four SIMDs
     while (m.nwaves > 1 && (size_t)m.off_waves + (size_t)m.nwaves * m.wave_lds > 160 * 1024)

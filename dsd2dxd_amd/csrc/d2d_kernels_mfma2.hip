@@ -705,7 +705,7 @@ static bool mfma3_eligible(const FirArgs& a, const Mfma2Args& m, int MB, int NPG
     const bool frames_ok = !a.to_scratch && a.epi.channels == 2 && (a.epi.sample_bytes == 3 || a.epi.sample_bytes == 2) && m.qsh == 0 && !m.wide;
     const bool shape_ok = a.scale_bits >= 18 && a.scale_bits <= 30 && mfma3_supported(MB, NPG, NT);
     // ... or 32-bit float at 0 dB without the float dither: the sample is (float)v * 2^-S
-    static const char* noint = getenv("D2D_NO_INTQ");
+    const bool noint = (a.dbg_flags & D2D_DBG_NO_INTQ) != 0;
     const bool float_ok = !noint && !a.to_scratch && a.epi.channels == 2 && a.epi.bits == 32 && a.epi.dither != 'F' && a.epi.gain == 1.0 && !m.wide &&
                           a.sum_abs_q != 0 && a.sum_abs_q < (1ull << 31);
     // (M = 8 float frames too since the pipelined kernel stages that shape's frames through LDS: 4.18 against 4.50 ms on the one-group kernel)
@@ -720,7 +720,7 @@ static void mfma2_geometry(const FirArgs& a, int MB, int NPG, Mfma2Args& m, size
 static bool mx_eligible(const FirArgs& a, const Mfma2Args& m) {
     const bool range_ok = a.scale_bits >= 20 && a.scale_bits <= 30 && a.sum_abs_q != 0 && a.sum_abs_q < (1ull << 31) && a.mx_exact;
     if (a.to_scratch) return a.epi.channels >= 2 && a.epi.channels % 2 == 0 && range_ok;
-    static const char* noint = getenv("D2D_NO_INTQ");
+    const bool noint = (a.dbg_flags & D2D_DBG_NO_INTQ) != 0;
     const bool stereo = a.epi.channels == 2 && m.qsh == 0;
     const bool float_ok = !noint && stereo && a.epi.bits == 32 && a.epi.dither != 'F' && a.epi.gain == 1.0;
     const bool frames_ok = stereo && (a.epi.sample_bytes == 3 || a.epi.sample_bytes == 2) && m.intq;
@@ -728,36 +728,30 @@ static bool mx_eligible(const FirArgs& a, const Mfma2Args& m) {
 }
 
 int mfma2_pipelined(const FirArgs& a, int M, int N) {
-    // (read at every engine creation, not cached: the tests switch variants inside one process)
-    const char* nopipe = getenv("D2D_NO_PIPE");
-    const char* sparse = getenv("D2D_SPARSE");
-    if (nopipe && atoi(nopipe)) return 0;
+    if (a.dbg_flags & D2D_DBG_NO_PIPE) return 0;
     const int MB = M / 8, NPG = mfma2_pairs(M, N);
-    const char* nomx = getenv("D2D_NO_MX");
+    const bool nomx = (a.dbg_flags & D2D_DBG_NO_MX) != 0;
     Mfma2Args m{}; size_t smem = 0;
     mfma2_geometry(a, MB, NPG, m, smem);
     // M = 128 (DSD256 -> 88.2 kHz, DSD512 -> 176.4 kHz): only the fp6 kernel has the LDS for that tap table; its conditions are its own
     // (S = 30: no biased accumulators, and the int8 kernels' limb-sum bound `wide` does not apply)
     if (MB == 16) {
-        static const char* noint16 = getenv("D2D_NO_INTQ");
+        const bool noint16 = (a.dbg_flags & D2D_DBG_NO_INTQ) != 0;
         const bool range_ok = a.scale_bits >= 20 && a.scale_bits <= 30 && a.sum_abs_q != 0 && a.sum_abs_q < (1ull << 31) && a.mx_exact;
-        if ((nomx && atoi(nomx)) || !mx_supported(MB, N) || !range_ok || noint16) return 0;
+        if (nomx || !mx_supported(MB, N) || !range_ok || noint16) return 0;
         if (a.to_scratch) return a.epi.channels >= 2 && a.epi.channels % 2 == 0 ? 5 : 0;
         const bool depth_ok = a.epi.bits == 32 ? true : ((a.epi.bits == 24 || a.epi.bits == 20 || a.epi.bits == 16) && m.fbits > 0 && m.fbits <= 16 && a.epi.dither != 'F');
         if (a.epi.channels != 2 || !depth_ok || a.epi.dither == 'N') return 0;
         if (a.epi.gain == 1.0 && m.qsh == 0 && !(a.epi.bits == 32 && a.epi.dither == 'F')) return 5;
-        const char* nogain16 = getenv("D2D_NO_GAINQ");
-        return mx_gain_supported(MB, N) && !(nogain16 && atoi(nogain16)) ? 5 : 0;
+        return mx_gain_supported(MB, N) && !(a.dbg_flags & D2D_DBG_NO_GAINQ) ? 5 : 0;
     }
     // the fp6 x fp4 kernel (d2d_kernels_mx.hip) serves what the pipelined int8 kernel serves at M = 32 and 64: 5
-    if (!(nomx && atoi(nomx)) && mx_supported(MB, N) && mx_eligible(a, m)) return 5;
+    if (!nomx && mx_supported(MB, N) && mx_eligible(a, m)) return 5;
     // ... and stereo frames at another level than 0 dB (its gain flavours)
-    if (!(nomx && atoi(nomx)) && m.gainq && mx_gain_supported(MB, N) && a.mx_exact && a.scale_bits >= 20 && a.scale_bits <= 30 && (a.epi.bits == 32 || a.epi.sample_bytes == 2 || a.epi.sample_bytes == 3)) return 5;
+    if (!nomx && m.gainq && mx_gain_supported(MB, N) && a.mx_exact && a.scale_bits >= 20 && a.scale_bits <= 30 && (a.epi.bits == 32 || a.epi.sample_bytes == 2 || a.epi.sample_bytes == 3)) return 5;
     if (!mfma2_supported(M, N) && !mfma3_supported(MB, NPG, N) && !(a.to_scratch && mfma3_scr_supported(MB, NPG))) return 0;
     if (!mfma3_eligible(a, m, MB, NPG, N)) return 0;
-    // the structured-sparse chain issues 27 % fewer MFMAs but 8 % more vector instructions, and the kernel is bound by vector issue:
-    // measured 4-7 % slower than the dense chain; kept selectable (D2D_SPARSE=1), exact and tested
-    return sparse && atoi(sparse) && !a.to_scratch && a.epi.sample_bytes == 3 && mfma3_sparse_compiled(MB, N) ? 4 : 3;
+    return 3;
 }
 
 static void mfma2_geometry(const FirArgs& a, int MB, int NPG, Mfma2Args& m, size_t& smem) {
@@ -774,23 +768,24 @@ static void mfma2_geometry(const FirArgs& a, int MB, int NPG, Mfma2Args& m, size
     // |limb sum| <= (bytes of a group's window) * 255 * 128; below 2^23 the pairs recombine in int32
     m.wide = m2_unmask0(NPG) ? 0u : ((uint64_t)NPG * 8u * 255u * 128u >= (1u << 23) ? 1u : 0u);
     m.fbits = a.scale_bits - ((int)a.epi.bits - 1);
-    static const char* noint = getenv("D2D_NO_INTQ");
+    const bool noint = (a.dbg_flags & D2D_DBG_NO_INTQ) != 0;
     // (the fast form carries v0 = v + 2^S in an int32: 2^S + sum|q| has to stay below 2^31)
     m.intq = (!noint && !a.to_scratch && a.epi.bits != 32 && a.epi.gain == 1.0 && !m.wide && m.fbits > 0 && m.fbits <= 16 &&
               a.sum_abs_q != 0 && (1ull << a.scale_bits) + a.sum_abs_q < (1ull << 31)) ? 1u : 0u;
     // stereo 16/24-bit (dither T, R, none) or float (no float dither) frames at another level than 0 dB, and 20-bit frames and the float dither (the CLI's default for -b 32) at any level
     // (the all-integer requantiser has no 20-in-24 form; the f64 one shifts its result)
-    const char* nogain = getenv("D2D_NO_GAINQ");           // (read at every engine creation: the tests switch it inside one process)
-    m.gainq = (!noint && !(nogain && atoi(nogain)) && !a.to_scratch && a.epi.channels == 2 && (a.epi.gain != 1.0 || m.qsh != 0 || (a.epi.bits == 32 && a.epi.dither == 'F')) && !m.wide &&
+    m.gainq = (!noint && !(a.dbg_flags & D2D_DBG_NO_GAINQ) && !a.to_scratch && a.epi.channels == 2 && (a.epi.gain != 1.0 || m.qsh != 0 || (a.epi.bits == 32 && a.epi.dither == 'F')) && !m.wide &&
                (a.epi.dither != 'F' || a.epi.bits == 32) && a.epi.dither != 'N' && (a.epi.bits == 32 || (m.fbits > 0 && m.fbits <= 16)) && a.sum_abs_q != 0 && a.sum_abs_q < (1ull << 31)) ? 1u : 0u;
     m.off_waves = (uint32_t)(2 * NPG) * 1024u;
     m.off_out = (uint32_t)m2_stream_bytes(MB, NPG);
     // (only the LDS-staged epilogue needs the output slice)
     const bool lds_out = mfma2_epilogue(a, m) == 0;
     m.wave_lds = m.off_out + (lds_out ? (((uint32_t)M2_TILE * C * a.epi.sample_bytes + 15u) & ~15u) : 0u);
-    { static const char* e = getenv("D2D_DBG"); m.dbg = e ? (uint32_t)atoi(e) : 0u; }
-    static const char* wenv = getenv("D2D_MFMA_WAVES");   // diagnostic override
-    m.nwaves = wenv ? (uint32_t)atoi(wenv) : 12u;
+#if D2D_DIAG
+    { static const char* e = getenv("D2D_DBG"); m.dbg = e ? (uint32_t)atoi(e) : 0u; }     // (make DIAG=1 builds only: never the shipped library)
+#endif
+    const uint32_t wdbg = (a.dbg_flags >> 8) & 0xFFu;      // diagnostic override (d2d_params.debug_flags bits 8..15)
+    m.nwaves = wdbg ? wdbg : 12u;
     if (m.nwaves < 1 || m.nwaves > 12) m.nwaves = 12;
     // largest block that fits the CU's LDS, keeping the waves evenly spread over the four SIMDs
     while (m.nwaves > 1 && (size_t)m.off_waves + (size_t)m.nwaves * m.wave_lds > 160 * 1024)

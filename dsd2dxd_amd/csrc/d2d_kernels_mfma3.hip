@@ -71,29 +71,10 @@ __device__ __forceinline__ int32_t m3_max3(int32_t x, int32_t y, int32_t z) {
 
 typedef int v8i __attribute__((ext_vector_type(8)));
 
-// ---- geometry of the structured-sparse chain (NT = taps > 0) ----
-// One matrix column serves 16 consecutive outputs (two row blocks of 8 phases).  A step covers 32 "lo" bit times t of the
-// column's window together with their partners t + N: phase ph needs the bit at t iff M*ph <= t < M*ph + N and the bit at
-// t + N iff t < M*ph -- never both, so a row of v_smfmac_i32_32x32x64_i8 (2:4 sparsity along K) holds ONE tap per
-// (t, t + N) pair and the zero blocks of the dense formulation (a third of its MFMAs) are never issued: ceil(max(N, 15 M) / 32)
-// steps of two MFMAs instead of 2 * (NPG + MB) steps of two.  Row block 1 reads block 0's tap fragments M/4 steps later.
-__host__ __device__ constexpr int m4_nst(int MB, int NT) { return ((NT > 120 * MB ? NT : 120 * MB) + 31) / 32; }
-__host__ __device__ constexpr int m4_delay(int MB) { return 2 * MB; }                       // 8 M / 32 steps
-__host__ __device__ constexpr int m4_nfr(int MB, int NT) { return m4_nst(MB, NT) + m4_delay(MB); }
-__host__ __device__ constexpr int m4_rowdw(int MB, int NT) { return m4_nst(MB, NT) + NT / 32 + 2; }
-__host__ __device__ constexpr int m4_chunks(int MB, int NT) { return (31 * 4 * MB + m4_rowdw(MB, NT) + 3 + 3) / 4; }
-__host__ __device__ constexpr int m4_pf(int MB, int NT) { return (m4_chunks(MB, NT) + 63) / 64; }
-__host__ __device__ constexpr int m4_stream_bytes(int MB, int NT) {
-    const int dw = 4 * 64 * m4_pf(MB, NT);
-    const int lsh = MB == 1 ? 2 : MB == 2 ? 3 : MB == 4 ? 4 : MB == 8 ? 5 : 6;
-    return (((dw + (dw >> lsh) + 4) * 4 + 15) & ~15) + 16;
-}
-constexpr int M4_FRAG_BYTES = 1280;          // a tap fragment: 64 lanes x 16 compressed int8, then 64 index words
-
 // KIND: 0 no dither, 1 triangular, 2 rectangular (unit gain, all-integer requantiser); 4, 5, 6: the same dithers at any level in dB (f64
 // requantiser, M = 8 and 16).  Stereo; SBY = bytes per sample: 3 (24-bit packed frames), 2 (16-bit) or
 // 4 (32-bit float, KIND 0 only: the sample is (float)v * 2^-S, one rounding like the oracle's (float)(double)).
-// NT = 0: the dense chain (tables of build_mfma2_tables); NT = taps: the structured-sparse chain (build_mfma4_tables).
+// NT = 0 (the parameter once selected a structured-sparse chain, measured slower in round 2 and retired in round 4: profiles/r02_experiments.txt).
 #ifndef D2D_M3_SCR_AF
 #define D2D_M3_SCR_AF 0           // 1: the scratch flavour walks the call's inner tiles in the fixed-order loop too -- measured SLOWER (DSD64 -> 96 kHz 7.55-7.72
                                   // against 7.14-7.31 ms per step in one lease, profiles/r03_experiments.txt item 13): the general loop stays
@@ -102,18 +83,18 @@ template <int MB, int NPG, int NT, int KIND, int SBY>
 __global__ __launch_bounds__(D2D_M3_THREADS) void d2d_fir_mfma3_kernel(Mfma2Args m) {
     using G = M2Geom<MB>;
     constexpr int RS = G::RS, LSH = G::LSH;
-    constexpr bool SP = NT > 0;
+    static_assert(NT == 0, "the dense chain");
     // KIND = dither kind DK (0 none, 1 triangular, 2 rectangular), + 4 (GN) for any level in dB: the requantiser then follows the f64
     // definition operation by operation -- x = fl(v * (scale * 2^-S)), q = x + d, round half away, clip -- behind the same chains; it
     // has no careful path (nothing about it depends on the tile)
     constexpr int DK = KIND & 3;
     constexpr bool GN = KIND >= 4;
     constexpr uint32_t FB = 2u * (SBY ? SBY : 1);                   // bytes per stereo frame
-    constexpr int TP = SP ? m4_nst(MB, NT) : NPG + MB;              // steps of one chain
-    constexpr int NCHK = SP ? m4_chunks(MB, NT) : m2_chunks(MB, NPG);
-    constexpr int PF = SP ? m4_pf(MB, NT) : m2_pf(MB, NPG);
-    constexpr uint32_t SB = (uint32_t)(SP ? m4_stream_bytes(MB, NT) : m2_stream_bytes(MB, NPG));
-    constexpr uint32_t TBL16 = SP ? (uint32_t)m4_nfr(MB, NT) * (M4_FRAG_BYTES / 16) : 2u * NPG * 64u;   // 16-byte units of one table variant
+    constexpr int TP = NPG + MB;                                    // steps of one chain
+    constexpr int NCHK = m2_chunks(MB, NPG);
+    constexpr int PF = m2_pf(MB, NPG);
+    constexpr uint32_t SB = (uint32_t)m2_stream_bytes(MB, NPG);
+    constexpr uint32_t TBL16 = 2u * NPG * 64u;                      // 16-byte units of one table variant
     const FirArgs& a = m.f;
     constexpr uint32_t dbg = D2D_M3_ABL;                  // compile-time ablation mask (tools/ab_build.sh <name> -DD2D_M3_ABL=<mask>): 1 no chain, 2 no epilogue, 4 no staging, 8 never slow, 16 zero taps, 64 no stores
     extern __shared__ __align__(16) unsigned char smem[];
@@ -296,64 +277,9 @@ __global__ __launch_bounds__(D2D_M3_THREADS) void d2d_fir_mfma3_kernel(Mfma2Args
             __builtin_amdgcn_sched_barrier(0);
         });
     };
-    // The structured-sparse chain.  Step s, lane half h: lo bytes 4s + 2h, 4s + 2h + 1 of the row window (staged dword s) and
-    // their partners N/8 bytes further on are gathered into one dword P = [lo0 lo1 hi0 hi1] (v_perm_b32); P & plane mask p is B
-    // register p (one 2:4 group: positions 0, 1 = the lo bits, 2, 3 = their partners).  Lo bytes at or past N/8 are zeroed in P:
-    // those bit times are served as partners, so every (bit, phase) pair is counted once whichever row block looks at it.
-    constexpr int NB = SP ? NT / 8 : 4, NBQ = NB % 4, HD0 = NB / 4, DLY = m4_delay(MB), NFR = SP ? m4_nfr(MB, NT) : 1;
-    static_assert(!SP || (NT % 16 == 0 && (NBQ == 0 || NBQ == 2)), "taps: a multiple of 16");
-    const uint8_t* frag0 = smem + 16u * lane;                       // fragment f: 16 compressed bytes at frag0 + 1280 f, ...
-    const uint8_t* fidx0 = smem + 1024u + 4u * lane;                // ... its index word at fidx0 + 1280 f
-    // selectors of v_perm_b32(hi dword, lo dword): bytes 0-3 = lo dword, 4-7 = hi dword, 0x0c = zero
-    const uint32_t lo_sel = h ? 0x0302u : 0x0100u;
-    const uint32_t hi_sel = (NBQ == 2 ? (h ? 0x0504u : 0x0706u) : (h ? 0x0706u : 0x0504u)) << 16;
-    uint32_t selN = hi_sel | lo_sel, selZ = hi_sel | 0x0c0cu, selT = h ? selZ : selN;
-    asm volatile("" : "+v"(selN), "+v"(selZ), "+v"(selT));
-    v4i zero4 = {0, 0, 0, 0}, zero4b = {0, 0, 0, 0};                // (two opaque copies: the two loads below must not be merged into one + 16 moves)
-    asm volatile("" : "+v"(zero4), "+v"(zero4b));
-    auto chain_sparse = [&](const uint8_t* rowb, v16i& acc0, v16i& acc1, auto&& hook) {
-        // rowb = the lane's row base in the channel's stream buffer; the partner of half 1 sits one dword further when N/8 % 4 == 2,
-        // and one more where that step crosses a pad dword
-        const uint8_t* bH = rowb + (NBQ == 2 ? 4u * h : 0u);
-        const uint8_t* bH2 = rowb + (NBQ == 2 ? 8u * h : 0u);
-        uint32_t Wl[TP], Wh[TP];
-        v4i FA[NFR]; int FI[NFR];
-        auto rdW = [&](auto sc) {
-            constexpr int s = decltype(sc)::value;
-            constexpr int L = s + HD0;
-            Wl[s] = *reinterpret_cast<const uint32_t*>(rowb + 4 * (s + (s >> LSH)));
-            if constexpr (NBQ == 2 && ((L + 1) % RS) == 0) Wh[s] = *reinterpret_cast<const uint32_t*>(bH2 + 4 * (L + (L >> LSH)));
-            else Wh[s] = *reinterpret_cast<const uint32_t*>(bH + 4 * (L + (L >> LSH)));
-        };
-        auto rdF = [&](auto fc) {
-            constexpr int f = decltype(fc)::value;
-            FA[f] = *reinterpret_cast<const v4i*>(frag0 + M4_FRAG_BYTES * f);
-            FI[f] = *reinterpret_cast<const int*>(fidx0 + M4_FRAG_BYTES * f);
-        };
-        constexpr int AHEAD = 2;
-        // block 1 needs fragments 0 .. DLY-1 during its first DLY steps, block 0 starts at fragment DLY
-        static_for<0, DLY + AHEAD>([&](auto fc) { if constexpr (decltype(fc)::value < NFR) rdF(fc); });
-        static_for<0, AHEAD>([&](auto sc) { rdW(sc); });
-        acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(zero4, zero4, cinit, 0, 0, 0);      // the sparse MFMA accumulates in place: load -2^S
-        acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(zero4b, zero4b, cinit, 0, 0, 0);
-        static_for<0, TP>([&](auto sc) {
-            constexpr int s = decltype(sc)::value;
-            if constexpr (s + AHEAD < TP) rdW(std::integral_constant<int, s + AHEAD>{});
-            if constexpr (s + DLY + AHEAD < NFR) rdF(std::integral_constant<int, s + DLY + AHEAD>{});
-            const uint32_t sel = 4 * s + 2 < NB ? selN : (4 * s >= NB ? selZ : selT);
-            const uint32_t P = __builtin_amdgcn_perm(Wh[s], Wl[s], sel);
-            const v8i B = {(int)(P & km[0]), (int)(P & km[1]), (int)(P & km[2]), (int)(P & km[3]),
-                           (int)(P & km[4]), (int)(P & km[5]), (int)(P & km[6]), (int)(P & km[7])};
-            acc0 = __builtin_amdgcn_smfmac_i32_32x32x64_i8(FA[s + DLY], B, acc0, FI[s + DLY], 0, 0);
-            acc1 = __builtin_amdgcn_smfmac_i32_32x32x64_i8(FA[s], B, acc1, FI[s], 0, 0);
-            hook(sc);
-            __builtin_amdgcn_sched_barrier(0);
-        });
-    };
     // the channel's chain: c = 0 / 1 picks the stream buffer
     auto chain = [&](uint32_t c, v16i& acc0, v16i& acc1, auto&& hook) {
-        if constexpr (SP) chain_sparse(wbase + c * SB + 4u * (RS + 1) * r, acc0, acc1, hook);
-        else chain_dense(wbase + c * SB + 4u * ((RS + 1) * r + h), acc0, acc1, hook);
+        chain_dense(wbase + c * SB + 4u * ((RS + 1) * r + h), acc0, acc1, hook);
     };
     auto no_hook = [](auto) {};
 
@@ -863,40 +789,6 @@ static inline int8_t limb_of4(int64_t v, int l) {
     return dgt;
 }
 
-// Tap fragments of the structured-sparse chain: [4 byte shifts][NFR fragments][1024 bytes A | 64 index words].  Fragment f serves
-// step f - DLY of a row block.  Operand layout of v_smfmac_i32_32x32x64_i8 (measured, tools/ubench/smfmac_probe.hip): A lane l =
-// matrix row l & 31, half ah = l >> 5; its byte e belongs to 2:4 group g = e >> 1 and multiplies byte (idx >> 2e & 3) of B register
-// (g & 3) + 4 ah in lane half g >> 2.  Here B register p = bit plane p of P = [lo0 lo1 hi0 hi1], so byte e = 2g + n of lane
-// (row, ah) carries the tap of pair n (staged lo byte 4 s + 2 (g >> 2) + n, or its partner N/8 bytes on) at plane 4 ah + (g & 3).
-std::vector<int8_t> build_mfma4_tables(const d2d_filter_def& f, bool msb_first) {
-    const int M = f.M, N = f.ntaps, MB = M / 8;
-    const int DLY = m4_delay(MB), NFR = m4_nfr(MB, N);
-    const size_t per = (size_t)NFR * M4_FRAG_BYTES;
-    std::vector<int8_t> t(4 * per, 0);
-    for (int sh = 0; sh < 4; ++sh)
-        for (int fr = 0; fr < NFR; ++fr)
-            for (int l = 0; l < 64; ++l) {
-                const int row = l & 31, ah = l >> 5, limb = row & 3;
-                // D row i lands in lane half (i >> 2) & 1, register group i >> 3: phase 4 * half + group (as in build_mfma2_tables)
-                const int ph = 4 * ((row >> 2) & 1) + (row >> 3);
-                uint32_t idx = 0;
-                for (int e = 0; e < 16; ++e) {
-                    const int g = e >> 1, n = e & 1, p = 4 * ah + (g & 3), hh = g >> 2;
-                    const int bl = 4 * (fr - DLY) + 2 * hh + n;                         // staged row byte of the pair's lo element
-                    const int tau = 8 * (bl - sh) + (msb_first ? 7 - p : p);            // its time index in the window
-                    const int klo = tau - ph * M, khi = klo + N;
-                    int k = -1, pos = n;
-                    if (klo >= 0 && klo < N) { k = klo; pos = n; }
-                    else if (khi >= 0 && khi < N) { k = khi; pos = 2 + n; }
-                    int64_t T = 0;
-                    if (k >= 0) { const int64_t q = tap_q(f, k); T = p == 7 ? -q : q * (int64_t)(1 << (7 - p)); }   // plane p arrives as 2^p (p = 7: -128)
-                    t[sh * per + (size_t)fr * M4_FRAG_BYTES + (size_t)l * 16 + e] = limb_of4(T, limb);
-                    idx |= (uint32_t)pos << (2 * e);
-                }
-                memcpy(&t[sh * per + (size_t)fr * M4_FRAG_BYTES + 1024 + (size_t)l * 4], &idx, 4);
-            }
-    return t;
-}
 
 #endif
 
@@ -908,12 +800,12 @@ static hipError_t launch_mfma3_t(Mfma2Args& m, uint32_t nwt_max, uint32_t nrows,
     hipError_t e = prep.max_dynamic_lds(fn, 160 * 1024, &dev);
     if (e != hipSuccess) return e;
     // LDS: the shared tap table, then two stream buffers per wave; eight waves per block = two per SIMD
-    m.off_waves = NT ? (uint32_t)m4_nfr(MB, NT) * M4_FRAG_BYTES : (uint32_t)(2 * NPG) * 1024u;
-    m.wave_lds = 2u * (uint32_t)(NT ? m4_stream_bytes(MB, NT) : m2_stream_bytes(MB, NPG));
+    m.off_waves = (uint32_t)(2 * NPG) * 1024u;
+    m.wave_lds = 2u * (uint32_t)m2_stream_bytes(MB, NPG);
     m.off_out = m.wave_lds;
     if (D2D_M3_STAGED && MB == 1 && SBY != 0) m.wave_lds += (uint32_t)M2_TILE * 2u * SBY;     // the tile's frames, staged for whole-line stores
-    static const char* wenv = getenv("D2D_MFMA_WAVES");   // diagnostic override
-    m.nwaves = wenv ? (uint32_t)atoi(wenv) : 8u;
+    const uint32_t wdbg = (m.f.dbg_flags >> 8) & 0xFFu;   // diagnostic override (d2d_params.debug_flags bits 8..15)
+    m.nwaves = wdbg ? wdbg : 8u;
     if (m.nwaves < 1 || m.nwaves > 8) m.nwaves = 8;
     while (m.nwaves > 1 && (size_t)m.off_waves + (size_t)m.nwaves * m.wave_lds > 160 * 1024) m.nwaves >>= 1;
     const size_t smem = (size_t)m.off_waves + (size_t)m.nwaves * m.wave_lds;
@@ -984,22 +876,15 @@ hipError_t launch_fir_mfma3_s16(Mfma2Args& m, int MB, int NPG, int NT, uint32_t 
 #else
 hipError_t launch_fir_mfma3_s16(Mfma2Args& m, int MB, int NPG, int NT, uint32_t nwt_max, uint32_t nrows, hipStream_t s);
 hipError_t launch_fir_mfma3_scr(Mfma2Args& m, int MB, int NPG, uint32_t nwt_max, uint32_t nrows, hipStream_t s);
-// variant 3: the dense chain, 4: the structured-sparse chain (24-bit frames only)
 hipError_t launch_fir_mfma3(Mfma2Args& m, int variant, int MB, int NPG, int NT, uint32_t nwt_max, uint32_t nrows, hipStream_t s) {
     if (m.f.to_scratch) return launch_fir_mfma3_scr(m, MB, NPG, nwt_max, nrows, s);
     if (m.f.epi.sample_bytes != 3) return launch_fir_mfma3_s16(m, MB, NPG, NT, nwt_max, nrows, s);     // 16-bit and float frames: part 1
-    if (variant == 4) {          // the sparse chain is an experiment: compiled for the E filters only
-        if (MB == 4 && NT == 560) K3(4, 13, 560, 3)
-#ifndef D2D_M2_DEV
-        if (MB == 8 && NT == 1104) K3(8, 25, 1104, 3)
-#endif
-    }
+    (void)variant;
 #define X(mb, npg, nt) if (MB == mb && NPG == npg && NT == nt) K3(mb, npg, 0, 3)
     D2D_M3_SHAPES(X)
 #undef X
     return hipErrorInvalidValue;
 }
-bool mfma3_sparse_compiled(int MB, int NT) { return (MB == 4 && NT == 560) || (MB == 8 && NT == 1104); }
 #endif
 #undef K3
 

@@ -989,8 +989,8 @@ static hipError_t launch_mx_t(Mfma2Args& m, uint32_t max_nout, uint32_t nrows, h
     m.off_waves = (uint32_t)mx_nf(MB, NT) * MX_FRAG_BYTES;
     m.off_out = 2u * (uint32_t)mx_stream_bytes(MB, NT, G);
     m.wave_lds = m.off_out + (SBY ? 2u * TILE * 4u : 0u);
-    static const char* wenv = getenv("D2D_MFMA_WAVES");   // diagnostic override
-    uint32_t nwaves = wenv ? (uint32_t)atoi(wenv) : (uint32_t)(D2D_MX_THREADS / 64);
+    const uint32_t wdbg = (m.f.dbg_flags >> 8) & 0xFFu;   // diagnostic override (d2d_params.debug_flags bits 8..15)
+    uint32_t nwaves = wdbg ? wdbg : (uint32_t)(D2D_MX_THREADS / 64);
     if (nwaves < 1 || nwaves > D2D_MX_THREADS / 64) nwaves = D2D_MX_THREADS / 64;
     while (nwaves > 1 && (size_t)m.off_waves + (size_t)nwaves * m.wave_lds > 160 * 1024) nwaves >>= 1;
     const bool coop = SBY == 0 && m.f.coop;                 // a block = all channel pairs of a file on one tile: one wave per pair, one grid row per file

@@ -99,10 +99,10 @@ __global__ __launch_bounds__(PX_THREADS) void d2d_fir_px_kernel(PxArgs a) {
     asm volatile("" : "+v"(kmA), "+v"(kmB));
     int scA = 0x7f7f7f7f, scB = (int)0x82828282u;                     // e8m0 scales: A x 1, B x 8 (every product becomes an integer)
     asm volatile("" : "+v"(scA), "+v"(scB));
-    // accumulators start from -2^S: the digit-4 rows (weight 2^20) of every sample, so that the digits recombine to v = 2 sum Q b - 2^S = sum Q s
-    px_v16f cinit;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) cinit[i] = (i < 15 && (i % 5) == 4) ? -(float)(1 << (a.S - 20)) : 0.0f;
+    // the accumulators start from zero (an inline constant: no registers) and hold sum 2 Q b; the -2^S that makes it v = 2 sum Q b - 2^S = sum Q s
+    // rides in the recombination: hi = S3 + 32 S4 - 2^(S-15), exact in f32 (px_exact)
+    const px_v16f cinit = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const float kNegBias = -(float)(1 << (a.S - 15));
 
     const int F = a.fbits;
     const float k32 = 32.0f, k1024 = 1024.0f;
@@ -130,9 +130,26 @@ __global__ __launch_bounds__(PX_THREADS) void d2d_fir_px_kernel(PxArgs a) {
     auto tile_a0 = [&](uint32_t t) -> int32_t { return (int32_t)((tile_br(t) >> 3) & ~(int64_t)15); };
     // FAST tiles: every chunk lies inside the call's full power-of-two blocks -- one straight block of 16-byte loads into the prefetch
     // registers, nothing else (a gather path that met this one at a join made the compiler copy the registers, i.e. wait, right there)
-    auto is_fast = [&](uint32_t t) -> bool { const int32_t a0 = tile_a0(t); return fast_layout && a0 >= 0 && (uint32_t)a0 + 16u * (uint32_t)NCHK <= full_bytes; };
+    // IL (a.il2: byte-interleaved stereo -- DFF files, the reference CLI's default -f I -- both channels converted): the tile's frames come
+    // as they lie in memory, 2 NCHK pieces of 16 bytes = eight frames each, in the same registers; two v_perm_b32 per channel pull a piece apart
+    const bool il = a.il2 != 0;
+    auto is_fast = [&](uint32_t t) -> bool {
+        const int32_t a0 = tile_a0(t);
+        return a0 >= 0 && (il ? (uint32_t)a0 + 16u * (uint32_t)NCHK <= Lcall : fast_layout && (uint32_t)a0 + 16u * (uint32_t)NCHK <= full_bytes);
+    };
     auto issue = [&](uint32_t t) {
         const uint32_t a0 = (uint32_t)tile_a0(t);
+        if (il) {
+            const D2D_GLOBAL uint8_t* src = as_global(j0.in) + 2u * (size_t)a0;
+#pragma unroll
+            for (int j = 0; j < 2 * PF; ++j) {
+                uint32_t k = lane + 64u * j;
+                k = k < 2u * (uint32_t)NCHK ? k : 2u * (uint32_t)NCHK - 1u;
+                if (dbg & 4) pf[j / PF][j % PF] = u32x4{0u, 0u, 0u, 0u};
+                else pf[j / PF][j % PF] = *reinterpret_cast<D2D_GLOBAL const u32x4*>(src + 16u * k);
+            }
+            return;
+        }
         // (channel 1 of a mono group re-reads channel 0's bytes; nothing is written from them)
 #pragma unroll
         for (int c = 0; c < 2; ++c)
@@ -150,6 +167,18 @@ __global__ __launch_bounds__(PX_THREADS) void d2d_fir_px_kernel(PxArgs a) {
         *reinterpret_cast<u32x4*>(wbase + c * SB + 16u * ck) = v;
     };
     auto commit = [&]() {
+        if (il) {
+#pragma unroll
+            for (int j = 0; j < 2 * PF; ++j) {
+                const uint32_t k = lane + 64u * j;
+                const u32x4 p4 = pf[j / PF][j % PF];
+                u32x2 c0 = {__builtin_amdgcn_perm(p4.y, p4.x, 0x06040200u), __builtin_amdgcn_perm(p4.w, p4.z, 0x06040200u)};
+                u32x2 c1 = {__builtin_amdgcn_perm(p4.y, p4.x, 0x07050301u), __builtin_amdgcn_perm(p4.w, p4.z, 0x07050301u)};
+                if (a.msb) { c0 = u32x2{px_lsb_first(c0.x), px_lsb_first(c0.y)}; c1 = u32x2{px_lsb_first(c1.x), px_lsb_first(c1.y)}; }
+                if (k < 2u * (uint32_t)NCHK) { *reinterpret_cast<u32x2*>(wbase + 8u * k) = c0; *reinterpret_cast<u32x2*>(wbase + SB + 8u * k) = c1; }
+            }
+            return;
+        }
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
             if ((uint32_t)c >= cwn) continue;
@@ -166,118 +195,119 @@ __global__ __launch_bounds__(PX_THREADS) void d2d_fir_px_kernel(PxArgs a) {
             for (uint32_t ck = lane; ck < (uint32_t)NCHK; ck += 64) put(c, ck, gather_chunk(jobs + c, Ct, a.B, a.keep, a0 + (int32_t)(16u * ck)));
     };
 
-    // One tile from its staged image: the chains of the group's channels, their epilogues, the frames
-    auto convert_tile = [&](uint32_t t) {
-        const uint64_t mT = (T0 + t) * (uint32_t)TILE;
-        const int64_t br = tile_br(t);
-        const uint32_t obit = (uint32_t)(br - 8 * (int64_t)tile_a0(t));      // column 0 starts at this bit (0 .. 127) of the image
-        const int64_t nl0 = (int64_t)(mT - m0);                               // the tile's first output, relative to the call's (may be negative)
-
-        const uint32_t cbit = obit + (uint32_t)SBITS * n;             // the lane's column starts at this bit of the image
+    // ---- the chain of channel c for the lane's column (it starts at bit `cbit` of the channel's image): TP steps of 64 stream bits, group g
+    // takes part in steps u0(g) .. u1(g); `hook(k)` is whatever else the wave does behind its k-th matrix instruction ----
+    auto chain = [&](uint32_t c, uint32_t cbit, px_v16f (&acc)[G], auto&& hook) {
+        const uint8_t* rb = wbase + c * SB + 4u * ((cbit >> 5) + kh);
         const uint32_t shn = cbit & 31u;
-        static_for<0, 2>([&](auto cc) {
-            constexpr uint32_t c = (uint32_t)decltype(cc)::value;
-            if (c >= cwn) return;
-            // ---- the chain: TP steps of 64 stream bits; group g takes part in steps u0(g) .. u1(g) ----
-            const uint8_t* rb = wbase + c * SB + 4u * ((cbit >> 5) + kh);
-            px_v16f acc[G];
-            if constexpr ((dbg & 1) != 0) {
+        if constexpr ((dbg & 1) != 0) {
 #pragma unroll
-                for (int g = 0; g < G; ++g) { acc[g] = cinit + (float)(lane + g); asm volatile("" : "+v"(acc[g])); }
-            } else {
-                // LDS reads are issued ahead of their use (stream dwords AW steps, tap fragments AF matrix instructions) and every matrix
-                // instruction is fenced, so that the compiler neither hoists all the fragment reads (258 registers) nor sinks them
-                constexpr int AW = 2, AF = 3;
-                uint32_t D0[TP], D1[TP];
-                v4i F4[NSLOT]; u32x2 F2[NSLOT];
-                auto rdW = [&](auto uc) {
-                    constexpr int u = decltype(uc)::value;
-                    D0[u] = *reinterpret_cast<const uint32_t*>(rb + 8 * u); D1[u] = *reinterpret_cast<const uint32_t*>(rb + 8 * u + 4);
-                };
-                auto rdF = [&](auto kc) {
-                    constexpr int k = decltype(kc)::value;
-                    F4[k] = *reinterpret_cast<const v4i*>(tp16 + PX_FRAG_BYTES * k);
-                    F2[k] = *reinterpret_cast<const u32x2*>(tp8 + PX_FRAG_BYTES * k);
-                };
-                static_for<0, (AW < TP ? AW : TP)>([&](auto uc) { rdW(uc); });
-                static_for<0, (AF < NSLOT ? AF : NSLOT)>([&](auto kc) { rdF(kc); });
-                px_v8i Bv = {0, 0, 0, 0, 0, 0, 0, 0};
-                static_for<0, NSLOT>([&](auto kc) {
-                    constexpr int k = decltype(kc)::value;
-                    constexpr int u = px_slot_u(LP, MP, NP, G, k), g = px_slot_g(LP, MP, NP, G, k);
-                    if constexpr (k == 0 || px_slot_u(LP, MP, NP, G, k > 0 ? k - 1 : 0) != u) {      // the step's first matrix instruction: its operand
-                        if constexpr (u + AW < TP) rdW(std::integral_constant<int, u + AW>{});
-                        const uint32_t w = __builtin_amdgcn_alignbit(D1[u], D0[u], shn), w2 = w >> 2;
-                        Bv = px_v8i{(int)(w & kmA), (int)(w & kmB), (int)(w2 & kmA), (int)(w2 & kmB), 0, 0, 0, 0};
-                    }
-                    if constexpr (k + AF < NSLOT) rdF(std::integral_constant<int, k + AF>{});
-                    const px_v8i Av = {F4[k].x, F4[k].y, F4[k].z, F4[k].w, (int)F2[k].x, (int)F2[k].y, 0, 0};
-                    if constexpr (u == px_u0(LP, MP, g)) acc[g] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(Av, Bv, cinit, 2, 4, 0, scA, 0, scB);
-                    else acc[g] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(Av, Bv, acc[g], 2, 4, 0, scA, 0, scB);
-                    __builtin_amdgcn_sched_barrier(0);
-                });
-                // the chain ends HERE (or the compiler sinks each group's matrix instructions into the block that uses its sums)
-#pragma unroll
-                for (int g = 0; g < G; ++g) asm volatile("" : "+v"(acc[g]));
+            for (int g = 0; g < G; ++g) { acc[g] = cinit + (float)(lane + g); asm volatile("" : "+v"(acc[g])); }
+            static_for<0, NSLOT>([&](auto kc) { hook(kc); });
+            return;
+        }
+        // LDS reads are issued ahead of their use (stream dwords AW steps, tap fragments AF matrix instructions) and every matrix
+        // instruction is fenced, so that the compiler neither hoists all the fragment reads (258 registers) nor sinks them
+        constexpr int AW = 2, AF = 3;
+        uint32_t D0[TP], D1[TP];
+        v4i F4[NSLOT]; u32x2 F2[NSLOT];
+        auto rdW = [&](auto uc) {
+            constexpr int u = decltype(uc)::value;
+            D0[u] = *reinterpret_cast<const uint32_t*>(rb + 8 * u); D1[u] = *reinterpret_cast<const uint32_t*>(rb + 8 * u + 4);
+        };
+        auto rdF = [&](auto kc) {
+            constexpr int k = decltype(kc)::value;
+            F4[k] = *reinterpret_cast<const v4i*>(tp16 + PX_FRAG_BYTES * k);
+            F2[k] = *reinterpret_cast<const u32x2*>(tp8 + PX_FRAG_BYTES * k);
+        };
+        static_for<0, (AW < TP ? AW : TP)>([&](auto uc) { rdW(uc); });
+        static_for<0, (AF < NSLOT ? AF : NSLOT)>([&](auto kc) { rdF(kc); });
+        px_v8i Bv = {0, 0, 0, 0, 0, 0, 0, 0};
+        static_for<0, NSLOT>([&](auto kc) {
+            constexpr int k = decltype(kc)::value;
+            constexpr int u = px_slot_u(LP, MP, NP, G, k), g = px_slot_g(LP, MP, NP, G, k);
+            if constexpr (k == 0 || px_slot_u(LP, MP, NP, G, k > 0 ? k - 1 : 0) != u) {      // the step's first matrix instruction: its operand
+                if constexpr (u + AW < TP) rdW(std::integral_constant<int, u + AW>{});
+                const uint32_t w = __builtin_amdgcn_alignbit(D1[u], D0[u], shn), w2 = w >> 2;
+                Bv = px_v8i{(int)(w & kmA), (int)(w & kmB), (int)(w2 & kmA), (int)(w2 & kmB), 0, 0, 0, 0};
             }
-
-            // ---- epilogue: the lane's samples of this channel: outputs 3 kh + i of every group (half 1 owns two) ----
-            const uint32_t rkey = rkeys[c], rstep = rsteps[c], rlo0 = rlo0s[c];
-            uint32_t vm = 0;
-            static_for<0, G>([&](auto gc) {
-                constexpr int g = decltype(gc)::value;
-#pragma unroll
-                for (int i = 0; i < 3; ++i) {
-                    const uint32_t o = (uint32_t)OC * n + 5u * g + 3u * kh + (uint32_t)i;       // output inside the tile
-                    const int64_t nl = nl0 + (int64_t)o;
-                    const bool live = (i < 2 || kh == 0) && (uint64_t)nl < (uint64_t)nout;
-                    // v = sum Q s: the digits S0 .. S4 of sample i are registers 5 i .. 5 i + 4 (exact integers in f32)
-                    const float lo = __builtin_fmaf(acc[g][5 * i + 2], k1024, __builtin_fmaf(acc[g][5 * i + 1], k32, acc[g][5 * i]));
-                    const float hi = __builtin_fmaf(acc[g][5 * i + 4], k32, acc[g][5 * i + 3]);
-                    const int32_t v = (int32_t)(((uint32_t)(int32_t)hi << 15) + (uint32_t)(int32_t)lo);
-                    const uint32_t va = (uint32_t)(v < 0 ? -v : v);
-                    vm = max(vm, live ? va : 0u);
-                    int32_t rv;
-                    if constexpr (KIND == 4 || (dbg & 2) != 0) {
-                        rv = v;
-                    } else {
-                        uint32_t z = 0;
-                        if constexpr (KIND != 0) {
-                            const uint32_t nlo = (uint32_t)m0 + (uint32_t)nl;                  // lo32 of the absolute output index
-                            z = nlo + rkey + (nlo < rlo0 ? rstep : 0u);
-                            z ^= z >> 16; z *= 0x7feb352dU;
-                            z ^= z >> 15; z *= 0x846ca68bU;
-                            z ^= z >> 16;
-                        }
-                        if constexpr (KIND == 3) {
-                            const double x = (double)v * kCg;
-                            rv = a.epi.bits == 32 ? __float_as_int(finish_f32(a.epi, x, z)) : finish_int(a.epi, x, z);
-                        } else {
-                            // x = v * 2^-F LSB, dither in 2^-16 (2^-17) LSB, round half away from zero, clip: all integers
-                            const int32_t vh = v >> F;
-                            const uint32_t vl = (uint32_t)v & ((1u << F) - 1u);
-                            int32_t rr;
-                            if constexpr (KIND == 2) {
-                                const int32_t w = (int32_t)(vl << (17 - F)) + (int32_t)(2u * (z >> 16) + 1u) - 65536;
-                                const int32_t neg = (vh + (w >> 17)) >> 31;
-                                rr = vh + ((w + 65536 + neg) >> 17);
-                            } else {
-                                int32_t w = (int32_t)(vl << (16 - F));
-                                if constexpr (KIND == 1) w += (int32_t)((z & 0xFFFFu) + (z >> 16)) - 65535;
-                                const int32_t neg = (vh + (w >> 16)) >> 31;
-                                rr = vh + ((w + 32768 + neg) >> 16);
-                            }
-                            rv = min(max(rr, a.qmin_i), a.qmax_i);
-                        }
-                    }
-                    if (i < 2 || kh == 0) ob[c * TILE + o] = rv;
-                }
-            });
-            vmax[c] = max(vmax[c], vm);
+            if constexpr (k + AF < NSLOT) rdF(std::integral_constant<int, k + AF>{});
+            const px_v8i Av = {F4[k].x, F4[k].y, F4[k].z, F4[k].w, (int)F2[k].x, (int)F2[k].y, 0, 0};
+            if constexpr (u == px_u0(LP, MP, g)) acc[g] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(Av, Bv, cinit, 2, 4, 0, scA, 0, scB);
+            else acc[g] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(Av, Bv, acc[g], 2, 4, 0, scA, 0, scB);
+            // (what rides along sits BEHIND a matrix instruction: an in-order wave that issues two back to back sits out the first one's 32 cycles)
+            hook(kc);
+            __builtin_amdgcn_sched_barrier(0);
         });
-        wave_sync2();
+        // the chain ends HERE (or the compiler sinks each group's matrix instructions into the block that uses its sums)
+#pragma unroll
+        for (int g = 0; g < G; ++g) asm volatile("" : "+v"(acc[g]));
+    };
+    auto no_hook = [](auto) {};
+    // v0 = v + 2^S = 2 sum Q b of sample i of a group's accumulators: the digits S0 .. S4 are registers 5 i .. 5 i + 4 (exact integers in f32)
+    auto recombine0 = [&](const px_v16f& A, int i) -> int32_t {
+        const float lo = __builtin_fmaf(A[5 * i + 2], k1024, __builtin_fmaf(A[5 * i + 1], k32, A[5 * i]));
+        const float hi = __builtin_fmaf(A[5 * i + 4], k32, A[5 * i + 3]);
+        return (int32_t)(((uint32_t)(int32_t)hi << 15) + (uint32_t)(int32_t)lo);
+    };
+    const int32_t kBias = 1 << a.S;
 
-        // ---- the tile's samples out of the slice ----
+    // ---- the epilogue of (tile, channel c) sample by sample, every case exact (clipping, rounding ties, outputs outside the call): the
+    // lane's samples are outputs 3 kh + i of every group (half 1 owns two) ----
+    auto epilogue_exact = [&](uint32_t c, const px_v16f (&acc)[G], int64_t nl0) {
+        const uint32_t rkey = rkeys[c], rstep = rsteps[c], rlo0 = rlo0s[c];
+        uint32_t vm = 0;
+        static_for<0, G>([&](auto gc) {
+            constexpr int g = decltype(gc)::value;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const uint32_t o = (uint32_t)OC * n + 5u * g + 3u * kh + (uint32_t)i;       // output inside the tile
+                const int64_t nl = nl0 + (int64_t)o;
+                const bool live = (i < 2 || kh == 0) && (uint64_t)nl < (uint64_t)nout;
+                const int32_t v = recombine0(acc[g], i) - kBias;
+                const uint32_t va = (uint32_t)(v < 0 ? -v : v);
+                vm = max(vm, live ? va : 0u);
+                int32_t rv;
+                if constexpr (KIND == 4 || (dbg & 2) != 0) {
+                    rv = v;
+                } else {
+                    uint32_t z = 0;
+                    if constexpr (KIND != 0) {
+                        const uint32_t nlo = (uint32_t)m0 + (uint32_t)nl;                  // lo32 of the absolute output index
+                        z = nlo + rkey + (nlo < rlo0 ? rstep : 0u);
+                        z ^= z >> 16; z *= 0x7feb352dU;
+                        z ^= z >> 15; z *= 0x846ca68bU;
+                        z ^= z >> 16;
+                    }
+                    if constexpr (KIND == 3) {
+                        const double x = (double)v * kCg;
+                        rv = a.epi.bits == 32 ? __float_as_int(finish_f32(a.epi, x, z)) : finish_int(a.epi, x, z);
+                    } else {
+                        // x = v * 2^-F LSB, dither in 2^-16 (2^-17) LSB, round half away from zero, clip: all integers
+                        const int32_t vh = v >> F;
+                        const uint32_t vl = (uint32_t)v & ((1u << F) - 1u);
+                        int32_t rr;
+                        if constexpr (KIND == 2) {
+                            const int32_t w = (int32_t)(vl << (17 - F)) + (int32_t)(2u * (z >> 16) + 1u) - 65536;
+                            const int32_t neg = (vh + (w >> 17)) >> 31;
+                            rr = vh + ((w + 65536 + neg) >> 17);
+                        } else {
+                            int32_t w = (int32_t)(vl << (16 - F));
+                            if constexpr (KIND == 1) w += (int32_t)((z & 0xFFFFu) + (z >> 16)) - 65535;
+                            const int32_t neg = (vh + (w >> 16)) >> 31;
+                            rr = vh + ((w + 32768 + neg) >> 16);
+                        }
+                        rv = min(max(rr, a.qmin_i), a.qmax_i);
+                    }
+                }
+                if (i < 2 || kh == 0) ob[c * TILE + o] = rv;
+            }
+        });
+        vmax[c] = max(vmax[c], vm);
+    };
+
+    // ---- the tile's samples out of the slice: nl0 = the tile's first output relative to the call's (may be negative) ----
+    auto store_tile = [&](int64_t nl0) {
         if constexpr ((dbg & 8) != 0) {
         } else if constexpr (KIND == 4) {
             for (uint32_t c = 0; c < cwn; ++c) {
@@ -340,14 +370,34 @@ __global__ __launch_bounds__(PX_THREADS) void d2d_fir_px_kernel(PxArgs a) {
         }
     };
 
+    auto tile_nl0 = [&](uint32_t t) -> int64_t { return (int64_t)((T0 + t) * (uint32_t)TILE - m0); };
+    auto tile_cbit = [&](uint32_t t) -> uint32_t {           // the lane's column starts at this bit of the tile's staged image
+        return (uint32_t)(tile_br(t) - 8 * (int64_t)tile_a0(t)) + (uint32_t)SBITS * n;
+    };
+    // One tile from its staged image, one thing after the other: the chains of the group's channels, their epilogues, the frames
+    auto convert_tile = [&](uint32_t t) {
+        const int64_t nl0 = tile_nl0(t);
+        const uint32_t cbit = tile_cbit(t);
+        static_for<0, 2>([&](auto cc) {
+            constexpr uint32_t c = (uint32_t)decltype(cc)::value;
+            if (c >= cwn) return;
+            px_v16f acc[G];
+            chain(c, cbit, acc, no_hook);
+            epilogue_exact(c, acc, nl0);
+        });
+        wave_sync2();
+        store_tile(nl0);
+    };
+
     const uint32_t wstride = gridDim.x * a.nwaves, wv = blockIdx.x * a.nwaves + wave;
     // the fast tiles are a range [t_lo, t_hi) (a tile's first byte grows with its index)
     uint32_t t_lo = 0, t_hi = 0;
-    if (fast_layout) {
+    if (fast_layout || il) {
+        const uint32_t lim = il ? Lcall : full_bytes;
         const int64_t c0 = tile_br(0), K = (int64_t)(TILE / LP) * MP;                 // stream bits between two tiles
         t_lo = c0 >= 0 ? 0u : (uint32_t)((-c0 + K - 1) / K);
         if (t_lo > ntiles) t_lo = ntiles;
-        const int64_t room = 8 * ((int64_t)full_bytes - 16 * NCHK + 15) - c0;
+        const int64_t room = 8 * ((int64_t)lim - 16 * NCHK + 15) - c0;
         t_hi = room < 0 ? t_lo : (uint32_t)std::min<int64_t>(room / K + 1, (int64_t)ntiles);
         if (t_hi < t_lo) t_hi = t_lo;
         while (t_hi > t_lo && !is_fast(t_hi - 1)) --t_hi;
@@ -363,6 +413,138 @@ __global__ __launch_bounds__(PX_THREADS) void d2d_fir_px_kernel(PxArgs a) {
     }
     uint32_t t = wv;
     while (t < t_lo) t += wstride;
+
+    // PIPE (a channel pair, the all-integer requantisers): the epilogue of one chain rides on the next, cut into jobs behind its matrix
+    // instructions --
+    //     region A (tile t):  chain of channel 0  ||  requantise channel 1 of the tile before; then that tile's frames leave
+    //     region B (tile t):  chain of channel 1  ||  requantise channel 0 of tile t
+    // in a branch-free form that is valid for a tile in which nothing clips, no rounding is an exact tie, the dither counter does not wrap
+    // and every output belongs to the call; per tile the lane keeps the extremes of v and the least tie distance, one ballot after the
+    // region decides, and a tile that fails is redone by epilogue_exact from the accumulators the jobs just read (they are still live).
+    constexpr bool PIPE = KIND <= 2 && (dbg & 3) == 0;
+    if constexpr (PIPE) {
+        if (cwn == 2) {
+            constexpr int NS = 3 * G;                                  // sample slots per lane and channel (half 1's third slot of a group repeats its second: the table holds output 4 twice)
+            constexpr int JPS = KIND == 0 ? 2 : 3;                     // jobs per sample: [hash,] recombine, finish
+            constexpr int NJ = JPS * NS;
+            uint32_t kF = (uint32_t)F, kSh = 16u - (uint32_t)F, kShR = 32u - (uint32_t)F, kC1 = 0x7feb352dU, kC2 = 0x846ca68bU, kTm = (uint32_t)-32767;
+            int32_t kHalf = 1 << (F - 1), kNegB = -kBias;
+            asm volatile("" : "+v"(kF), "+v"(kSh), "+v"(kShR), "+v"(kC1), "+v"(kC2), "+v"(kTm), "+v"(kHalf), "+v"(kNegB));
+            const int32_t kSafe = (int32_t)(((uint32_t)a.qmax_i - 2u) << F);
+            // where the lane's samples go in the slice: slot i of group g at base + 5 g + i; half 1's third slot goes to a dword nobody reads
+            int32_t* const sl_real = ob + (uint32_t)OC * n + 3u * kh;
+            int32_t* const sl_third[2] = {kh ? ob + 2 * TILE + n : sl_real, kh ? ob + 2 * TILE + n : sl_real + TILE};
+            int32_t tmn[2] = {kBias, kBias}, tmx[2] = {kBias, kBias};    // running extremes of v0 = v + 2^S over the tiles the fast form served
+            struct Fast { uint32_t zb, T; int32_t v0, mn, mx; uint32_t tie; };
+            auto fast_begin = [&](Fast& f, uint32_t tt, uint32_t c) {
+                const uint32_t first = (uint32_t)((T0 + tt) * (uint32_t)TILE);             // lo32 of the tile's first output index
+                f.zb = first + rkeys[c] + (first < rlo0s[c] ? rsteps[c] : 0u) + (uint32_t)OC * n + 3u * kh;
+                f.mn = kBias; f.mx = kBias; f.tie = 0xFFFFu;
+            };
+            auto fast_job = [&](Fast& f, auto cc, const px_v16f (&o)[G], auto jc) {
+                constexpr int j = decltype(jc)::value;
+                constexpr int c = decltype(cc)::value;
+                constexpr int i = j / JPS, g = i / 3, q = i % 3;
+                constexpr int tk = j % JPS + (KIND == 0 ? 1 : 0);       // 0 hash, 1 recombine, 2 finish
+                if constexpr (tk == 0) {
+                    uint32_t z = f.zb + (uint32_t)(5 * g + q);
+                    z ^= z >> 16; z *= kC1;
+                    z ^= z >> 15; z *= kC2;
+                    z ^= z >> 16;
+                    if constexpr (KIND == 1) f.T = __builtin_amdgcn_sad_u16(z, 0u, kTm);    // lo16 + hi16 - 32767, units of 2^-16 LSB
+                    else f.T = z >> kShR;                                                   // (2 hi16 + 1) >> (17 - F)
+                    asm volatile("" : "+v"(f.T));
+                } else if constexpr (tk == 1) {
+                    f.v0 = recombine0(o[g], q);
+                    asm volatile("" : "+v"(f.v0));
+                } else {
+                    const int32_t v0 = f.v0;
+                    int32_t sres;
+                    if constexpr (KIND == 1) {
+                        // r = floor(x + d + 1/2) = (v + (T >> (16 - F))) >> F; an exact tie (the only case where round-half-away differs) has the low 16 bits of v 2^(16-F) + T zero
+                        sres = v0 + ((int32_t)f.T >> kSh) + kNegB;
+                        const uint32_t w = ((uint32_t)v0 << kSh) + f.T;
+                        uint32_t tmin; asm("v_min3_u16 %0, %1, %2, %3" : "=v"(tmin) : "v"(f.tie), "v"(w), "v"(w)); f.tie = tmin;
+                    } else if constexpr (KIND == 2) {
+                        sres = v0 + (int32_t)f.T + kNegB;                                  // never a tie
+                    } else {
+                        const int32_t v = v0 + kNegB;
+                        sres = v + kHalf + (v >> 31);                                      // round half away from zero
+                    }
+                    if constexpr (q == 2) sl_third[c][5 * g + q] = sres >> kF;
+                    else sl_real[c * TILE + 5 * g + q] = sres >> kF;
+                    f.mn = min(f.mn, v0); f.mx = max(f.mx, v0);
+                }
+            };
+            auto fast_hook = [&](Fast& f, auto c, const px_v16f (&o)[G], auto kc) {
+                constexpr int k = decltype(kc)::value;
+                static_for<0, NJ>([&](auto jc) {
+                    constexpr int j = decltype(jc)::value;
+                    if constexpr ((j * NSLOT) / NJ == k) fast_job(f, c, o, jc);
+                });
+            };
+            auto fast_failed = [&](const Fast& f, uint32_t tt) -> bool {
+                const int64_t nl0 = tile_nl0(tt);
+                const uint32_t first = (uint32_t)((T0 + tt) * (uint32_t)TILE);
+                if (nl0 < 0 || (uint64_t)nl0 + (uint32_t)TILE > (uint64_t)nout || first > 0xFFFFFFFFu - (uint32_t)TILE) return true;     // (uniform)
+                const bool bad = (KIND == 1 && (f.tie & 0xFFFFu) == 0) || f.mx > kSafe + kBias || f.mn < kBias - kSafe;
+                return __builtin_amdgcn_ballot_w64(bad) != 0;
+            };
+            auto finish_channel = [&](const Fast& f, uint32_t tt, auto cc, const px_v16f (&o)[G]) {
+                constexpr int c = decltype(cc)::value;
+                if (fast_failed(f, tt)) epilogue_exact((uint32_t)c, o, tile_nl0(tt));
+                else { tmn[c] = min(tmn[c], f.mn); tmx[c] = max(tmx[c], f.mx); }
+            };
+            using C0 = std::integral_constant<int, 0>;
+            using C1 = std::integral_constant<int, 1>;
+            if (t < t_hi) issue(t);
+            px_v16f accA[G], accB[G];                                  // channel 0's / channel 1's accumulators
+#pragma unroll
+            for (int g = 0; g < G; ++g)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) accB[g][i] = 0.0f;
+            bool have_prev = false;
+            uint32_t pw = t;                                           // the tile whose channel 1 still waits for its epilogue
+            for (; t < t_hi; t += wstride) {
+                const uint32_t cbit = tile_cbit(t);
+                wave_sync2();
+                commit();
+                if (t + wstride < t_hi) issue(t + wstride);            // the next tile's bytes are on their way while this one is converted
+                wave_sync2();
+                {   // ---- region A ----
+                    Fast f;
+                    fast_begin(f, pw, 1);
+                    chain(0u, cbit, accA, [&](auto kc) { fast_hook(f, C1{}, accB, kc); });
+                    if (have_prev) {
+                        finish_channel(f, pw, C1{}, accB);
+                        wave_sync2();
+                        store_tile(tile_nl0(pw));
+                        wave_sync2();
+                    }
+                }
+                {   // ---- region B ----
+                    Fast f;
+                    fast_begin(f, t, 0);
+                    chain(1u, cbit, accB, [&](auto kc) { fast_hook(f, C0{}, accA, kc); });
+                    finish_channel(f, t, C0{}, accA);
+                }
+                have_prev = true; pw = t;
+            }
+            if (have_prev) {
+                // drain: channel 1 of the wave's last tile
+                Fast f;
+                fast_begin(f, pw, 1);
+                static_for<0, NJ>([&](auto jc) { fast_job(f, C1{}, accB, jc); });
+                finish_channel(f, pw, C1{}, accB);
+                wave_sync2();
+                store_tile(tile_nl0(pw));
+            }
+            // the extremes the fast form met, as |v|
+#pragma unroll
+            for (int c = 0; c < 2; ++c) vmax[c] = max(vmax[c], (uint32_t)max(tmx[c] - kBias, kBias - tmn[c]));
+            t = t_hi;                                                  // (nothing left for the plain loop below)
+        }
+    }
     if (t < t_hi) issue(t);
     for (; t < t_hi; t += wstride) {
         wave_sync2();
@@ -408,7 +590,7 @@ static hipError_t launch_px_t(PxArgs& a, uint32_t max_nout, uint32_t nfiles, hip
     a.ngroups = (C + a.cw - 1) / a.cw;
     a.off_waves = (uint32_t)px_nslot(LP, MP, NP, G) * PX_FRAG_BYTES;
     a.off_out = a.cw * (uint32_t)px_stream_bytes(LP, MP, NP, G);
-    a.wave_lds = a.off_out + a.cw * TILE * 4u;
+    a.wave_lds = a.off_out + a.cw * TILE * 4u + 256u;                // (+ 64 dwords nobody reads: where the pipelined epilogue puts half 1's third slot)
     uint32_t nwaves = PX_THREADS / 64;
     while (nwaves > 1 && (size_t)a.off_waves + (size_t)nwaves * a.wave_lds > 160 * 1024) --nwaves;
     a.nwaves = nwaves;
@@ -576,8 +758,9 @@ std::vector<int8_t> build_px_tables(const d2d_poly_def& p) {
                 const int row = l & 31, kh = l >> 5;
                 const int half = (row >> 2) & 1, rr = 4 * (row >> 3) + (row & 3);
                 uint32_t regs[6] = {0, 0, 0, 0, 0, 0};
-                const int ii = rr / 5, dg = rr % 5, og = 3 * half + ii;
-                if (rr < 15 && og < 5) {
+                const int ii = rr / 5, dg = rr % 5;
+                const int og = 3 * half + ii < 5 ? 3 * half + ii : 4;         // (half 1's third slot repeats output 4: a real sample for the pipelined epilogue's extremes, stored nowhere)
+                if (rr < 15) {
                     const int o = 5 * g + og;
                     const int qo = px_q(LP, MP, o), ph = (int)(((long long)o * MP) % LP);
                     for (int e = 0; e < 32; ++e) {

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <map>
 #include <mutex>
 #include <string>
 
@@ -44,15 +45,21 @@ struct KernelPrep {
 // (per thread: engines are driven from one thread each), copied into the engine by d2d_translate_batch_device, so that
 // d2d_kernel_name() reports what ran and not what the dispatch logic predicts.
 extern thread_local const char* d2d_last_launched_kernel;
+// (one string per (kernel family, instantiation): the family is part of the key -- a function-local static keyed by the int pack alone
+// was shared by every family with the same pack, and the first caller's name won)
 template <int... V>
 inline const char* launched_name(const char* base) {
-    static const std::string n = [&] {
+    static std::mutex mu;
+    static std::map<std::string, std::string> names;
+    std::lock_guard<std::mutex> g(mu);
+    auto it = names.find(base);
+    if (it == names.end()) {
         std::string s = std::string(base) + "<";
         const int v[] = {V...};
         for (size_t i = 0; i < sizeof...(V); ++i) s += (i ? ", " : "") + std::to_string(v[i]);
-        return s + ">";
-    }();
-    return n.c_str();
+        it = names.emplace(base, s + ">").first;
+    }
+    return it->second.c_str();       // (map nodes do not move)
 }
 
 size_t lut_smem_bytes(const FirArgs& a, int MB);

@@ -34,9 +34,8 @@ size_t mfma2_smem_bytes(int M, int N, uint32_t channels, uint32_t sample_bytes, 
 // false: every plane masked (the pipelined kernel)
 std::vector<int8_t> build_mfma2_tables(const d2d_filter_def& f, bool msb_first, bool unmask0);
 // does this launch shape go to the software-pipelined kernel (d2d_kernels_mfma3.hip)?  Fixed per engine: decides the table variant.
-// 0: the two-group kernel itself; 3: the pipelined kernel with the dense chain; 4: with the structured-sparse chain (its own tables)
+// 0: the two-group kernel itself; 3: the int8 pipelined kernel; 5: the fp6 x fp4 kernel (d2d_kernels_mx.hip)
 int mfma2_pipelined(const FirArgs& a, int M, int N);
-std::vector<int8_t> build_mfma4_tables(const d2d_filter_def& f, bool msb_first);
 void mfma2_debug_stamps(unsigned long long out[8]);   // diagnostic (make DIAG=1, D2D_DBG & 256)
 hipError_t launch_fir_mfma2(const FirArgs& a, int M, int N, uint32_t max_nout, uint32_t nstreams, hipStream_t s);
 void mfma3_debug_stamps(unsigned long long out[8]);  // diagnostic (make DIAG=1, D2D_DBG & 256): per-wave lifetimes of the pipelined kernel

@@ -80,6 +80,7 @@ struct PxArgs {
     uint32_t in_channels;      // channels of the input layout
     uint32_t B, keep;          // effective block size, history bytes per channel
     uint32_t msb;              // 1: the stream's bytes hold their first bit in bit 7
+    uint32_t il2;              // 1: byte-interleaved STEREO input, both channels converted: the matrix-core kernel's staging pulls the channels apart (B = 1)
     uint32_t to_scratch;       // 1: the exact integers sum Q s go to job.xs (the noise-shaping pass requantises)
     uint32_t cw;               // channels a wave converts per tile (2, or 1 for a mono file)
     uint32_t ngroups;          // channel groups per file: ceil(channels / cw)

@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define D2D_ABI_VERSION 4   /* 3: the table blob header names the table variant; 4: d2d_params.tap_bits */
+#define D2D_ABI_VERSION 5   /* 3: the table blob header names the table variant; 4: d2d_params.tap_bits; 5: d2d_params.debug_flags (was reserved0) */
 
 /* status codes */
 enum {
@@ -49,6 +49,20 @@ enum { D2D_DITHER_TPDF = 'T', D2D_DITHER_RECT = 'R', D2D_DITHER_FPD = 'F', D2D_D
        D2D_DITHER_NOISE_SHAPED = 'N' };
 /* which device kernel evaluates the FIR (same numbers either way) */
 enum { D2D_KERNEL_AUTO = 0, D2D_KERNEL_LUT = 1, D2D_KERNEL_MFMA = 2 };
+/* d2d_params.debug_flags (ABI 5): diagnostic dispatch switches.  0 = production dispatch; the library reads NO environment variable.
+ * Each flag sends a conversion down an older kernel or route that produces the SAME bytes -- what the parity tests compare routes with
+ * and what A/B measurements time; all are fixed when the engine is created. */
+enum {
+    D2D_DBG_NO_MX       = 1u << 0,   /* M = 32 / 64 / 128 stay off the fp6 x fp4 kernel (int8 pipelined kernel / older kernels)            */
+    D2D_DBG_NO_GAINQ    = 1u << 1,   /* levels other than 0 dB, 20-bit and the float dither go back to the two-group / one-group kernels   */
+    D2D_DBG_NO_COOP     = 1u << 2,   /* byte-interleaved input goes through the planar pre-pass instead of the kernels' own staging         */
+    D2D_DBG_HOST_STAGED = 1u << 3,   /* host-pointer entry points stage through device buffers even when the GPU can address the memory   */
+    D2D_DBG_NO_PIPE     = 1u << 4,   /* stereo conversions stay on the two-group kernel (no software-pipelined kernel)                    */
+    D2D_DBG_MFMA_V1     = 1u << 5,   /* the one-group matrix-core kernel of round 1 for every decimation                                   */
+    D2D_DBG_NO_INTQ     = 1u << 6,   /* the f64 epilogues instead of the all-integer requantisers                                           */
+    D2D_DBG_NS_GENERAL  = 1u << 7    /* the general noise-shaping kernel for stereo too                                                     */
+    /* bits 8..15: waves per block of the matrix-core kernels (0 = their own choice)                                                        */
+};
 
 /* The conversion parameters of Rdsd2Pcm::new (src/main.rs:325-342) that concern the hot path.
  * File/sink arguments (output type, out_dir, append_rate, base_dir, in_path) stay on the host
@@ -82,7 +96,7 @@ typedef struct d2d_params {
      * table, then the small residual table q32 - 256 q -- and combines the two exact integer sums before level, dither and
      * requantisation; about three times the device time.  44.1k-family rates, dither T / R / F / X. */
     uint32_t tap_bits;
-    uint32_t reserved0;
+    uint32_t debug_flags;   /* D2D_DBG_* (ABI 5; 0 in production)                                    */
 } d2d_params;
 
 typedef struct d2d_engine d2d_engine;
@@ -143,7 +157,7 @@ int d2d_translate_batch_device(d2d_engine* e, d2d_file_io* io, uint32_t n_files,
  * PINNED buffers (hipHostMalloc / hipHostRegister, 16-byte aligned) are addressed by the kernels
  * themselves: one set of launches reads the DSD and writes the frames over the link, so upload,
  * conversion and download overlap by construction and nothing is staged (bench shape: 90 GB/s over
- * the link both ways, `pcie_inclusive`).  Any other memory -- or D2D_HOST_STAGED=1, or a file of 2 GiB
+ * the link both ways, `pcie_inclusive`).  Any other memory -- or D2D_DBG_HOST_STAGED, or a file of 2 GiB
  * per channel and more -- takes the pipeline: the batch is cut along time into slices of about
  * `slice_bytes_per_channel` (0 = 4 MiB; whole planar blocks), and upload, conversion and download
  * of consecutive slices run on three streams over double-buffered device staging (77 GB/s with

@@ -181,22 +181,19 @@ def test_engines_on_concurrent_threads(engine_lib, oracle_mod):
 
 @pytest.mark.parametrize("out_rate,fmt,pinned,staged", [(88200, "P", True, True), (88200, "P", True, False), (96000, "I", True, False), (96000, "I", False, False),
                                                         (176400, "P", False, False), (88200, "N24", True, False)])
-def test_host_resident_batch_pipeline(engine_lib, oracle_mod, monkeypatch, out_rate, fmt, pinned, staged):
+def test_host_resident_batch_pipeline(engine_lib, oracle_mod, out_rate, fmt, pinned, staged):
     """d2d_translate_batch_host: ragged files, many slices (upload / convert / download overlapped), state
     carried from slice to slice; the bytes equal the oracle's one-shot conversion of each file.  Pinned buffers are
-    read and written by the kernels themselves (no staging, one call) unless D2D_HOST_STAGED=1 keeps the pipeline."""
+    read and written by the kernels themselves (no staging, one call) unless the D2D_DBG_HOST_STAGED flag keeps the pipeline."""
     import torch
-    if staged:
-        monkeypatch.setenv("D2D_HOST_STAGED", "1")
-    else:
-        monkeypatch.delenv("D2D_HOST_STAGED", raising=False)
+    debug = engine_lib.DBG_HOST_STAGED if staged else 0
     extra = {}
     if fmt == "N24":
         fmt, extra = "P", dict(dither="N")
     kw = dict(KW, output_rate=out_rate, fmt=fmt, endianness="L" if fmt == "P" else "M", **extra)
     lens = [4096 * 7 + 123, 4096 * 3, 0, 4096 * 12 + 4000]
     files = [pack_layout([random_bytes(n, 60 + i), random_bytes(n, 70 + i)], fmt, 4096 if fmt == "P" else 1) for i, n in enumerate(lens)]
-    e = engine_lib.Engine(n_files=len(lens), kernel=2, **kw)
+    e = engine_lib.Engine(n_files=len(lens), kernel=2, debug=debug, **kw)
     fb = e.frame_bytes
     want = [oracle_mod.Oracle(**kw).translate(f) for f in files]
     ins, outs = [], []
@@ -215,14 +212,14 @@ def test_host_resident_batch_pipeline(engine_lib, oracle_mod, monkeypatch, out_r
         assert ios[i].frames_out == rf, (i, ios[i].frames_out, rf)
         assert np.array_equal(outs[i][:rf * fb].numpy(), r[:rf * fb]), i
     # too small an output buffer is reported, not overrun
-    e2 = engine_lib.Engine(n_files=len(lens), kernel=2, **kw)
+    e2 = engine_lib.Engine(n_files=len(lens), kernel=2, debug=debug, **kw)
     ios[3].pcm_capacity_bytes = 64
     with pytest.raises(Exception, match="pcm buffer too small"):
         e2.translate_batch_host(ios, 8192)
 
 
 @pytest.mark.parametrize("out_rate,dither", [(88200, "T"), (96000, "T"), (88200, "N")])
-def test_per_block_calls_on_pinned_buffers_need_no_staging(engine_lib, oracle_mod, monkeypatch, out_rate, dither):
+def test_per_block_calls_on_pinned_buffers_need_no_staging(engine_lib, oracle_mod, out_rate, dither):
     """d2d_translate with buffers the GPU can address (hipHostMalloc / hipHostRegister: torch's pinned tensors): the kernels read
     and write them in place, call after call with carried state; same bytes as the staged route and the oracle"""
     import torch
@@ -233,8 +230,7 @@ def test_per_block_calls_on_pinned_buffers_need_no_staging(engine_lib, oracle_mo
     want = [o.translate(b) for b in data]
     got = {}
     for staged in ("0", "1"):
-        monkeypatch.setenv("D2D_HOST_STAGED", staged)
-        e = engine_lib.Engine(n_files=1, kernel=2, **kw)
+        e = engine_lib.Engine(n_files=1, kernel=2, debug=engine_lib.DBG_HOST_STAGED if staged == "1" else 0, **kw)
         fb = e.frame_bytes
         res = []
         for b, n in zip(data, blocks):
@@ -249,15 +245,14 @@ def test_per_block_calls_on_pinned_buffers_need_no_staging(engine_lib, oracle_mo
 
 @pytest.mark.parametrize("staged", [True, False])
 @pytest.mark.parametrize("block", [100, 4100, 7])
-def test_host_resident_batch_with_odd_block_sizes(engine_lib, oracle_mod, monkeypatch, block, staged):
+def test_host_resident_batch_with_odd_block_sizes(engine_lib, oracle_mod, block, staged):
     """slices of d2d_translate_batch_host must be whole planar blocks for ANY block size (-s takes any
     value); rounding the slice to 16 bytes afterwards cut blocks in two and mixed the channels."""
     import torch
-    monkeypatch.setenv("D2D_HOST_STAGED", "1" if staged else "0")
     kw = dict(KW, output_rate=88200, fmt="P", endianness="L", block_size=block)
     lens = [block * 37 + 11, block * 5, block * 64]
     files = [pack_layout([random_bytes(n, 160 + i), random_bytes(n, 170 + i)], "P", block) for i, n in enumerate(lens)]
-    e = engine_lib.Engine(n_files=len(lens), kernel=2, **kw)
+    e = engine_lib.Engine(n_files=len(lens), kernel=2, debug=engine_lib.DBG_HOST_STAGED if staged else 0, **kw)
     fb = e.frame_bytes
     want = [oracle_mod.Oracle(**kw).translate(f) for f in files]
     ins = [torch.from_numpy(f.copy()).pin_memory() for f in files]
@@ -311,11 +306,11 @@ def test_channel_subsets_reproduce_the_full_conversion(engine_lib, oracle_mod, k
 
 def test_profile_read_all_brackets_every_kernel_of_a_call(engine_lib):
     """d2d_profile_read_all: the FIR kernel's device time and the time of every kernel of the calls (the
-    bench priced multi-kernel workloads with the FIR launch alone).  For the 48k cascade the step holds stage A, stage B
-    and the carries; for a plain 44.1k conversion the step is the FIR kernel plus the history carry."""
+    bench priced multi-kernel workloads with the FIR launch alone).  For the 48k cascade (DSD256 / DSD512 input) the step holds stage A,
+    stage B and the carries; for a plain 44.1k conversion, or the composed 48k filter of DSD64 / DSD128, the FIR kernel plus the history carry."""
     import torch
-    for out_rate, more in ((88200, 1.0), (96000, 1.3)):
-        kw = dict(KW, output_rate=out_rate, fmt="P", endianness="L")
+    for dsd_rate, out_rate, more in ((1, 88200, 1.0), (1, 96000, 1.0), (4, 192000, 1.3)):
+        kw = dict(KW, dsd_rate=dsd_rate, output_rate=out_rate, fmt="P", endianness="L")
         e = engine_lib.Engine(n_files=2, kernel=2, **kw)
         n = 4096 * 64
         buf = torch.from_numpy(np.concatenate([pack_layout([random_bytes(n, 1), random_bytes(n, 2)], "P", 4096)] * 1)).cuda()

@@ -31,9 +31,10 @@ RATE_MATRIX = [
 ]
 
 
-def run_pair(engine_lib, oracle_mod, bufs, kw, kernel=0):
-    """bufs: list of call buffers fed in sequence.  Returns (gpu_bytes, oracle_bytes, gpu_engine, oracle)."""
-    e = engine_lib.Engine(kernel=kernel, **kw)
+def run_pair(engine_lib, oracle_mod, bufs, kw, kernel=0, debug=0):
+    """bufs: list of call buffers fed in sequence.  Returns (gpu_bytes, oracle_bytes, gpu_engine, oracle).
+    debug: d2d_params.debug_flags (engine_lib.DBG_*) -- a diagnostic route that must give the same bytes."""
+    e = engine_lib.Engine(kernel=kernel, debug=debug, **kw)
     o = oracle_mod.Oracle(**kw)
     g_all, o_all = [], []
     for b in bufs:
@@ -299,29 +300,24 @@ def test_noise_shaped_many_segments_many_waves(engine_lib, oracle_mod, bits):
     assert np.array_equal(one, g)
 
 
-@pytest.mark.parametrize("chain,bits", [("mx", 24), ("mx", 16), ("mx", 32), ("dense", 24), ("sparse", 24), ("dense", 16), ("dense", 32)],
-                         ids=["fp6_chain", "fp6_chain_16bit", "fp6_chain_float", "dense_chain", "sparse_chain", "dense_chain_16bit", "dense_chain_float"])
+@pytest.mark.parametrize("chain,bits", [("mx", 24), ("mx", 16), ("mx", 32), ("dense", 24), ("dense", 16), ("dense", 32)],
+                         ids=["fp6_chain", "fp6_chain_16bit", "fp6_chain_float", "dense_chain", "dense_chain_16bit", "dense_chain_float"])
 @pytest.mark.parametrize("dither", ["T", "R", "X"])
 @pytest.mark.parametrize("dsd_rate,out_rate,filt", [(1, 88200, "E"), (1, 88200, "X"), (2, 88200, "E"), (2, 176400, "C"), (4, 176400, "E"),
                                                     (1, 176400, "E"), (1, 352800, "E"), (1, 176400, "X"), (2, 352800, "C"), (1, 352800, "D"), (4, 88200, "E")])
-def test_pipelined_stereo_kernel_fast_and_careful_tiles(engine_lib, oracle_mod, monkeypatch, dsd_rate, out_rate, filt, dither, chain, bits):
+def test_pipelined_stereo_kernel_fast_and_careful_tiles(engine_lib, oracle_mod, dsd_rate, out_rate, filt, dither, chain, bits):
     """Stereo 24-bit (and 16-bit, and float without the float dither) at 0 dB runs a software-pipelined kernel -- d2d_fir_mx_kernel (fp6 x fp4
-    matrix-core chain, M = 32 and 64) or d2d_fir_mfma3_kernel (int8 chain; every M up to 64 with D2D_NO_MX=1): the requantiser rides on the next chain in its branch-free form and a
+    matrix-core chain, M = 32 and 64) or d2d_fir_mfma3_kernel (int8 chain; every M up to 64 with the D2D_DBG_NO_MX flag): the requantiser rides on the next chain in its branch-free form and a
     tile that could clip, holds an exact rounding tie or is cut short by the end of the call is redone sample by sample.
     Full-scale stretches (all-ones / all-zeros bytes clip at both rails), quiet stretches, ragged call sizes and a short last
     call exercise those paths (an exact tie under triangular dither is a 2^-16 event per sample: likely here, certain in
-    tests/test_gpu_fullsize.py).  D2D_SPARSE=1 swaps the kernel's dense MFMA chain for the structured-sparse one
-    (v_smfmac_i32_32x32x64_i8, its own tap tables): same results."""
-    sparse = 1 if chain == "sparse" else 0
+    tests/test_gpu_fullsize.py)."""
     M = 2822400 * dsd_rate // out_rate
-    if sparse and (filt != "E" or out_rate // dsd_rate > 88200):
-        pytest.skip("the sparse chain is compiled for the E filters at M = 32 and 64 only")
     if chain == "mx" and M < 32:
         pytest.skip("the fp6 chain serves M = 32, 64 and 128 (at M = 8 and 16 the groups of six phases do not share tap fragments)")
     if chain != "mx" and M == 128:
         pytest.skip("M = 128: the fp6 kernel only (the int8 kernels' tap table does not fit next to eight waves)")
-    monkeypatch.setenv("D2D_SPARSE", str(sparse))
-    monkeypatch.setenv("D2D_NO_MX", "0" if chain == "mx" else "1")
+    debug = 0 if chain == "mx" else engine_lib.DBG_NO_MX
     rng = np.random.default_rng(5)
     nbytes = 4096 * 40 * dsd_rate
     chans = []
@@ -337,14 +333,14 @@ def test_pipelined_stereo_kernel_fast_and_careful_tiles(engine_lib, oracle_mod, 
               filter=filt, bit_depth=bits, dither=dither, seed=99)
     cuts = [0, 4096 * 7, 4096 * 7 + 4096 * 20, nbytes - 4096, nbytes]
     bufs = [pack_layout([ch[a:b] for ch in chans], "P", 4096) for a, b in zip(cuts[:-1], cuts[1:])]
-    g, r, e, o = run_pair(engine_lib, oracle_mod, bufs, kw, 2)
+    g, r, e, o = run_pair(engine_lib, oracle_mod, bufs, kw, 2, debug)
     targs = [t.strip() for t in e.kernel_name().split("<")[1].rstrip(">").split(",")]
     if chain == "mx":
         assert e.kernel_name().startswith("d2d_fir_mx_kernel")                             # <MB, taps, groups, dither kind, bytes per sample>
         assert targs[0] == str(M // 8) and targs[4] == str(bits // 8)
     else:
         assert e.kernel_name().startswith("d2d_fir_mfma3_kernel")                          # <MB, NPG, taps (0 = dense chain), dither kind, bytes per sample>
-        assert (targs[2] == "0") == (sparse == 0) and targs[4] == str(bits // 8)
+        assert targs[2] == "0" and targs[4] == str(bits // 8)
     assert g.size == r.size and g.size > 0
     assert np.array_equal(g, r)
     pcm = decode_pcm(g, bits, 2)
@@ -358,11 +354,11 @@ def test_pipelined_stereo_kernel_fast_and_careful_tiles(engine_lib, oracle_mod, 
 
 @pytest.mark.parametrize("channels,dsd_rate,out_rate,dither,endian", [(8, 8, 96000, "T", "M"), (4, 8, 96000, "X", "L"), (8, 4, 192000, "R", "M"),
                                                                       (4, 2, 88200, "N", "M"), (8, 1, 88200, "N", "L")])
-def test_multichannel_interleaved_input_is_deinterleaved_inside_the_fir_kernel(engine_lib, oracle_mod, monkeypatch, channels, dsd_rate, out_rate, dither, endian):
+def test_multichannel_interleaved_input_is_deinterleaved_inside_the_fir_kernel(engine_lib, oracle_mod, channels, dsd_rate, out_rate, dither, endian):
     """byte-interleaved 4- and 8-channel streams (DFF) into the stage-A / noise-shaper scratch through d2d_fir_mx_kernel (M = 32, 64): the
     kernel's staging de-interleaves -- a block per (file, tile), one wave per channel pair, two block barriers per tile; tiles at the
     call's edges (history in front, the ragged end) are gathered byte by byte.  Ragged calls, two files of different length, equal to
-    the oracle and to the pre-pass route (D2D_NO_COOP=1)."""
+    the oracle and to the pre-pass route (the D2D_DBG_NO_COOP flag)."""
     nbytes = 4096 * 9 * dsd_rate // 2 + 333
     files = []
     for f in range(2):
@@ -374,9 +370,8 @@ def test_multichannel_interleaved_input_is_deinterleaved_inside_the_fir_kernel(e
     cuts = [0, 1000, 4096 * 2 + 7, nbytes - 1500 - 40, nbytes]
     outs = {}
     for nocoop in ("0", "1"):
-        monkeypatch.setenv("D2D_NO_COOP", nocoop)
         import torch
-        e = engine_lib.Engine(n_files=2, kernel=2, **kw)
+        e = engine_lib.Engine(n_files=2, kernel=2, debug=engine_lib.DBG_NO_COOP if nocoop == "1" else 0, **kw)
         got = [[], []]
         for a, b in zip(cuts[:-1], cuts[1:]):
             bufs = [pack_layout([ch[min(a, len(ch)):min(b, len(ch))] for ch in files[f]], "I", 1) for f in range(2)]
@@ -417,18 +412,17 @@ def test_multichannel_interleaved_input_is_deinterleaved_inside_the_fir_kernel(e
     (1, 96000, 24, "T", "M", 4096 * 9 + 333), (1, 192000, 16, "R", "L", 3_000_000 + 11), (2, 384000, 24, "X", "M", 4096 * 20 + 7), (1, 352800, 24, "N", "M", 2_000_000 + 5),
     (1, 176400, 16, "N", "L", 4096 * 9 + 1),
     (1, 88200, 24, "N", "M", 4096 * 9 + 333), (2, 88200, 16, "N", "L", 8_000_000 + 9), (4, 192000, 24, "T", "M", 4096 * 30 + 3), (8, 96000, 24, "R", "M", 12_000_000 + 1)])
-def test_interleaved_stereo_is_deinterleaved_inside_the_fir_kernel(engine_lib, oracle_mod, monkeypatch, dsd_rate, out_rate, bits, dither, endian, nbytes):
+def test_interleaved_stereo_is_deinterleaved_inside_the_fir_kernel(engine_lib, oracle_mod, dsd_rate, out_rate, bits, dither, endian, nbytes):
     """byte-interleaved STEREO (DFF files, the reference CLI's default -f I) into frames through d2d_fir_mx_kernel (M = 32, 64) and
-    d2d_fir_mfma3_kernel (M = 8, 16; M = 32 with D2D_NO_MX: "m3"): the wave that converts the pair pulls the channels apart inside its
+    d2d_fir_mfma3_kernel (M = 8, 16; M = 32 with the D2D_DBG_NO_MX flag: "m3"), and at DSD64 / DSD128 -> 48k multiples d2d_fir_px_kernel: the wave that converts the pair pulls the channels apart inside its
     staging (pieces fetched once, channel 1's bytes parked in registers for one region); tiles at the call's edges are gathered byte by
     byte.  Ragged calls, two files of different length, waves that walk several tiles (the long cases); equal to the oracle and to the
-    pre-pass route (D2D_NO_COOP=1)."""
+    pre-pass route (the D2D_DBG_NO_COOP flag)."""
     import torch
+    no_mx = 0
     if endian == "m3":
         endian = "M"
-        monkeypatch.setenv("D2D_NO_MX", "1")
-    else:
-        monkeypatch.delenv("D2D_NO_MX", raising=False)
+        no_mx = engine_lib.DBG_NO_MX
     files = []
     for f in range(2):
         n = nbytes - 1501 * f
@@ -439,8 +433,7 @@ def test_interleaved_stereo_is_deinterleaved_inside_the_fir_kernel(engine_lib, o
     cuts = [0, 1000, 4096 * 2 + 7, nbytes - 1501 - 40, nbytes]
     outs = {}
     for nocoop in ("0", "1"):
-        monkeypatch.setenv("D2D_NO_COOP", nocoop)
-        e = engine_lib.Engine(n_files=2, kernel=2, **kw)
+        e = engine_lib.Engine(n_files=2, kernel=2, debug=no_mx | (engine_lib.DBG_NO_COOP if nocoop == "1" else 0), **kw)
         fb = e.frame_bytes
         got = [[], []]
         for a, b in zip(cuts[:-1], cuts[1:]):
@@ -462,7 +455,7 @@ def test_interleaved_stereo_is_deinterleaved_inside_the_fir_kernel(engine_lib, o
             M = 2822400 * dsd_rate // out_rate if out_rate % 44100 == 0 else 8 * dsd_rate          # (48k family: stage A decimates to 352.8 kHz)
             M = min(M, 64)
             composed = out_rate % 48000 == 0 and dsd_rate <= 2          # DSD64 / DSD128 -> 48k multiples: one polyphase pass (d2d_kernels_px.hip)
-            assert ("d2d_fir_px_kernel" if composed else "d2d_fir_mx_kernel" if M >= 32 and "D2D_NO_MX" not in os.environ else "d2d_fir_mfma3_kernel") in e.kernel_name()
+            assert ("d2d_fir_px_kernel" if composed else "d2d_fir_mx_kernel" if M >= 32 and not no_mx else "d2d_fir_mfma3_kernel") in e.kernel_name()
             for f in range(2):
                 o = oracle_mod.Oracle(**kw)
                 want = []
@@ -478,10 +471,10 @@ def test_interleaved_stereo_is_deinterleaved_inside_the_fir_kernel(engine_lib, o
 @pytest.mark.parametrize("dsd_rate,out_rate", [(1, 352800), (1, 176400), (2, 352800), (2, 705600), (4, 1411200), (1, 88200), (2, 88200), (2, 176400), (4, 176400)])
 @pytest.mark.parametrize("bits,dither,level", [(24, "T", -3.0), (16, "R", 4.0), (24, "X", -0.5), (32, "X", -4.0), (16, "T", 20.0), (24, "R", -60.0),
                                                (20, "T", 0.0), (20, "R", 20.0), (20, "X", -4.0), (32, "F", 0.0), (32, "F", -4.0)])
-def test_level_in_db_inside_the_pipelined_kernel(engine_lib, oracle_mod, monkeypatch, dsd_rate, out_rate, bits, dither, level):
+def test_level_in_db_inside_the_pipelined_kernel(engine_lib, oracle_mod, dsd_rate, out_rate, bits, dither, level):
     """--level other than 0 dB (the reference's own test scripts use +-4 dB, build_test_*.sh) 20-bit frames and the float dither (the CLI's default for -b 32) at any level: stereo frames stay on the pipelined
     kernels (int8 at M = 8, 16; fp6 at M = 32, 64), whose epilogue then follows the f64 definition (KIND + 4); + 20 dB clips both rails, - 60 dB leaves a few LSB.
-    Equal to the oracle and to the one-group kernel (D2D_NO_GAINQ=1), samples and peaks, over ragged calls."""
+    Equal to the oracle and to the one-group kernel (the D2D_DBG_NO_GAINQ flag), samples and peaks, over ragged calls."""
     nbytes = 4096 * 6 * dsd_rate
     chans = [synth("sine", nbytes, seed=71, dsd_rate=dsd_rate, amp=0.5), synth("pink", nbytes, seed=72, dsd_rate=dsd_rate, amp=0.2)]
     kw = dict(dsd_rate=dsd_rate, output_rate=out_rate, channels=2, fmt="P", endianness="L", block_size=4096, filter="E",
@@ -489,8 +482,7 @@ def test_level_in_db_inside_the_pipelined_kernel(engine_lib, oracle_mod, monkeyp
     cuts = [0, 4096, 4096 * 2 + 4096 // 2, nbytes]
     outs = {}
     for off in ("0", "1"):
-        monkeypatch.setenv("D2D_NO_GAINQ", off)
-        e = engine_lib.Engine(n_files=1, kernel=2, **kw)
+        e = engine_lib.Engine(n_files=1, kernel=2, debug=engine_lib.DBG_NO_GAINQ if off == "1" else 0, **kw)
         o = oracle_mod.Oracle(**kw)
         got = []
         for a, b in zip(cuts[:-1], cuts[1:]):
