@@ -265,6 +265,7 @@ def main():
     ap.add_argument("--dither", default="", help="override the workload's dither (T, R, X, F, N)")
     ap.add_argument("--level", type=float, default=0.0, help="volume in dB (the reference's -l; its own test scripts use +-4)")
     ap.add_argument("--tap-bits", type=int, default=24, choices=(24, 32), help="tap grid (32: the optional 32-bit taps, two FIR passes and a combining pass; 44.1k-family workloads with dither T/R/F/X)")
+    ap.add_argument("--force-dist", action="store_true", help="one rank, but through the multi-GPU protocol: process group over RCCL, table blob broadcast and imported, barriers and the MAX-reduce around the timed region")
     ap.add_argument("--debug", type=lambda v: int(v, 0), default=0, help="d2d_params.debug_flags (include/dsd2dxd_amd.h: D2D_DBG_*), e.g. 2 = the older kernels for levels other than 0 dB; the line then names the flags and cites no counter traffic")
     ap.add_argument("--pcie-slice", type=int, default=0, help="bytes per channel per slice of the host-resident batch (0 = the library's default)")
     args = ap.parse_args()
@@ -294,7 +295,13 @@ def main():
     torch.cuda.set_device(local_dev)
     dev = torch.device("cuda", local_dev)
     cdev = dev if backend == "nccl" else torch.device("cpu")      # where collective payloads live
-    if world > 1:
+    # --force-dist: the collective path of a multi-GPU run with ONE rank (init, table-blob broadcast and import, barriers, MAX-reduce of
+    # the time), so that it has executed on a real GPU before an 8-GPU node sees it; no scaling number follows from it
+    dist_on = world > 1 or args.force_dist
+    if dist_on and world == 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29531")
+        os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
+    if dist_on:
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
@@ -340,7 +347,7 @@ def main():
     stream = torch.cuda.current_stream().cuda_stream
 
     # the shared filter tables: rank 0's copy is broadcast over RCCL and adopted by the others
-    if world > 1:
+    if dist_on:
         nb_t = torch.tensor([eng.tables_bytes()], dtype=torch.int64, device=cdev)      # rank 0's size (another variant may differ)
         dist.broadcast(nb_t, src=0)
         nb = int(nb_t.item())
@@ -352,7 +359,7 @@ def main():
         dist.broadcast(wire, src=0)
         blob.copy_(wire)
         torch.cuda.synchronize()
-        if rank != 0:
+        if rank != 0 or args.force_dist:
             # a rank whose conversion differs from rank 0's (an uneven channel shard: other channel count, hence another kernel and
             # table variant) is refused by the blob's header and keeps the tables it built itself
             try:
@@ -388,17 +395,17 @@ def main():
     eng.profile_enable(True)
     dts = []
     for _ in range(max(1, args.reps)):
-        if world > 1:
+        if dist_on:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(args.steps):
             step()
         torch.cuda.synchronize()
-        if world > 1:
+        if dist_on:
             dist.barrier()
         dt = time.perf_counter() - t0
-        if world > 1:
+        if dist_on:
             t = torch.tensor([dt], dtype=torch.float64, device=cdev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
@@ -409,7 +416,7 @@ def main():
     sustained = None
     if args.sustain > 0:
         n_sus = max(args.steps, int(args.sustain / max(min(dts) / args.steps, 1e-6)) + 1)
-        if world > 1:
+        if dist_on:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -417,7 +424,7 @@ def main():
             step()
         torch.cuda.synchronize()
         dts_ = time.perf_counter() - t0
-        if world > 1:
+        if dist_on:
             t = torch.tensor([dts_], dtype=torch.float64, device=cdev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dts_ = float(t.item())
@@ -465,6 +472,8 @@ def main():
     # a development library (D2D_AMD_LIB, tools/ab_*.sh) is named in the line, and no counter traffic is cited for it
     if args.debug:
         out["config"]["debug_flags"] = args.debug
+    if dist_on:
+        out["config"]["collectives"] = {"backend": backend, "world": world, "table_blob_bytes": int(nb)}
     alt_lib = os.environ.get("D2D_AMD_LIB")
     if alt_lib:
         with open(alt_lib, "rb") as fl:
@@ -502,13 +511,13 @@ def main():
             e2.reset()
             e2.translate_batch_host(hios, args.pcie_slice)       # warm-up (allocates what the route needs)
             reps = 2
-            if world > 1:
+            if dist_on:
                 dist.barrier()
             t1 = time.perf_counter()
             for _ in range(reps):
                 e2.translate_batch_host(hios, args.pcie_slice)
             dth = (time.perf_counter() - t1) / reps
-            if world > 1:
+            if dist_on:
                 t = torch.tensor([dth], dtype=torch.float64, device=cdev)
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)
                 dth = float(t.item())
@@ -539,7 +548,7 @@ def main():
         out["cpu_baseline"] = None
     if rank == 0:
         print(json.dumps(out))
-    if world > 1:
+    if dist_on:
         dist.destroy_process_group()
 
 

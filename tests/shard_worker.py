@@ -34,8 +34,14 @@ def main():
     import torch.distributed as dist
     import dsd2dxd_amd as d
     from dsd2dxd_amd.shard import shard_channels, shard_range
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    backend = os.environ.get("D2D_SHARD_BACKEND", "gloo")      # "nccl": RCCL, collective payloads on the device (one rank per GPU)
     dev = torch.device("cuda", 0)
+    if backend == "nccl":
+        torch.cuda.set_device(dev)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    cdev = dev if backend == "nccl" else torch.device("cpu")
     if mode == "files":
         b, e = shard_range(N_FILES, world, rank)
         kw, nf = KW_FILES, e - b
@@ -48,17 +54,17 @@ def main():
     # rank 0's tables, broadcast and adopted: what bench.py does before its timed region
     # (a rank whose conversion differs from rank 0's -- an uneven channel shard: another channel count, hence another kernel and table
     # variant -- is refused by the blob's header and keeps the tables it built itself)
-    nb_t = torch.tensor([eng.tables_bytes()], dtype=torch.int64)
+    nb_t = torch.tensor([eng.tables_bytes()], dtype=torch.int64, device=cdev)
     dist.broadcast(nb_t, src=0)
     nb = int(nb_t.item())
     blob = torch.zeros(nb, dtype=torch.uint8, device=dev)
     if rank == 0:
         eng.tables_export_device(blob.data_ptr(), nb)
     torch.cuda.synchronize()
-    wire = blob.cpu()
+    wire = blob.to(cdev)
     dist.broadcast(wire, src=0)
     adopted = rank == 0
-    if rank != 0:
+    if rank != 0 or os.environ.get("D2D_SHARD_IMPORT_OWN"):
         blob.copy_(wire)
         torch.cuda.synchronize()
         try:

@@ -93,3 +93,24 @@ def test_uneven_channel_shards_keep_their_own_tables(engine_lib, oracle_mod, tmp
     want, fr = oracle_mod.Oracle(**dict(W.KW_CHANNELS, output_rate=rate)).translate(buf)
     merged = merge_channel_frames([(*shard_channels(W.CHN, 4, r), parts[r]["pcm0"]) for r in range(4)], 3)
     assert np.array_equal(merged, want[:fr * W.CHN * 3])
+
+
+@pytest.mark.timeout(300)
+def test_rccl_path_with_one_rank(engine_lib, oracle_mod, tmp_path):
+    """the collective path of the multi-GPU bench on the one GPU of the test box: a fresh process joins a one-rank process group over RCCL
+    (backend "nccl", device_id), the table blob is exported, broadcast as a DEVICE tensor, imported, and the conversion that follows is the
+    oracle's; then bench.py --force-dist runs its own broadcast / barrier / MAX-reduce lines once (no scaling number is claimed from it)"""
+    import json
+    import shard_worker as W
+    parts = _run_ranks("files", 1, tmp_path, env={"D2D_SHARD_BACKEND": "nccl", "D2D_SHARD_IMPORT_OWN": "1"})
+    assert bool(parts[0]["adopted"])
+    for f in range(W.N_FILES):
+        want, fr = oracle_mod.Oracle(**W.KW_FILES).translate(W.file_bytes(f))
+        assert np.array_equal(parts[0]["pcm%d" % f], want[:fr * 6]), f
+    env = dict(os.environ, MASTER_PORT=str(_free_port()))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--force-dist", "--files", "2", "--seconds", "2", "--steps", "2", "--warmup", "1",
+                        "--reps", "1", "--sustain", "0", "--no-cpu-baseline", "--no-pcie"], capture_output=True, text=True, timeout=240, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 1 and line["config"]["collectives"]["backend"] == "nccl" and line["config"]["collectives"]["table_blob_bytes"] > 0
+    assert line["value"] > 0
