@@ -265,6 +265,7 @@ def main():
     ap.add_argument("--dither", default="", help="override the workload's dither (T, R, X, F, N)")
     ap.add_argument("--level", type=float, default=0.0, help="volume in dB (the reference's -l; its own test scripts use +-4)")
     ap.add_argument("--tap-bits", type=int, default=24, choices=(24, 32), help="tap grid (32: the optional 32-bit taps, two FIR passes and a combining pass; 44.1k-family workloads with dither T/R/F/X)")
+    ap.add_argument("--as-rank", default="", help="--shard channels on ONE GPU: convert the channel range rank r of an N-way split would take, written r/N (e.g. 0/8)")
     ap.add_argument("--force-dist", action="store_true", help="one rank, but through the multi-GPU protocol: process group over RCCL, table blob broadcast and imported, barriers and the MAX-reduce around the timed region")
     ap.add_argument("--debug", type=lambda v: int(v, 0), default=0, help="d2d_params.debug_flags (include/dsd2dxd_amd.h: D2D_DBG_*), e.g. 2 = the older kernels for levels other than 0 dB; the line then names the flags and cites no counter traffic")
     ap.add_argument("--pcie-slice", type=int, default=0, help="bytes per channel per slice of the host-resident batch (0 = the library's default)")
@@ -340,6 +341,13 @@ def main():
         if world > channels:
             raise SystemExit(f"--shard channels: {world} ranks but only {channels} channels")
         ch_first, ch_count = shard_channels(channels, world, rank)
+        if args.as_rank:
+            # one GPU converts exactly the share rank r of an N-way channel split would convert (BASELINE config 5: one channel, or a pair,
+            # of an 8-channel stream per GPU): that rank's cost on record from a one-GPU lease
+            r_, n_ = (int(v) for v in args.as_rank.split("/"))
+            if world != 1 or not (0 <= r_ < n_ <= channels):
+                raise SystemExit("--as-rank r/N: one process, 0 <= r < N <= channels")
+            ch_first, ch_count = shard_channels(channels, n_, r_)
         kw.update(channel_first=ch_first, channel_count=ch_count)
     # file shards differ per rank; a channel shard reads the same files on every rank
     files = make_files(args.files, bpc, dsd_rate, args.distinct, rank if args.shard == "files" else 0, gen_threads, channels, fmt, endian, block)
@@ -472,6 +480,10 @@ def main():
     # a development library (D2D_AMD_LIB, tools/ab_*.sh) is named in the line, and no counter traffic is cited for it
     if args.debug:
         out["config"]["debug_flags"] = args.debug
+    if args.as_rank:
+        # the rank's algorithmic bytes count ITS channels only; what it must fetch is the whole byte-interleaved stream
+        out["config"]["as_rank"] = {"rank_of": args.as_rank, "channels": [ch_first, ch_count], "input_bytes_it_must_fetch_per_launch": int(args.files * bpc * channels) if fmt == "I" else int(args.files * bpc * ch_count),
+                                    "note": "one rank's share of a channel split, timed alone on one GPU; value and roofline count this rank's channels only"}
     if dist_on:
         out["config"]["collectives"] = {"backend": backend, "world": world, "table_blob_bytes": int(nb)}
     alt_lib = os.environ.get("D2D_AMD_LIB")

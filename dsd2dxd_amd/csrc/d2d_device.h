@@ -158,6 +158,39 @@ __device__ __forceinline__ double emit_sample(const Epilogue& ep, const StreamJo
     return fabs(y * ep.gain);
 }
 
+// The two samples of a channel PAIR into a wider frame (multichannel files are converted pair by pair): 6 / 4 / 8 bytes that start on an even
+// byte of the frame -- one 4-byte and one 2-byte store for 24-bit samples (the three byte stores per sample this replaces were what stage B
+// of an 8-channel conversion spent most of its time on), one store otherwise.  The frames' base is 16-byte aligned and the pair's offset
+// even, so 2-byte alignment is all these stores have.
+typedef uint32_t u32_a2 __attribute__((aligned(2)));
+typedef uint32_t u32x2_a2 __attribute__((ext_vector_type(2), aligned(2)));
+__device__ __forceinline__ void store_pair_in_frame(uint8_t* dst, uint32_t L, uint32_t R, uint32_t SBY) {
+    if (SBY == 3) {
+        *reinterpret_cast<D2D_GLOBAL u32_a2*>(as_global(dst)) = (L & 0x00FFFFFFu) | (R << 24);
+        *reinterpret_cast<D2D_GLOBAL uint16_t*>(as_global(dst + 4)) = (uint16_t)(R >> 8);
+    } else if (SBY == 2) {
+        *reinterpret_cast<D2D_GLOBAL u32_a2*>(as_global(dst)) = (L & 0xFFFFu) | (R << 16);
+    } else {
+        *reinterpret_cast<D2D_GLOBAL u32x2_a2*>(as_global(dst)) = u32x2_a2{L, R};
+    }
+}
+
+// Which (file, channel group) a block row converts.  The channel groups of one multichannel file write into the SAME frames (a pair's 6 bytes
+// of every 24-byte frame of an 8-channel stream), so their partial line writes should meet in one L2: workgroups go to the 8 XCDs round
+// robin by their flat index (x fastest), and with one block per row the groups of a file would land on different XCDs, whose L2s cannot
+// merge them (stage B of the config-5 shape: 21 ms for 4.4 GB of frames).  Rows y = 8 k ng + 8 s + x (x < 8, s < ng) of whole batches of
+// eight files are therefore dealt out as file 8 k + x, group s: the ng blocks of a file sit 8 apart -- same XCD, dispatched together.
+// Grids with several blocks per row (gridDim.x a multiple of 8) already have that property and keep the plain order.
+__device__ __forceinline__ void row_to_file_group(uint32_t y, uint32_t nrows, uint32_t ng, uint32_t gx, uint32_t& file, uint32_t& grp) {
+    const uint32_t batch = 8u * ng;
+    if (ng > 1 && (gx & 7u) != 0 && y < nrows / batch * batch) {
+        const uint32_t k = y / batch, r = y - k * batch;
+        file = 8u * k + (r & 7u); grp = r >> 3;
+    } else {
+        file = y / ng; grp = y - file * ng;
+    }
+}
+
 // Non-negative doubles order like their bit patterns: one atomic per block for the peak meter.
 __device__ __forceinline__ void block_peak_max(double pk, double* dst, double* lds_red /* [nwaves] */) {
 #pragma unroll

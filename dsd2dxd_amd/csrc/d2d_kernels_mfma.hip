@@ -119,7 +119,9 @@ __global__ __launch_bounds__(MFMA_MAX_THREADS, 3) void d2d_fir_mfma_kernel(MfmaA
     // channels of this group, cbase = its first channel among the Cs; jobs[c].ch is the channel's
     // index in the FILE.
     const uint32_t Ct = a.in_channels, Cs = a.epi.channels, sb = a.epi.sample_bytes;
-    const uint32_t fidx = blockIdx.y / m.ngroups, cbase = (blockIdx.y - fidx * m.ngroups) * 2u;
+    uint32_t fidx, grp_;                                         // (XCD-aware: the channel pairs of a file write into the same frames, d2d_device.h)
+    row_to_file_group(blockIdx.y, gridDim.y, m.ngroups, gridDim.x, fidx, grp_);
+    const uint32_t cbase = grp_ * 2u;
     const uint32_t C = m.ngroups == 1 ? Cs : (Cs - cbase < 2u ? Cs - cbase : 2u);
     const uint32_t fbytes = sb * C;                        // frame bytes inside the wave's LDS out-slice
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;

@@ -54,7 +54,9 @@ __global__ __launch_bounds__(D2D_M2_THREADS) void d2d_fir_mfma2_kernel(Mfma2Args
     // the output frame, C = channels of this group (== CH except for the odd last channel of a
     // multichannel file, whose block runs the CH = 2 code with the second chain skipped).
     const uint32_t Ct = a.in_channels, Cs = a.epi.channels, sb = a.epi.sample_bytes;
-    const uint32_t fidx = blockIdx.y / m.ngroups, cbase = (blockIdx.y - fidx * m.ngroups) * 2u;
+    uint32_t fidx, grp_;                                         // (XCD-aware: the channel pairs of a file write into the same frames, d2d_device.h)
+    row_to_file_group(blockIdx.y, gridDim.y, m.ngroups, gridDim.x, fidx, grp_);
+    const uint32_t cbase = grp_ * 2u;
     const uint32_t C = m.ngroups == 1 ? Cs : (Cs - cbase < 2u ? Cs - cbase : 2u);
     const uint32_t fbytes = sb * C;                        // frame bytes inside the wave's LDS out-slice
     const uint32_t tid = threadIdx.x, lane = tid & 63;

@@ -72,7 +72,8 @@ __global__ __launch_bounds__(PX_THREADS) void d2d_fir_px_kernel(PxArgs a) {
     __syncthreads();
 
     const uint32_t C = a.epi.channels, Ct = a.in_channels;
-    const uint32_t file = blockIdx.y / a.ngroups, grp = blockIdx.y - file * a.ngroups;
+    uint32_t file, grp;
+    row_to_file_group(blockIdx.y, gridDim.y, a.ngroups, gridDim.x, file, grp);
     const uint32_t cbase = grp * a.cw;
     const uint32_t cwn = min(a.cw, C - cbase);                       // channels of this group (an odd count leaves a single)
     const StreamJob* jobs = a.jobs + (size_t)file * C + cbase;
@@ -358,6 +359,7 @@ __global__ __launch_bounds__(PX_THREADS) void d2d_fir_px_kernel(PxArgs a) {
                 for (uint32_t i = lane; i < (uint32_t)TILE; i += 64) {
                     const int64_t nl = nl0 + (int64_t)i;
                     if ((uint64_t)nl >= (uint64_t)nout) continue;
+                    if (cwn == 2) { store_pair_in_frame(out + (size_t)nl * fb, (uint32_t)ob[i], (uint32_t)ob[TILE + i], SBY); continue; }
                     for (uint32_t c = 0; c < cwn; ++c) {
                         const uint32_t w = (uint32_t)ob[c * TILE + i];
                         uint8_t* dst = out + (size_t)nl * fb + c * SBY;

@@ -82,7 +82,8 @@ __global__ __launch_bounds__(512) void d2d_resample_mfma_kernel(Rs2Args a) {
 
     const uint32_t C = a.epi.channels, cw_n = a.cw;
     const uint32_t ngroups = C / cw_n;
-    const uint32_t file = blockIdx.y / ngroups, grp = blockIdx.y - file * ngroups;
+    uint32_t file, grp;
+    row_to_file_group(blockIdx.y, gridDim.y, ngroups, gridDim.x, file, grp);
     const StreamJob* jobs = a.jobs + (size_t)file * C + (size_t)grp * cw_n;
     const StreamJob j0 = jobs[0];                                  // m0, nres, n0, nout, out are common to a file's channels
     const uint32_t nres = j0.nres;
@@ -314,6 +315,7 @@ __global__ __launch_bounds__(512) void d2d_resample_mfma_kernel(Rs2Args a) {
             for (uint32_t i = lane; i < tile_out; i += 64) {
                 const int32_t o = o_tile + (int32_t)i;
                 if ((uint32_t)o >= nres) continue;
+                if (cw_n == 2) { store_pair_in_frame(out + (size_t)(uint32_t)o * fb, ob[i], ob[tile_out + i], SBY); continue; }
                 for (uint32_t cw = 0; cw < cw_n; ++cw) {
                     const uint32_t w = ob[cw * tile_out + i];
                     uint8_t* dst = out + (size_t)(uint32_t)o * fb + cw * SBY;
