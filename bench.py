@@ -44,6 +44,8 @@ WORKLOADS = {
     "dsd64_to_88k2_s24_stereo": (1, 88200, 24, "T", 2, 32 / 8 + 3),
     "dsd64_to_88k2_s24_stereo_nodither": (1, 88200, 24, "X", 2, 32 / 8 + 3),
     "dsd64_to_88k2_s24_6ch": (1, 88200, 24, "T", 6, 32 / 8 + 3),          # a 5.1 stream, planar
+    "dsd64_to_88k2_s24_mono": (1, 88200, 24, "T", 1, 32 / 8 + 3),         # six of the reference's eleven fixtures are mono (test/1kHz_mono_p.dsf ...)
+    "dsd64_to_352k8_s24_mono": (1, 352800, 24, "T", 1, 8 / 8 + 3),        # run_all_tests.sh:8 / build_test_mono.sh convert mono at +4 dB (bench.py --level 4)
     "dsd64_to_88k2_s16_stereo": (1, 88200, 16, "T", 2, 32 / 8 + 2),
     "dsd64_to_88k2_f32_stereo": (1, 88200, 32, "X", 2, 32 / 8 + 4),
     "dsd64_to_176k4_s24_stereo": (1, 176400, 24, "T", 2, 16 / 8 + 3),

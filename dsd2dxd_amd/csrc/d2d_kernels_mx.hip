@@ -614,6 +614,27 @@ __global__ __launch_bounds__(D2D_MX_THREADS) void d2d_fir_mx_kernel(Mfma2Args m)
                 for (int k = 0; k < 3; ++k) if (nl + 6u * g + k < j0.nout) xs[6 * g + k] = v[3 * g + k];
         }
     };
+    // SCR, the pipelined loop: both channels' integers of a tile leave the slice as 16-byte rows along their scratch lines (a lane storing its
+    // own runs of three left every line to several partial writes: stage A wrote twice the bytes of its scratch, profiles/r03_summary_c5.txt)
+    auto store_scr_tile = [&](uint32_t tile) {
+        const uint32_t nl0 = tile * (uint32_t)TILE;
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            D2D_GLOBAL int32_t* xs = as_global(jobs[c].xs) + (size_t)nl0;
+#pragma unroll
+            for (int p = 0; p < QPASS; ++p) {
+                const uint32_t Q = lane + 64u * p;
+                if ((NQ % 64) != 0 && p == QPASS - 1 && Q >= (uint32_t)NQ) continue;
+                const i32x4 v = *reinterpret_cast<const i32x4*>(ob + c * TILE + 4 * Q);
+                if (nl0 + 4u * Q + 3u < j0.nout) *reinterpret_cast<D2D_GLOBAL i32x4*>(xs + 4u * Q) = v;
+                else {
+                    const int32_t e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) if (nl0 + 4u * Q + k < j0.nout) xs[4u * Q + k] = e[k];
+                }
+            }
+        }
+    };
     auto merge_extremes = [&](const Fast& f, uint32_t c) { vmn[c] = min(vmn[c], f.tmn); vmx[c] = max(vmx[c], f.tmx); };
 
     const uint32_t wv = coop ? blockIdx.x : blockIdx.x * m.nwaves + wave;       // this wave's (COOP: this block's) index among the file's tile workers
@@ -709,7 +730,7 @@ __global__ __launch_bounds__(D2D_MX_THREADS) void d2d_fir_mx_kernel(Mfma2Args m)
                 pin(accA);                      // the chain ends HERE (or the compiler sinks its MFMAs into the blocks that use them, behind the epilogue)
                 stamp(1);
                 if (have_prev) {
-                    if constexpr (SCR) store_scr(pw, 1, f.res);
+                    if constexpr (SCR) put_samples(1, f.res);
                     else {
                         if (!(dbg & 3) && fast_failed(f, pw)) { int32_t o[NS]; redo_acc(accB, pw, 1, o); put_samples(1, o); } else merge_extremes(f, 1);
                     }
@@ -727,6 +748,7 @@ __global__ __launch_bounds__(D2D_MX_THREADS) void d2d_fir_mx_kernel(Mfma2Args m)
             }
             if constexpr (AF) { if (!SCR) store_tile(pw, true); }
             else if (have_prev && !SCR) store_tile(pw);
+            if constexpr (SCR) { if (have_prev) { wave_sync2(); store_scr_tile(pw); } }
             wave_sync2();
             stamp(0);
             {
@@ -737,7 +759,7 @@ __global__ __launch_bounds__(D2D_MX_THREADS) void d2d_fir_mx_kernel(Mfma2Args m)
                 else chain(1u, accB, [&](auto uc) { fast_hook(f, accA, uc); });
                 pin(accB);
                 stamp(1);
-                if constexpr (SCR) store_scr(wt, 0, f.res);
+                if constexpr (SCR) put_samples(0, f.res);
                 else {
                     if (!(dbg & 3) && fast_failed(f, wt)) { int32_t o[NS]; redo_acc(accA, wt, 0, o); put_samples(0, o); } else merge_extremes(f, 0);
                 }
@@ -749,7 +771,7 @@ __global__ __launch_bounds__(D2D_MX_THREADS) void d2d_fir_mx_kernel(Mfma2Args m)
             Fast f;
             fast_begin(f, pw, 1);
             static_for<0, NJ>([&](auto jc) { fast_job(f, accB, jc); });
-            if constexpr (SCR) store_scr(pw, 1, f.res);
+            if constexpr (SCR) { put_samples(1, f.res); wave_sync2(); store_scr_tile(pw); wave_sync2(); }
             else {
                 if (fast_failed(f, pw)) { int32_t o[NS]; redo_acc(accB, pw, 1, o); put_samples(1, o); } else merge_extremes(f, 1);
                 wave_sync2();
@@ -988,7 +1010,7 @@ static hipError_t launch_mx_t(Mfma2Args& m, uint32_t max_nout, uint32_t nrows, h
     // LDS: the shared tap table, then per wave two stream buffers and the output slice; eight waves per block = two per SIMD
     m.off_waves = (uint32_t)mx_nf(MB, NT) * MX_FRAG_BYTES;
     m.off_out = 2u * (uint32_t)mx_stream_bytes(MB, NT, G);
-    m.wave_lds = m.off_out + (SBY ? 2u * TILE * 4u : 0u);
+    m.wave_lds = m.off_out + 2u * TILE * 4u;                 // (the scratch flavour too: its integers leave as rows of the slice)
     const uint32_t wdbg = (m.f.dbg_flags >> 8) & 0xFFu;   // diagnostic override (d2d_params.debug_flags bits 8..15)
     uint32_t nwaves = wdbg ? wdbg : (uint32_t)(D2D_MX_THREADS / 64);
     if (nwaves < 1 || nwaves > D2D_MX_THREADS / 64) nwaves = D2D_MX_THREADS / 64;
