@@ -101,6 +101,10 @@ struct d2d_engine {
     const d2d_poly_def* poly = nullptr;
     bool poly_plain = false;              // ... through the bit-by-bit kernel (D2D_KERNEL_LUT engines)
     bool cascade() const { return fc.resamp && !poly; }      // the two-kernel 48k path (DSD256 / DSD512 input)
+    // MONO2 (round 4): a mono stream on the fp6 pipelined kernel as a planar PAIR -- the two halves of a call converted side by side (FirArgs::mono2);
+    // calls it does not fit (odd sizes, very short ones) take the engine's ordinary mono kernel: same bytes either way
+    bool mono2_ok = false;
+    void* d_fir_tables_m2 = nullptr;
     bool il2 = false;                     // byte-interleaved stereo input de-interleaved inside the pipelined frame kernels' staging (FirArgs::il2)
     uint8_t* d_out = nullptr; size_t d_out_cap = 0;
 
@@ -160,6 +164,7 @@ static void free_device(d2d_engine* e) {
     if (e->d_peak) hipFree(e->d_peak);
     if (e->d_scratch) hipFree(e->d_scratch);
     if (e->d_fir_tables_lo) hipFree(e->d_fir_tables_lo);
+    if (e->d_fir_tables_m2) hipFree(e->d_fir_tables_m2);
     for (int i = 0; i < 2; ++i) if (e->d_ns[i]) hipFree(e->d_ns[i]);
     if (e->d_ns_dump) hipFree(e->d_ns_dump);
     if (e->d_ys) hipFree(e->d_ys);
@@ -375,6 +380,18 @@ int d2d_create(const d2d_params* params, uint32_t n_files, d2d_engine** out) {
             CK(hipMemcpy(e->d_fir_tables_lo, tl.data(), tl.size(), hipMemcpyHostToDevice));
         }
     }
+    if (!e->poly && e->kernel == D2D_KERNEL_MFMA && e->Cin == 1 && e->C == 1 && !e->fine && !e->noise_shape && !e->fc.resamp &&
+        !(e->p.debug_flags & (D2D_DBG_NO_PIPE | D2D_DBG_MFMA_V1 | D2D_DBG_NO_MX))) {
+        // would the stereo conversion of this format run the fp6 pipelined kernel?  Then so can a mono stream, two halves of a call at a time
+        FirArgs a2{}; fir_args_static(e, a2);
+        a2.epi.channels = 2; a2.in_channels = 2;
+        if (mfma2_pipelined(a2, e->M, e->N) == 5) {
+            const std::vector<int8_t> t2 = build_mx_tables(f, msb);
+            CK(hipMalloc(&e->d_fir_tables_m2, t2.size()));
+            CK(hipMemcpy(e->d_fir_tables_m2, t2.data(), t2.size(), hipMemcpyHostToDevice));
+            e->mono2_ok = true;
+        }
+    }
     if (e->fine) {
         if (e->kernel == D2D_KERNEL_LUT) {
             std::vector<double> tl = build_lut_tables(e->lo_def, e->Mb, msb);
@@ -405,7 +422,7 @@ int d2d_create(const d2d_params* params, uint32_t n_files, d2d_engine** out) {
     CK(hipMalloc((void**)&e->d_hist[0], hbytes));
     CK(hipMalloc((void**)&e->d_hist[1], hbytes));
     CK(hipMalloc((void**)&e->d_peak, sizeof(double) * e->nstreams));
-    const size_t njobs = (size_t)e->nstreams * (e->fine ? 2u : 1u);      // (32-bit taps: the second pass's jobs behind the first's)
+    const size_t njobs = (size_t)e->nstreams * (e->fine ? 2u : e->mono2_ok ? 3u : 1u);      // (32-bit taps: the second pass's jobs behind the first's; MONO2: the half-call jobs)
     CK(hipMalloc((void**)&e->d_jobs, sizeof(StreamJob) * njobs));
     CK(hipHostMalloc((void**)&e->h_jobs, sizeof(StreamJob) * njobs * JOB_SLOTS, hipHostMallocDefault));
     for (int i = 0; i < JOB_SLOTS; ++i) CK(hipEventCreateWithFlags(&e->job_ev[i], hipEventDisableTiming));
@@ -509,7 +526,7 @@ int d2d_translate_batch_device(d2d_engine* e, d2d_file_io* io, uint32_t n_files,
     const int slot = e->job_slot;
     e->job_slot = (slot + 1) % JOB_SLOTS;
     if (e->job_ev_used[slot]) HIPCHK(e, hipEventSynchronize(e->job_ev[slot]));
-    const size_t njobs = (size_t)e->nstreams * (e->fine ? 2u : 1u);
+    const size_t njobs = (size_t)e->nstreams * (e->fine ? 2u : e->mono2_ok ? 3u : 1u);
     StreamJob* hj = e->h_jobs + (size_t)slot * njobs;
     const int cur = e->hist_cur;
     for (uint32_t f = 0; f < n_files; ++f) {
@@ -540,6 +557,26 @@ int d2d_translate_batch_device(d2d_engine* e, d2d_file_io* io, uint32_t n_files,
             j.rng_lo0 = (uint32_t)i0;
         }
     }
+    // MONO2: every file's call splits into two equal halves of whole outputs and whole 16-byte chunks, long enough to hold the second half's history
+    bool mono2 = e->mono2_ok && max_nx > 0;
+    for (uint32_t f = 0; f < n_files && mono2; ++f) {
+        const StreamJob& j = hj[f];
+        const uint64_t half = j.L / 2;
+        mono2 = (j.L % 2 == 0) && (half % 16 == 0) && (half % (uint64_t)e->Mb == 0) && half >= e->keep && (j.nout % 2 == 0) &&
+                (uint64_t)(uint32_t)j.n0 + j.nout <= 0xFFFFFFFFull;
+    }
+    if (mono2)
+        for (uint32_t f = 0; f < n_files; ++f) {
+            StreamJob ja = hj[f];
+            const uint64_t half = ja.L / 2;
+            ja.L = half; ja.nout /= 2; ja.ch = 0; ja.och = 0;
+            StreamJob jb = ja;
+            jb.ch = 1;
+            jb.hist = ja.in + half - e->keep;                           // the end of the first half
+            jb.out = (uint8_t*)ja.out + (size_t)ja.nout * fb;
+            jb.rng_key = ja.rng_key + ja.nout;                          // (the kernel hashes (first half's index + key): the second half's indices lie nout further on)
+            hj[e->nstreams + 2 * f] = ja; hj[e->nstreams + 2 * f + 1] = jb;
+        }
     if (e->fine)
         for (uint32_t i = 0; i < e->nstreams; ++i) { hj[e->nstreams + i] = hj[i]; hj[e->nstreams + i].xs = hj[i].xs + (size_t)e->nstreams * e->scratch_stride; }
     HIPCHK(e, hipMemcpyAsync(e->d_jobs, hj, sizeof(StreamJob) * njobs, hipMemcpyHostToDevice, s));
@@ -582,6 +619,12 @@ int d2d_translate_batch_device(d2d_engine* e, d2d_file_io* io, uint32_t n_files,
         px.epi = e->epi;
         if (e->poly_plain) HIPCHK(e, launch_poly_plain(px, *e->poly, max_frames, e->nstreams, s));
         else HIPCHK(e, launch_fir_px(px, *e->poly, max_frames, n_files, s));
+    } else if (mono2) {
+        FirArgs a2 = a;
+        a2.jobs = e->d_jobs + e->nstreams; a2.tables = e->d_fir_tables_m2;
+        a2.epi.channels = 2; a2.in_channels = 2; a2.B = 0x40000000u;     // (one "block" per half: the gather path's layout rule then reads half c at c * half)
+        a2.pipelined = 5; a2.mono2 = 1;
+        HIPCHK(e, launch_fir_mfma2(a2, e->M, e->N, max_nx / 2, 2 * n_files, s));
     } else if (max_nx) {
         if (e->kernel == D2D_KERNEL_LUT) {
             const uint32_t per_tile = lut_outputs_per_tile(e->Mb);

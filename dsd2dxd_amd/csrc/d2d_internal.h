@@ -68,6 +68,8 @@ struct FirArgs {
                                // pulls the channels apart (one v_perm_b32 per channel and eight input bytes); B = 1, no planar copy
     uint32_t mx_exact;         // 1: the table's base-32 digit sums recombine exactly in f32 (d2d_mx.h: mx_exact)
     uint32_t dbg_flags;        // d2d_params.debug_flags (D2D_DBG_*), fixed when the engine was created
+    uint32_t mono2;            // 1 (d2d_kernels_mx.hip, frames): a MONO stream served as a planar pair -- jobs 2 f, 2 f + 1 are the two halves of file f's call
+                               // (equal lengths and outputs; the second's history is the end of the first, its frames follow the first's)
     Epilogue epi;
 };
 

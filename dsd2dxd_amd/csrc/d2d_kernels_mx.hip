@@ -144,18 +144,24 @@ __global__ __launch_bounds__(D2D_MX_THREADS) void d2d_fir_mx_kernel(Mfma2Args m)
                 wad[i][k] = pad_addr(L, (uint32_t)k);
             }
     }
-    const uint32_t Bsz = a.B, Lcall = (uint32_t)j0.L;
+    // MONO2 (a.mono2): a MONO stream served as a planar pair -- "channel" 0 = the first half of the call's bytes, "channel" 1 = the second half
+    // (its history: the end of the first half), each with its own frames: the two halves of the call are converted side by side by the
+    // stereo machinery and leave as two mono streams.  Its one "block" is the half call: as a power of two past every offset (2^31) the
+    // block arithmetic below degenerates to base + offset.
+    const bool mono2 = a.mono2 != 0;
+    const uint32_t Bsz = mono2 ? 0x80000000u : a.B, Lcall = (uint32_t)j0.L;
     const bool pow2B = Bsz >= 16 && (Bsz & (Bsz - 1)) == 0;
     const uint32_t bshift = pow2B ? 31 - __builtin_clz(Bsz) : 0;
-    const uint32_t full_bytes = il ? Lcall : pow2B ? (Lcall >> bshift) << bshift : 0;
+    const uint32_t full_bytes = il || mono2 ? Lcall : pow2B ? (Lcall >> bshift) << bshift : 0;
     const uint32_t jump = (Ct - 1u) * Bsz;
-    const bool fast_layout = pow2B && (uint64_t)full_bytes * Ct < (1ull << 32) && jump < (1u << 24);
+    const bool fast_layout = mono2 || (pow2B && (uint64_t)full_bytes * Ct < (1ull << 32) && jump < (1u << 24));
     auto tile_ab16 = [&](uint32_t w) -> int32_t { return (int32_t)((first0 + (int64_t)w * (TILE * MB)) & ~(int64_t)15); };
 
     uint32_t lofs[PF];
 #pragma unroll
     for (int i = 0; i < PF; ++i) { const uint32_t q = lane + 64u * i; lofs[i] = 16u * (q < (uint32_t)NCHK ? q : (uint32_t)NCHK - 1u); }
     const uint32_t chf[2] = {(uint32_t)__builtin_amdgcn_readfirstlane((int)jobs[0].ch), (uint32_t)__builtin_amdgcn_readfirstlane((int)jobs[1].ch)};
+    const uint64_t chan_off[2] = {mono2 ? 0ull : (uint64_t)chf[0] << bshift, mono2 ? (uint64_t)Lcall : (uint64_t)chf[1] << bshift};
     // one prefetch register set: a channel's bytes are requested one chain ahead (about two microseconds)
     u32x4 pf[PF];
     auto issue_loads = [&](uint32_t w, auto cc, auto af) {
@@ -164,7 +170,7 @@ __global__ __launch_bounds__(D2D_MX_THREADS) void d2d_fir_mx_kernel(Mfma2Args m)
         const int32_t ab = tile_ab16(w);
         if (AF || (fast_layout && ab >= 0 && (uint32_t)ab + 16u * NCHK <= full_bytes)) {
             const uint32_t blk0 = (uint32_t)ab >> bshift, r0 = (uint32_t)ab & (Bsz - 1);
-            const uint8_t* base = j0.in + ((uint64_t)(blk0 * Ct + chf[c]) << bshift);
+            const uint8_t* base = j0.in + ((uint64_t)(blk0 * Ct) << bshift) + chan_off[c];
 #pragma unroll
             for (int i = 0; i < PF; ++i) {
                 const uint32_t off = r0 + lofs[i];
@@ -343,6 +349,7 @@ __global__ __launch_bounds__(D2D_MX_THREADS) void d2d_fir_mx_kernel(Mfma2Args m)
         for (int g = 0; g < G; ++g) asm volatile("" : "+v"(acc[g]));
     };
 
+    uint8_t* const mono_out[2] = {reinterpret_cast<uint8_t*>(jobs[0].out), reinterpret_cast<uint8_t*>(jobs[1].out)};      // (MONO2: each half's own frames)
     // dither keys of the two channels (uniform)
     uint32_t rkey[2], rstep[2], rlo0[2];
 #pragma unroll
@@ -562,6 +569,43 @@ __global__ __launch_bounds__(D2D_MX_THREADS) void d2d_fir_mx_kernel(Mfma2Args m)
         const bool full = known_full || tile_full(tile);
         uint8_t* gout = reinterpret_cast<uint8_t*>(j0.out) + (size_t)tile * (TILE * FB);
         const uint32_t nl0 = tile * (uint32_t)TILE;
+        if constexpr (SBY != 0) {
+            if (mono2) {
+                // two mono streams: a lane takes four consecutive samples of a half (12 / 8 / 16 contiguous bytes; the second half's frames start at
+                // any byte of the caller's buffer)
+                typedef uint32_t u32x3_a1 __attribute__((ext_vector_type(3), aligned(1)));
+                typedef uint32_t u32x2_a1 __attribute__((ext_vector_type(2), aligned(1)));
+                typedef uint32_t u32x4_a1 __attribute__((ext_vector_type(4), aligned(1)));
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    uint8_t* gc = mono_out[c] + (size_t)nl0 * SBY;
+#pragma unroll
+                    for (int p = 0; p < QPASS; ++p) {
+                        const uint32_t Q = lane + 64u * p;
+                        if ((NQ % 64) != 0 && p == QPASS - 1 && Q >= (uint32_t)NQ) continue;
+                        const i32x4 v = *reinterpret_cast<const i32x4*>(ob + c * TILE + 4 * Q);
+                        const uint32_t s0 = (uint32_t)v.x, s1 = (uint32_t)v.y, s2 = (uint32_t)v.z, s3 = (uint32_t)v.w;
+                        uint8_t* gq = gc + 4u * SBY * Q;
+                        if (full) {
+                            if (dbg & 64) { asm volatile("" :: "v"(v)); continue; }
+                            if constexpr (SBY == 3) *reinterpret_cast<D2D_GLOBAL u32x3_a1*>(as_global(gq)) = u32x3_a1{(s0 & 0x00FFFFFFu) | (s1 << 24), ((s1 >> 8) & 0xFFFFu) | (s2 << 16), ((s2 >> 16) & 0xFFu) | (s3 << 8)};
+                            else if constexpr (SBY == 2) *reinterpret_cast<D2D_GLOBAL u32x2_a1*>(as_global(gq)) = u32x2_a1{(s0 & 0xFFFFu) | (s1 << 16), (s2 & 0xFFFFu) | (s3 << 16)};
+                            else *reinterpret_cast<D2D_GLOBAL u32x4_a1*>(as_global(gq)) = u32x4_a1{s0, s1, s2, s3};
+                        } else {
+                            const uint32_t sv[4] = {s0, s1, s2, s3};
+#pragma unroll
+                            for (int k = 0; k < 4; ++k)
+                                if (nl0 + 4u * Q + k < j0.nout) {
+                                    D2D_GLOBAL uint8_t* pb = as_global(gq + SBY * k);
+#pragma unroll
+                                    for (int b = 0; b < SBY; ++b) pb[b] = (uint8_t)(sv[k] >> (8 * b));
+                                }
+                        }
+                    }
+                }
+                return;
+            }
+        }
 #pragma unroll
         for (int p = 0; p < QPASS; ++p) {
             const uint32_t Q = lane + 64u * p;

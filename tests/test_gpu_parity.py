@@ -546,3 +546,45 @@ def test_m128_on_the_fp6_kernel_with_several_tiles_per_wave(engine_lib, oracle_m
     assert e.kernel_name().startswith("d2d_fir_mx_kernel<16, 2192, 1,"), e.kernel_name()
     assert gf == wf and np.array_equal(g, w[:wf * e.frame_bytes])
     assert [e.peak(c) for c in range(2)] == [o.peak(c) for c in range(2)]
+
+
+@pytest.mark.parametrize("dsd_rate,out_rate,filt", [(1, 88200, "E"), (1, 88200, "X"), (2, 88200, "E"), (4, 176400, "E"), (4, 88200, "E")])
+@pytest.mark.parametrize("bits,dither,level", [(24, "T", 0.0), (16, "R", 0.0), (32, "X", 0.0), (24, "T", 4.0), (20, "T", 0.0), (32, "F", -3.0), (24, "X", 0.0)])
+def test_mono_streams_as_a_planar_pair_on_the_pipelined_kernel(engine_lib, oracle_mod, dsd_rate, out_rate, filt, bits, dither, level):
+    """a MONO stream on the fp6 pipelined kernel (round 4, FirArgs::mono2): the two halves of a call are converted side by side as the two
+    "channels" of a planar pair -- the second half's history is the end of the first, its dither indices and frames follow the first's -- and
+    leave as one mono stream.  Calls that do not split into two equal halves of whole outputs and 16-byte chunks (odd sizes, very short
+    ones) take the ordinary mono kernel; the bytes are the oracle's either way, in any sequence of calls, peaks included."""
+    nbytes = 4096 * 40 * dsd_rate
+    x = synth("sine", nbytes, seed=31, dsd_rate=dsd_rate, amp=0.5).copy()
+    x[5000:7000] = 0xFF; x[90000:91500] = 0x00                       # full-scale stretches: both rails at the integer depths
+    kw = dict(dsd_rate=dsd_rate, output_rate=out_rate, channels=1, fmt="P", endianness="L", block_size=4096, filter=filt, bit_depth=bits,
+              dither=dither, seed=77, level_db=level)
+    cuts = [0, 4096 * 8, 4096 * 8 + 4096 * 16, 4096 * 24 + 1000, 4096 * 24 + 1000 + 8192 * dsd_rate, nbytes - 4096, nbytes]
+    e = engine_lib.Engine(kernel=2, **kw)
+    o = oracle_mod.Oracle(**kw)
+    names = []
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        g, gf = e.translate(x[a:b])
+        r, rf = o.translate(x[a:b])
+        assert gf == rf and np.array_equal(g, r[:rf * o.frame_bytes]), (a, b, e.kernel_name())
+        names.append(e.kernel_name())
+    assert names[0].startswith("d2d_fir_mx_kernel") and names[1].startswith("d2d_fir_mx_kernel")       # whole blocks: the pair route
+    assert not names[2].startswith("d2d_fir_mx_kernel")                                                 # 4096 * 16 + 1000 bytes: the ordinary mono kernel
+    assert e.peak(0) == o.peak(0)
+    # a batch of files of different lengths in one launch takes the pair route only if every file's call fits
+    import torch
+    lens = [4096 * 6 * dsd_rate, 4096 * 4 * dsd_rate, 4096 * 10 * dsd_rate]
+    eb = engine_lib.Engine(n_files=3, kernel=2, **kw)
+    d_in = [torch.from_numpy(x[:n].copy()).cuda() for n in lens]
+    d_out = [torch.zeros(eb.next_frames(n, file=i) * eb.frame_bytes + 16, dtype=torch.uint8, device="cuda") for i, n in enumerate(lens)]
+    ios = (engine_lib.FileIO * 3)()
+    for i, n in enumerate(lens):
+        ios[i].dsd = d_in[i].data_ptr(); ios[i].bytes_per_channel = n
+        ios[i].pcm = d_out[i].data_ptr(); ios[i].pcm_capacity_bytes = d_out[i].numel()
+    eb.translate_batch_device(ios, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert eb.kernel_name().startswith("d2d_fir_mx_kernel")
+    for i, n in enumerate(lens):
+        w, fr = oracle_mod.Oracle(**kw).translate(x[:n])
+        assert ios[i].frames_out == fr and np.array_equal(d_out[i][:fr * eb.frame_bytes].cpu().numpy(), w[:fr * eb.frame_bytes]), i
