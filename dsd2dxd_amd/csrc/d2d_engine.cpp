@@ -104,6 +104,7 @@ struct d2d_engine {
     // MONO2 (round 4): a mono stream on the fp6 pipelined kernel as a planar PAIR -- the two halves of a call converted side by side (FirArgs::mono2);
     // calls it does not fit (odd sizes, very short ones) take the engine's ordinary mono kernel: same bytes either way
     bool mono2_ok = false;
+    int mono2_pipe = 0;                   // 5: the fp6 kernel (M = 32, 64, 128), 3: the int8 pipelined kernel (M = 8, 16)
     void* d_fir_tables_m2 = nullptr;
     bool il2 = false;                     // byte-interleaved stereo input de-interleaved inside the pipelined frame kernels' staging (FirArgs::il2)
     uint8_t* d_out = nullptr; size_t d_out_cap = 0;
@@ -382,11 +383,13 @@ int d2d_create(const d2d_params* params, uint32_t n_files, d2d_engine** out) {
     }
     if (!e->poly && e->kernel == D2D_KERNEL_MFMA && e->Cin == 1 && e->C == 1 && !e->fine && !e->noise_shape && !e->fc.resamp &&
         !(e->p.debug_flags & (D2D_DBG_NO_PIPE | D2D_DBG_MFMA_V1 | D2D_DBG_NO_MX))) {
-        // would the stereo conversion of this format run the fp6 pipelined kernel?  Then so can a mono stream, two halves of a call at a time
+        // would the stereo conversion of this format run a pipelined kernel?  Then so can a mono stream, two halves of a call at a time
         FirArgs a2{}; fir_args_static(e, a2);
         a2.epi.channels = 2; a2.in_channels = 2;
-        if (mfma2_pipelined(a2, e->M, e->N) == 5) {
-            const std::vector<int8_t> t2 = build_mx_tables(f, msb);
+        const int p2 = mfma2_pipelined(a2, e->M, e->N);
+        if (p2 == 5 || p2 == 3) {
+            const std::vector<int8_t> t2 = p2 == 5 ? build_mx_tables(f, msb) : build_mfma2_tables(f, msb, false);
+            e->mono2_pipe = p2;
             CK(hipMalloc(&e->d_fir_tables_m2, t2.size()));
             CK(hipMemcpy(e->d_fir_tables_m2, t2.data(), t2.size(), hipMemcpyHostToDevice));
             e->mono2_ok = true;
@@ -623,7 +626,7 @@ int d2d_translate_batch_device(d2d_engine* e, d2d_file_io* io, uint32_t n_files,
         FirArgs a2 = a;
         a2.jobs = e->d_jobs + e->nstreams; a2.tables = e->d_fir_tables_m2;
         a2.epi.channels = 2; a2.in_channels = 2; a2.B = 0x40000000u;     // (one "block" per half: the gather path's layout rule then reads half c at c * half)
-        a2.pipelined = 5; a2.mono2 = 1;
+        a2.pipelined = (uint32_t)e->mono2_pipe; a2.mono2 = 1;
         HIPCHK(e, launch_fir_mfma2(a2, e->M, e->N, max_nx / 2, 2 * n_files, s));
     } else if (max_nx) {
         if (e->kernel == D2D_KERNEL_LUT) {

@@ -134,7 +134,10 @@ __global__ __launch_bounds__(D2D_M3_THREADS) void d2d_fir_mfma3_kernel(Mfma2Args
         const uint32_t Ll = 4u * q - X0;
         wlo[i] = q == 0 ? DUMMY : 4u * (Ll + (Ll >> LSH));
     }
-    const uint32_t Bsz = a.B, Lcall = (uint32_t)j0.L;
+    // MONO2 (a.mono2, d2d_kernels_mx.hip has the long comment): a mono stream as a planar pair -- "channel" c = half c of the call's bytes; as
+    // one "block" of 2^31 bytes the block arithmetic below degenerates to base + offset
+    const bool mono2 = a.mono2 != 0;
+    const uint32_t Bsz = mono2 ? 0x80000000u : a.B, Lcall = (uint32_t)j0.L;
     const bool pow2B = Bsz >= 16 && (Bsz & (Bsz - 1)) == 0;
     const uint32_t bshift = pow2B ? 31 - __builtin_clz(Bsz) : 0;
     // IL (a.il2: byte-interleaved stereo -- DFF files, the CLI's default -f I -- both channels converted, M < 64; the scratch flavour too): the
@@ -142,7 +145,7 @@ __global__ __launch_bounds__(D2D_M3_THREADS) void d2d_fir_mfma3_kernel(Mfma2Args
     // one v_perm_b32 per channel and dword pair pulls a channel's eight bytes = its stream dwords 2 g, 2 g + 1 (run_loop below)
     constexpr bool ILK = MB < 8;
     const bool il = ILK && a.il2 != 0;
-    const uint32_t full_bytes = il ? Lcall : pow2B ? (Lcall >> bshift) << bshift : 0;
+    const uint32_t full_bytes = il || mono2 ? Lcall : pow2B ? (Lcall >> bshift) << bshift : 0;
     uint32_t wil[ILK ? 2 * PF : 1][2];
     if constexpr (ILK) {
 #pragma unroll
@@ -154,7 +157,7 @@ __global__ __launch_bounds__(D2D_M3_THREADS) void d2d_fir_mfma3_kernel(Mfma2Args
             }
     }
     const uint32_t jump = (Ct - 1u) * Bsz;
-    const bool fast_layout = pow2B && (uint64_t)full_bytes * Ct < (1ull << 32) && jump < (1u << 24);
+    const bool fast_layout = mono2 || (pow2B && (uint64_t)full_bytes * Ct < (1ull << 32) && jump < (1u << 24));
     auto tile_ab16 = [&](uint32_t w) -> int32_t { return (int32_t)((first0 + (int64_t)w * (M2_TILE * MB)) & ~(int64_t)15); };
 
     // per-lane chunk offsets: lanes past the last chunk of a tile re-read it (their LDS writes are masked off), so the loads
@@ -163,6 +166,8 @@ __global__ __launch_bounds__(D2D_M3_THREADS) void d2d_fir_mfma3_kernel(Mfma2Args
 #pragma unroll
     for (int i = 0; i < PF; ++i) { const uint32_t q = lane + 64u * i; lofs[i] = 16u * (q < (uint32_t)NCHK ? q : (uint32_t)NCHK - 1u); }
     const uint32_t chf[2] = {(uint32_t)__builtin_amdgcn_readfirstlane((int)jobs[0].ch), (uint32_t)__builtin_amdgcn_readfirstlane((int)jobs[1].ch)};
+    const uint64_t chan_off[2] = {mono2 ? 0ull : (uint64_t)chf[0] << bshift, mono2 ? (uint64_t)Lcall : (uint64_t)chf[1] << bshift};
+    uint8_t* const mono_out[2] = {reinterpret_cast<uint8_t*>(jobs[0].out), reinterpret_cast<uint8_t*>(jobs[1].out)};      // (MONO2: each half's own frames)
     // M = 32: one prefetch register set per channel, a tile's bytes are requested a whole tile ahead; M = 64 (five chunks per lane and
     // channel, no registers to spare): one set, a chain's bytes are requested one chain ahead
     constexpr int NPFSET = MB >= 8 ? 1 : 2;
@@ -175,7 +180,7 @@ __global__ __launch_bounds__(D2D_M3_THREADS) void d2d_fir_mfma3_kernel(Mfma2Args
         const int32_t ab = tile_ab16(w);
         if (AF || (fast_layout && ab >= 0 && (uint32_t)ab + 16u * NCHK <= full_bytes)) {
             const uint32_t blk0 = (uint32_t)ab >> bshift, r0 = (uint32_t)ab & (Bsz - 1);
-            const uint8_t* base = j0.in + ((uint64_t)(blk0 * Ct + chf[c]) << bshift);
+            const uint8_t* base = j0.in + ((uint64_t)(blk0 * Ct) << bshift) + chan_off[c];
 #pragma unroll
             for (int i = 0; i < PF; ++i) {
                 const uint32_t off = r0 + lofs[i];
@@ -464,7 +469,18 @@ __global__ __launch_bounds__(D2D_M3_THREADS) void d2d_fir_mfma3_kernel(Mfma2Args
             for (int g = 0; g < 2; ++g) {
                 const uint32_t La = L[4 * g], Ra = R[4 * g], Lb = L[4 * g + 1], Rb = R[4 * g + 1];
                 const uint32_t Lc = L[4 * g + 2], Rc = R[4 * g + 2], Ld = L[4 * g + 3], Rd = R[4 * g + 3];
-                if constexpr (SBY == 3) {
+                if (mono2) {
+                    // two mono streams: the lane's four consecutive samples of each half, 12 / 8 / 16 contiguous bytes per half
+                    if constexpr (SBY == 3) {
+                        p4[g] = u32x4{(La & 0x00FFFFFFu) | (Lb << 24), ((Lb >> 8) & 0xFFFFu) | (Lc << 16), ((Lc >> 16) & 0xFFu) | (Ld << 8), (Ra & 0x00FFFFFFu) | (Rb << 24)};
+                        p2[g] = u32x4{((Rb >> 8) & 0xFFFFu) | (Rc << 16), ((Rc >> 16) & 0xFFu) | (Rd << 8), 0u, 0u};
+                    } else if constexpr (SBY == 4) {
+                        p4[g] = u32x4{La, Lb, Lc, Ld};
+                        p2[g] = u32x4{Ra, Rb, Rc, Rd};
+                    } else {
+                        p4[g] = u32x4{(La & 0xFFFFu) | (Lb << 16), (Lc & 0xFFFFu) | (Ld << 16), (Ra & 0xFFFFu) | (Rb << 16), (Rc & 0xFFFFu) | (Rd << 16)};
+                    }
+                } else if constexpr (SBY == 3) {
                     // frames k, k+1 -> 12 bytes: [L0 L1 L2 R0 | R1 R2 L0' L1' | L2' R0' R1' R2']
                     p4[g] = u32x4{__builtin_amdgcn_perm(Ra, La, 0x04020100u), __builtin_amdgcn_perm(Lb, Ra, 0x05040201u),
                                   __builtin_amdgcn_perm(Rb, Lb, 0x06050402u), __builtin_amdgcn_perm(Rc, Lc, 0x04020100u)};
@@ -489,6 +505,14 @@ __global__ __launch_bounds__(D2D_M3_THREADS) void d2d_fir_mfma3_kernel(Mfma2Args
                     uint32_t Lv = 0, Rv = 0;
 #pragma unroll
                     for (int q = 0; q < 8; ++q) { Lv = i == q ? (uint32_t)L[q] : Lv; Rv = i == q ? (uint32_t)R[q] : Rv; }
+                    if (mono2) {
+                        constexpr uint32_t SBm = SBY ? SBY : 1;
+                        D2D_GLOBAL uint8_t* pl = as_global(mono_out[0] + (size_t)(nl_base + 8u * g + k) * SBm);
+                        D2D_GLOBAL uint8_t* pr = as_global(mono_out[1] + (size_t)(nl_base + 8u * g + k) * SBm);
+#pragma unroll
+                        for (uint32_t b = 0; b < SBm; ++b) { pl[b] = (uint8_t)(Lv >> (8 * b)); pr[b] = (uint8_t)(Rv >> (8 * b)); }
+                        continue;
+                    }
                     D2D_GLOBAL uint16_t* p16 = reinterpret_cast<D2D_GLOBAL uint16_t*>(as_global(gout + 8u * FB * g + FB * k));
                     if constexpr (SBY == 3) { p16[0] = (uint16_t)Lv; p16[1] = (uint16_t)(((Lv >> 16) & 0xFFu) | (Rv << 8)); p16[2] = (uint16_t)(Rv >> 8); }
                     else if constexpr (SBY == 4) { p16[0] = (uint16_t)Lv; p16[1] = (uint16_t)(Lv >> 16); p16[2] = (uint16_t)Rv; p16[3] = (uint16_t)(Rv >> 16); }
@@ -499,6 +523,33 @@ __global__ __launch_bounds__(D2D_M3_THREADS) void d2d_fir_mfma3_kernel(Mfma2Args
     };
     auto store_packed = [&](uint32_t tile, const u32x4 (&p4)[2], const u32x4 (&p2)[2], bool known_full = false) {
         if (!known_full && !tile_full(tile)) return;
+        if constexpr (!SCR) {
+            if (mono2) {
+                // (straight from the registers at every M: staging the halves through LDS as the stereo frames of M = 8 are was measured, 4.12 against 4.05 ms)
+                typedef uint32_t u32x3_a1 __attribute__((ext_vector_type(3), aligned(1)));
+                typedef uint32_t u32x2_a1 __attribute__((ext_vector_type(2), aligned(1)));
+                typedef uint32_t u32x4_a1 __attribute__((ext_vector_type(4), aligned(1)));
+                constexpr uint32_t SBm = SBY ? SBY : 1;
+                const size_t at = ((size_t)tile * M2_TILE + lane_fr) * SBm;
+#pragma unroll
+                for (int g = 0; g < 2; ++g) {
+                    if (dbg & 64) { asm volatile("" :: "v"(p4[g]), "v"(p2[g])); continue; }
+                    uint8_t* gl = mono_out[0] + at + 8u * SBm * g;
+                    uint8_t* gr = mono_out[1] + at + 8u * SBm * g;
+                    if constexpr (SBY == 3) {
+                        *reinterpret_cast<D2D_GLOBAL u32x3_a1*>(as_global(gl)) = u32x3_a1{p4[g].x, p4[g].y, p4[g].z};
+                        *reinterpret_cast<D2D_GLOBAL u32x3_a1*>(as_global(gr)) = u32x3_a1{p4[g].w, p2[g].x, p2[g].y};
+                    } else if constexpr (SBY == 4) {
+                        *reinterpret_cast<D2D_GLOBAL u32x4_a1*>(as_global(gl)) = u32x4_a1{p4[g].x, p4[g].y, p4[g].z, p4[g].w};
+                        *reinterpret_cast<D2D_GLOBAL u32x4_a1*>(as_global(gr)) = u32x4_a1{p2[g].x, p2[g].y, p2[g].z, p2[g].w};
+                    } else {
+                        *reinterpret_cast<D2D_GLOBAL u32x2_a1*>(as_global(gl)) = u32x2_a1{p4[g].x, p4[g].y};
+                        *reinterpret_cast<D2D_GLOBAL u32x2_a1*>(as_global(gr)) = u32x2_a1{p4[g].z, p4[g].w};
+                    }
+                }
+                return;
+            }
+        }
         if constexpr (D2D_M3_STAGED && MB == 1 && !SCR) {
             // M = 8: the stores are what this shape waits for (profiles/r02_experiments.txt item 17): the tile's frames through
             // LDS, then 16 bytes per lane along the tile -- every store instruction writes eight whole, aligned lines

@@ -548,10 +548,11 @@ def test_m128_on_the_fp6_kernel_with_several_tiles_per_wave(engine_lib, oracle_m
     assert [e.peak(c) for c in range(2)] == [o.peak(c) for c in range(2)]
 
 
-@pytest.mark.parametrize("dsd_rate,out_rate,filt", [(1, 88200, "E"), (1, 88200, "X"), (2, 88200, "E"), (4, 176400, "E"), (4, 88200, "E")])
+@pytest.mark.parametrize("dsd_rate,out_rate,filt", [(1, 88200, "E"), (1, 88200, "X"), (2, 88200, "E"), (4, 176400, "E"), (4, 88200, "E"),
+                                                    (1, 352800, "E"), (1, 176400, "E"), (2, 352800, "C"), (1, 352800, "D"), (4, 1411200, "E")])
 @pytest.mark.parametrize("bits,dither,level", [(24, "T", 0.0), (16, "R", 0.0), (32, "X", 0.0), (24, "T", 4.0), (20, "T", 0.0), (32, "F", -3.0), (24, "X", 0.0)])
 def test_mono_streams_as_a_planar_pair_on_the_pipelined_kernel(engine_lib, oracle_mod, dsd_rate, out_rate, filt, bits, dither, level):
-    """a MONO stream on the fp6 pipelined kernel (round 4, FirArgs::mono2): the two halves of a call are converted side by side as the two
+    """a MONO stream on the pipelined kernels (round 4, FirArgs::mono2; fp6 at M = 32 / 64 / 128, int8 at M = 8 / 16): the two halves of a call are converted side by side as the two
     "channels" of a planar pair -- the second half's history is the end of the first, its dither indices and frames follow the first's -- and
     leave as one mono stream.  Calls that do not split into two equal halves of whole outputs and 16-byte chunks (odd sizes, very short
     ones) take the ordinary mono kernel; the bytes are the oracle's either way, in any sequence of calls, peaks included."""
@@ -569,8 +570,9 @@ def test_mono_streams_as_a_planar_pair_on_the_pipelined_kernel(engine_lib, oracl
         r, rf = o.translate(x[a:b])
         assert gf == rf and np.array_equal(g, r[:rf * o.frame_bytes]), (a, b, e.kernel_name())
         names.append(e.kernel_name())
-    assert names[0].startswith("d2d_fir_mx_kernel") and names[1].startswith("d2d_fir_mx_kernel")       # whole blocks: the pair route
-    assert not names[2].startswith("d2d_fir_mx_kernel")                                                 # 4096 * 16 + 1000 bytes: the ordinary mono kernel
+    pair = "d2d_fir_mx_kernel" if 2822400 * dsd_rate // out_rate >= 32 else "d2d_fir_mfma3_kernel"
+    assert names[0].startswith(pair) and names[1].startswith(pair)                                      # whole blocks: the pair route
+    assert not names[2].startswith(pair)                                                                # 4096 * 16 + 1000 bytes: the ordinary mono kernel
     assert e.peak(0) == o.peak(0)
     # a batch of files of different lengths in one launch takes the pair route only if every file's call fits
     import torch
@@ -584,7 +586,7 @@ def test_mono_streams_as_a_planar_pair_on_the_pipelined_kernel(engine_lib, oracl
         ios[i].pcm = d_out[i].data_ptr(); ios[i].pcm_capacity_bytes = d_out[i].numel()
     eb.translate_batch_device(ios, torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize()
-    assert eb.kernel_name().startswith("d2d_fir_mx_kernel")
+    assert eb.kernel_name().startswith(pair)
     for i, n in enumerate(lens):
         w, fr = oracle_mod.Oracle(**kw).translate(x[:n])
         assert ios[i].frames_out == fr and np.array_equal(d_out[i][:fr * eb.frame_bytes].cpu().numpy(), w[:fr * eb.frame_bytes]), i
