@@ -58,6 +58,8 @@ WORKLOADS = {
     "dsd64_to_96k_s24_stereo": (1, 96000, 24, "T", 2, 29.4 / 8 + 3),
     "dsd64_to_192k_s24_stereo": (1, 192000, 24, "T", 2, 14.7 / 8 + 3),
     "dsd128_to_384k_s24_stereo": (2, 384000, 24, "T", 2, 14.7 / 8 + 3),
+    "dsd128_to_96k_s24_stereo": (2, 96000, 24, "T", 2, 58.8 / 8 + 3),
+    "dsd256_to_192k_s24_stereo": (4, 192000, 24, "T", 2, 58.8 / 8 + 3),     # the reference README's other recommended setting (README.md:223-228)
     "dsd512_to_96k_s24_8ch": (8, 96000, 24, "T", 8, 235.2 / 8 + 3),      # config 5: byte-interleaved MSB-first
     "dsd64_to_88k2_s24_stereo_dff": (1, 88200, 24, "T", 2, 32 / 8 + 3),   # the reference CLI's default input format (-f I; DFF files): byte-interleaved MSB-first
     "dsd64_to_352k8_s24_stereo_dff": (1, 352800, 24, "T", 2, 8 / 8 + 3),  # ... at the CLI's default output rate

@@ -566,7 +566,7 @@ __global__ __launch_bounds__(PX_THREADS) void d2d_fir_px_kernel(PxArgs a) {
     }
 }
 
-// (LP, MP, NP, G) of the tables this kernel serves (filters/filter_tables.inc: D2D_POLYS); one shape per object (Makefile: -DD2D_PX_PART=0..5),
+// (LP, MP, NP, G) of the tables this kernel serves (filters/filter_tables.inc: D2D_POLYS); one shape per object (Makefile: -DD2D_PX_PART=0..7),
 // part 0 also holds the plain kernel, the table builder and the dispatcher
 #define D2D_PX_SHAPE_0(X) X(5, 147, 751, 3)
 #define D2D_PX_SHAPE_1(X) X(10, 147, 375, 4)
@@ -574,10 +574,12 @@ __global__ __launch_bounds__(PX_THREADS) void d2d_fir_px_kernel(PxArgs a) {
 #define D2D_PX_SHAPE_3(X) X(5, 294, 1501, 2)
 #define D2D_PX_SHAPE_4(X) X(5, 147, 771, 3)
 #define D2D_PX_SHAPE_5(X) X(10, 147, 539, 4)
-#define D2D_PX_SHAPES(X) D2D_PX_SHAPE_0(X) D2D_PX_SHAPE_1(X) D2D_PX_SHAPE_2(X) D2D_PX_SHAPE_3(X) D2D_PX_SHAPE_4(X) D2D_PX_SHAPE_5(X)
+#define D2D_PX_SHAPE_6(X) X(5, 294, 1541, 2)
+#define D2D_PX_SHAPE_7(X) X(5, 147, 1079, 3)
+#define D2D_PX_SHAPES(X) D2D_PX_SHAPE_0(X) D2D_PX_SHAPE_1(X) D2D_PX_SHAPE_2(X) D2D_PX_SHAPE_3(X) D2D_PX_SHAPE_4(X) D2D_PX_SHAPE_5(X) D2D_PX_SHAPE_6(X) D2D_PX_SHAPE_7(X)
 
 #define D2D_PX_DECL(n) hipError_t launch_fir_px_part##n(PxArgs& a, const d2d_poly_def& p, uint32_t max_nout, uint32_t nfiles, hipStream_t s);
-D2D_PX_DECL(0) D2D_PX_DECL(1) D2D_PX_DECL(2) D2D_PX_DECL(3) D2D_PX_DECL(4) D2D_PX_DECL(5)
+D2D_PX_DECL(0) D2D_PX_DECL(1) D2D_PX_DECL(2) D2D_PX_DECL(3) D2D_PX_DECL(4) D2D_PX_DECL(5) D2D_PX_DECL(6) D2D_PX_DECL(7)
 
 template <int LP, int MP, int NP, int G, int KIND>
 static hipError_t launch_px_t(PxArgs& a, uint32_t max_nout, uint32_t nfiles, hipStream_t s) {
@@ -791,7 +793,7 @@ hipError_t launch_fir_px(PxArgs& a, const d2d_poly_def& p, uint32_t max_nout, ui
     a.qsh = a.epi.bits == 20 ? 4u : 0u;
 #define R(n, shape) { auto hit = [&]() -> bool { shape(XT) return false; }; if (hit()) return launch_fir_px_part##n(a, p, max_nout, nfiles, s); }
 #define XT(lp, mp, np, g) if (p.Lp == lp && p.Mp == mp && p.NP == np) return true;
-    R(0, D2D_PX_SHAPE_0) R(1, D2D_PX_SHAPE_1) R(2, D2D_PX_SHAPE_2) R(3, D2D_PX_SHAPE_3) R(4, D2D_PX_SHAPE_4) R(5, D2D_PX_SHAPE_5)
+    R(0, D2D_PX_SHAPE_0) R(1, D2D_PX_SHAPE_1) R(2, D2D_PX_SHAPE_2) R(3, D2D_PX_SHAPE_3) R(4, D2D_PX_SHAPE_4) R(5, D2D_PX_SHAPE_5) R(6, D2D_PX_SHAPE_6) R(7, D2D_PX_SHAPE_7)
 #undef XT
 #undef R
     return hipErrorInvalidValue;
@@ -804,8 +806,12 @@ D2D_PX_PART_FN(2, D2D_PX_SHAPE_2)
 D2D_PX_PART_FN(3, D2D_PX_SHAPE_3)
 #elif D2D_PX_PART == 4
 D2D_PX_PART_FN(4, D2D_PX_SHAPE_4)
-#else
+#elif D2D_PX_PART == 5
 D2D_PX_PART_FN(5, D2D_PX_SHAPE_5)
+#elif D2D_PX_PART == 6
+D2D_PX_PART_FN(6, D2D_PX_SHAPE_6)
+#else
+D2D_PX_PART_FN(7, D2D_PX_SHAPE_7)
 #endif
 
 }  // namespace d2d

@@ -1,4 +1,4 @@
-"""DSD64 / DSD128 -> 96 / 192 / 384 kHz: the 48k cascade composed into one polyphase filter on the bits (round 4).
+"""DSD64 / DSD128 -> 96 / 192 / 384 kHz and DSD256 -> 192 / 384 kHz: the 48k cascade composed into one polyphase filter on the bits (round 4).
 
 Until round 3 these rates ran as two stages that met in HBM (a decimator to 352.8 kHz, a polyphase L/147 resampler).  The two designs
 are now composed at table-build time (tools/design_filters.py: compose_polyphase; filters/filter_tables.inc: D2D_POLYS) and the output is
@@ -16,7 +16,7 @@ import pytest
 from helpers import decode_pcm, pack_layout, random_bytes, synth
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-RATES = [(1, 96000), (1, 192000), (1, 384000), (2, 96000), (2, 192000), (2, 384000)]
+RATES = [(1, 96000), (1, 192000), (1, 384000), (2, 96000), (2, 192000), (2, 384000), (4, 192000), (4, 384000)]
 
 
 def _polys():

@@ -184,8 +184,7 @@ def test_stage_b_grid_cost_against_its_f64_coefficients(oracle_mod, dsd_rate, ou
     for mode in ("grid", "f64"):
         for bits, dither in ((32, "X"), (24, "T")):
             o = O.Oracle(bit_depth=bits, dither=dither, **kw)
-            if dsd_rate <= 2:
-                o.use_cascade()           # (DSD64 / DSD128: the two-stage form is the study mode since round 4, tests/test_poly48k.py)
+            o.use_cascade()               # (where a composed table exists the two-stage form is the study mode since round 4, tests/test_poly48k.py)
             if mode == "f64":
                 o.use_f64_resamp_coef()
             outs[mode, bits] = o.translate(buf)[0]

@@ -237,6 +237,12 @@ def compose_polyphase(dsd_rate, r, hA_half):
                 method=f"A_M{MA} (*) B_{out_rate} on {Lp} ticks per bit, 24-bit grid, taps within {POLY_TRIM} units dropped at both ends")
 
 
+def composed_rates(resamplers):
+    """(dsd rate, stage B) pairs that get a composed one-pass table: DSD64 and DSD128 to every 48k multiple, DSD256 to 192 and 384 kHz (a window of
+    1,100-1,550 bits; DSD256 -> 96 kHz would need 3,400, DSD512 6,800: those keep the two-kernel cascade)"""
+    return [(rate, r) for rate in (1, 2, 4) for r in resamplers if rate < 4 or r["out_rate"] >= 192000]
+
+
 def fmt_i32(q):
     return ", ".join(str(int(v)) for v in q)
 
@@ -254,7 +260,7 @@ def main():
             f64 = json.load(f)
         for fl in filters:
             fl["q32"] = [int(v) for v in quantise_fine([float.fromhex(x) for x in f64[fl["name"]]], fl["S"], fl["q"])]
-        polys = [compose_polyphase(rate, r, np.array([float.fromhex(x) for x in f64[f"A_M{8 * rate}"]])) for rate in (1, 2) for r in resamplers]
+        polys = [compose_polyphase(rate, r, np.array([float.fromhex(x) for x in f64[f"A_M{8 * rate}"]])) for rate, r in composed_rates(resamplers)]
         write_tables(filters, resamplers, None, polys)
         return
     filters = []   # dicts: name, type, M, N, S, q(list), method
@@ -315,7 +321,7 @@ def main():
                                method=f"kaiser 120dB pass {fp:.0f} stop {fst:.0f} Hz"))
         print(f"B_{out_rate} L={L} P={P} N={N}", file=sys.stderr)
 
-    polys = [compose_polyphase(rate, r, np.array([float.fromhex(x) for x in unquantised[f"A_M{8 * rate}"]])) for rate in (1, 2) for r in resamplers]
+    polys = [compose_polyphase(rate, r, np.array([float.fromhex(x) for x in unquantised[f"A_M{8 * rate}"]])) for rate, r in composed_rates(resamplers)]
     write_tables(filters, resamplers, unquantised, polys)
 
 
