@@ -861,7 +861,10 @@ __global__ __launch_bounds__(D2D_MX_THREADS) void d2d_fir_mx_kernel(Mfma2Args m)
             store_tile(t);
         }
     };
-    if (SCR ? il : (fast_layout || il)) {
+#ifndef D2D_MX_SCR_AF
+#define D2D_MX_SCR_AF 1           // the planar scratch flavour walks the call's inner tiles in the fixed-order loop too (round 4: +1.4 .. 3 %; 0: the general loop)
+#endif
+    if (SCR ? (il || (D2D_MX_SCR_AF && fast_layout && !coop)) : (fast_layout || il)) {
         // the tiles [t_lo, t_hi) lie inside the call's full blocks: the loop without the gather path; the few around them one by one
         const int64_t T = (int64_t)TILE * MB;
         auto is_fast = [&](uint32_t w) { const int32_t ab = tile_ab16(w); return ab >= 0 && (uint32_t)ab + 16u * NCHK <= full_bytes; };
@@ -876,7 +879,7 @@ __global__ __launch_bounds__(D2D_MX_THREADS) void d2d_fir_mx_kernel(Mfma2Args m)
         }
         { const uint32_t nfull = j0.nout / (uint32_t)TILE; if (t_hi > nfull) t_hi = nfull > t_lo ? nfull : t_lo; }     // whole tiles only
         if (il) run_loop(t_lo, t_hi, std::true_type{}, std::true_type{});
-        else if constexpr (!SCR) run_loop(t_lo, t_hi, std::true_type{}, std::false_type{});
+        else if constexpr (!SCR || D2D_MX_SCR_AF) run_loop(t_lo, t_hi, std::true_type{}, std::false_type{});
         const uint32_t n_edge = t_lo + (nwt - t_hi);
         for (uint32_t i = wv; i < n_edge; i += wstride) slow_tile(i < t_lo ? i : t_hi + (i - t_lo));
     } else {
