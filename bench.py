@@ -499,8 +499,10 @@ def main():
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as fjs:
             pmc = json.load(fjs)
-        ent = pmc.get(eng.kernel_name() if scope == "kernel" else "step", {}).get(args.workload)      # "step": every kernel of the step, summed
-        if (ent and not alt_lib and not args.debug and ent.get("kernel_src_sha16") == kernel_source_hash() and ent.get("files_per_gpu") == args.files
+        # (a line taken with modifiers has its own key, as tools/collect.py files it: never the plain workload's entry)
+        pmc_key = args.workload + ("+taps32" if args.tap_bits == 32 else "") + ("+level%g" % args.level if args.level else "")
+        ent = pmc.get(eng.kernel_name() if scope == "kernel" else "step", {}).get(pmc_key)      # "step": every kernel of the step, summed
+        if (ent and not alt_lib and not args.debug and not args.as_rank and ent.get("kernel_src_sha16") == kernel_source_hash() and ent.get("files_per_gpu") == args.files
                 and abs(ent.get("seconds_per_file", 0) - out["config"]["seconds_per_file"]) < 1e-3):
             out["roofline"]["traffic"] = ent["hbm_bytes_per_launch"]
     except Exception:
