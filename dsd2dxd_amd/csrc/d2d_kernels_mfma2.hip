@@ -718,12 +718,21 @@ static bool mfma3_eligible(const FirArgs& a, const Mfma2Args& m, int MB, int NPG
 
 static void mfma2_geometry(const FirArgs& a, int MB, int NPG, Mfma2Args& m, size_t& smem);
 
+// Planar frames of an even channel count above two on the fp6 kernel: a wave converts every pair of a tile and stores whole frames
+// (d2d_kernels_mx.hip, NPR).  The pairs per wave, or 1.  (Byte-interleaved multichannel input reaches the kernel as the engine's planar copy.)
+static uint32_t mx_pairs(const FirArgs& a, int MB, int N) {
+    const uint32_t C = a.epi.channels;
+    if (a.to_scratch || a.mono2 || a.il2 || a.coop || C < 4 || C % 2) return 1u;
+    if (a.B < 16 || (a.B & (a.B - 1)) != 0) return 1u;
+    return mx_pairs_supported(MB, N, (int)(C / 2u)) ? C / 2u : 1u;
+}
+
 // the same conversions as mfma3_eligible, shape apart (the caller checks mx_supported and the engine mx_exact)
-static bool mx_eligible(const FirArgs& a, const Mfma2Args& m) {
+static bool mx_eligible(const FirArgs& a, const Mfma2Args& m, int MB, int N) {
     const bool range_ok = a.scale_bits >= 20 && a.scale_bits <= 30 && a.sum_abs_q != 0 && a.sum_abs_q < (1ull << 31) && a.mx_exact;
     if (a.to_scratch) return a.epi.channels >= 2 && a.epi.channels % 2 == 0 && range_ok;
     const bool noint = (a.dbg_flags & D2D_DBG_NO_INTQ) != 0;
-    const bool stereo = a.epi.channels == 2 && m.qsh == 0;
+    const bool stereo = (a.epi.channels == 2 || mx_pairs(a, MB, N) > 1u) && m.qsh == 0;       // (or whole frames of several pairs)
     const bool float_ok = !noint && stereo && a.epi.bits == 32 && a.epi.dither != 'F' && a.epi.gain == 1.0;
     const bool frames_ok = stereo && (a.epi.sample_bytes == 3 || a.epi.sample_bytes == 2) && m.intq;
     return range_ok && (float_ok || frames_ok);
@@ -743,12 +752,14 @@ int mfma2_pipelined(const FirArgs& a, int M, int N) {
         if (nomx || !mx_supported(MB, N) || !range_ok || noint16) return 0;
         if (a.to_scratch) return a.epi.channels >= 2 && a.epi.channels % 2 == 0 ? 5 : 0;
         const bool depth_ok = a.epi.bits == 32 ? true : ((a.epi.bits == 24 || a.epi.bits == 20 || a.epi.bits == 16) && m.fbits > 0 && m.fbits <= 16 && a.epi.dither != 'F');
-        if (a.epi.channels != 2 || !depth_ok || a.epi.dither == 'N') return 0;
+        const bool mp = mx_pairs(a, MB, N) > 1u;
+        if ((a.epi.channels != 2 && !mp) || !depth_ok || a.epi.dither == 'N') return 0;
         if (a.epi.gain == 1.0 && m.qsh == 0 && !(a.epi.bits == 32 && a.epi.dither == 'F')) return 5;
+        if (mp) return 0;                                          // (several pairs per wave: unit gain only)
         return mx_gain_supported(MB, N) && !(a.dbg_flags & D2D_DBG_NO_GAINQ) ? 5 : 0;
     }
     // the fp6 x fp4 kernel (d2d_kernels_mx.hip) serves what the pipelined int8 kernel serves at M = 32 and 64: 5
-    if (!nomx && mx_supported(MB, N) && mx_eligible(a, m)) return 5;
+    if (!nomx && mx_supported(MB, N) && mx_eligible(a, m, MB, N)) return 5;
     // ... and stereo frames at another level than 0 dB (its gain flavours)
     if (!nomx && m.gainq && mx_gain_supported(MB, N) && a.mx_exact && a.scale_bits >= 20 && a.scale_bits <= 30 && (a.epi.bits == 32 || a.epi.sample_bytes == 2 || a.epi.sample_bytes == 3)) return 5;
     if (!mfma2_supported(M, N) && !mfma3_supported(MB, NPG, N) && !(a.to_scratch && mfma3_scr_supported(MB, NPG))) return 0;
@@ -758,6 +769,7 @@ int mfma2_pipelined(const FirArgs& a, int M, int N) {
 
 static void mfma2_geometry(const FirArgs& a, int MB, int NPG, Mfma2Args& m, size_t& smem) {
     m.ngroups = a.epi.channels <= 2 ? 1u : (a.epi.channels + 1u) / 2u;
+    m.npairs = 1u;
     const uint32_t C = a.epi.channels <= 2 ? a.epi.channels : 2u;
     m.f = a;
     m.c0 = a.to_scratch ? ldexp(1.0, a.scale_bits) : (a.epi.bits == 32 ? a.epi.gain : a.epi.scale);   // scratch: the integer y*2^S
@@ -855,6 +867,8 @@ hipError_t launch_fir_mfma2(const FirArgs& a, int M, int N, uint32_t max_nout, u
     mfma2_geometry(a, MB, NPG, m, smem);
     const uint32_t nrows = (nstreams / C) * m.ngroups;       // grid rows: one per (file, channel group)
     if (a.pipelined == 5) {                                  // the fp6 kernel has its own LDS layout (and M = 128 no two-group one at all)
+        m.npairs = mx_pairs(a, MB, N);
+        if (m.npairs > 1u) return launch_fir_mx(m, MB, N, max_nout, nstreams / C, s);     // one block row per file
         if (MB == 16) m.gainq = (!a.to_scratch && (a.epi.gain != 1.0 || m.qsh != 0 || (a.epi.bits == 32 && a.epi.dither == 'F'))) ? 1u : 0u;
         return launch_fir_mx(m, MB, N, max_nout, nrows, s);
     }

@@ -76,10 +76,21 @@ __device__ __forceinline__ int32_t mx_max3(int32_t x, int32_t y, int32_t z) {
     return d;
 }
 
+// v_perm_b32 selector of the dword whose first byte is byte o of sample s0 (SBY bytes per sample, packed): the rest of s0 (second source), then s0 + 1 (first source)
+__host__ __device__ constexpr uint32_t mx_pack_sel(int SBY, int o) {
+    uint32_t sel = 0;
+    for (int j = 0; j < 4; ++j) { const int t = o + j; sel |= (uint32_t)(t < SBY ? t : 4 + (t - SBY)) << (8 * j); }
+    return sel;
+}
+
 // KIND: 0 no dither, 1 triangular, 2 rectangular (unit gain, all-integer requantiser); 4, 5, 6: the same dithers at any level in dB (the
 // f64 requantiser of the definition inside the pipelined epilogue, no careful path).  Stereo; SBY = bytes per sample: 3 (24-bit packed frames), 2 (16-bit),
 // 4 (32-bit float, KIND 0 only) or 0 (the exact integers y * 2^S to the scratch lines of a channel pair).
-template <int MB, int NT, int G, int KIND, int SBY>
+// NPR > 1 (planar multichannel frames, unit gain): a wave converts ALL the NPR channel pairs of a tile, one after the other through the same
+// two stream buffers and accumulator sets -- the pipelined loop's trips are (tile, pair), the pair unrolled -- into a slice
+// [2 NPR channels][TILE], and the tile's WHOLE frames leave together (a pair storing its own 6 bytes of every 18-byte frame left each line
+// to three partial writes: 14.0 ms against the 4.7 ms of the same samples as stereo, profiles/r04_experiments.txt item 10).
+template <int MB, int NT, int G, int KIND, int SBY, int NPR = 1>
 __global__ __launch_bounds__(D2D_MX_THREADS) void d2d_fir_mx_kernel(Mfma2Args m) {
     constexpr int CS = mx_cs(MB, G), DLY = mx_dly(MB), NF = mx_nf(MB, NT), TP = mx_nstep(MB, NT, G);
     constexpr int OC = 6 * G, TILE = 32 * OC, NS = 3 * G;           // outputs per column / per tile; samples per lane and channel
@@ -88,7 +99,9 @@ __global__ __launch_bounds__(D2D_MX_THREADS) void d2d_fir_mx_kernel(Mfma2Args m)
     // FLAT: the column stride is 2 mod 4 dwords, so the 32 lanes of a half already read 16 different banks from an unpadded image: the
     // chunks go to LDS as they come, one 16-byte write each, at their own 16-byte slots
     constexpr bool FLAT = mx_flat(MB, G);
-    constexpr uint32_t FB = 2u * (SBY ? SBY : 1);                   // bytes per stereo frame
+    constexpr int NCH = 2 * NPR;                                    // channels a wave converts
+    constexpr uint32_t FB = (uint32_t)NCH * (SBY ? SBY : 1);        // bytes per frame
+    static_assert(NPR == 1 || (SBY != 0 && KIND < 4), "several pairs per wave: frames at unit gain");
     constexpr uint32_t TBL16 = (uint32_t)NF * (MX_FRAG_BYTES / 16); // 16-byte units of one table variant
     constexpr bool SCR = SBY == 0;
     constexpr int DK = KIND & 3;                                    // the dither kind
@@ -106,7 +119,7 @@ __global__ __launch_bounds__(D2D_MX_THREADS) void d2d_fir_mx_kernel(Mfma2Args m)
     const uint32_t fidx = coop ? blockIdx.y : (SCR ? blockIdx.y / m.ngroups : blockIdx.y);
     const uint32_t cbase = coop ? 2u * wave : (SCR ? (blockIdx.y - fidx * m.ngroups) * 2u : 0u);
     uint8_t* wbase = smem + m.off_waves + wave * m.wave_lds;       // [channel 0 stream buffer | channel 1 stream buffer | output slice]
-    const StreamJob* jobs = a.jobs + (size_t)fidx * (SCR ? a.epi.channels : 2u) + cbase;
+    const StreamJob* jobs = a.jobs + (size_t)fidx * (SCR ? a.epi.channels : (uint32_t)NCH) + cbase;
     const StreamJob j0 = jobs[0];          // in, L, e0, n0, nout are common to a file's channels
 
     const int64_t first0 = j0.e0 - (int64_t)a.Wb;          // first byte of output 0's window
@@ -130,7 +143,7 @@ __global__ __launch_bounds__(D2D_MX_THREADS) void d2d_fir_mx_kernel(Mfma2Args m)
     // IL (a.il2: byte-interleaved stereo -- DFF files, the CLI's default -f I -- both channels converted): the tile's
     // frames come as they lie in memory, 2 NCHK pieces of 16 bytes = eight frames each, in two halves of PF pieces per lane; one
     // v_perm_b32 per channel and dword pair pulls a channel's bytes (run_loop below).  Piece g holds a channel's bytes 8 g .. 8 g + 7.
-    const bool il = a.il2 != 0 && !coop;          // (the scratch flavour too: there it is what the fixed-order loop is used for)
+    const bool il = NPR == 1 && a.il2 != 0 && !coop;          // (the scratch flavour too: there it is what the fixed-order loop is used for)
     auto pad_addr = [&](int32_t L, uint32_t k) -> uint32_t { return L < 0 ? DUMMY + 4u * k : 4u * ((uint32_t)L + (uint32_t)L / (uint32_t)CS); };
     uint32_t wad[FLAT ? 1 : PF][4];
     if constexpr (!FLAT) {
@@ -160,11 +173,15 @@ __global__ __launch_bounds__(D2D_MX_THREADS) void d2d_fir_mx_kernel(Mfma2Args m)
     uint32_t lofs[PF];
 #pragma unroll
     for (int i = 0; i < PF; ++i) { const uint32_t q = lane + 64u * i; lofs[i] = 16u * (q < (uint32_t)NCHK ? q : (uint32_t)NCHK - 1u); }
-    const uint32_t chf[2] = {(uint32_t)__builtin_amdgcn_readfirstlane((int)jobs[0].ch), (uint32_t)__builtin_amdgcn_readfirstlane((int)jobs[1].ch)};
-    const uint64_t chan_off[2] = {mono2 ? 0ull : (uint64_t)chf[0] << bshift, mono2 ? (uint64_t)Lcall : (uint64_t)chf[1] << bshift};
+    uint64_t chan_off[NCH];                             // where a channel's bytes start inside a block group (MONO2: inside the call)
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const uint32_t chf = (uint32_t)__builtin_amdgcn_readfirstlane((int)jobs[c].ch);
+        chan_off[c] = mono2 ? (c ? (uint64_t)Lcall : 0ull) : (uint64_t)chf << bshift;
+    }
     // one prefetch register set: a channel's bytes are requested one chain ahead (about two microseconds)
     u32x4 pf[PF];
-    auto issue_loads = [&](uint32_t w, auto cc, auto af) {
+    auto issue_loads = [&](uint32_t w, auto cc, auto af) {     // cc: the CHANNEL (of the wave's 2 NPR) whose bytes are requested
         constexpr int c = decltype(cc)::value;
         constexpr bool AF = decltype(af)::value;
         const int32_t ab = tile_ab16(w);
@@ -348,14 +365,22 @@ __global__ __launch_bounds__(D2D_MX_THREADS) void d2d_fir_mx_kernel(Mfma2Args m)
 #pragma unroll
         for (int g = 0; g < G; ++g) asm volatile("" : "+v"(acc[g]));
     };
+    // ... and every accumulator set stays live AS A WHOLE until its last sample has been taken from it.  Register 15 of a set belongs to no
+    // output row, so it is dead the moment the chain ends -- and the allocator then hands it to the next temporary, which may be the result of one
+    // of the inline-asm instructions of the epilogue (v_lshl_add_u32, v_min3 ...): the compiler's hazard recogniser does not look inside inline
+    // asm, no wait states are inserted, and the chain's last MFMA, still in flight, lands its zero row on top of the value (round 4: sample 0 of
+    // every lane of a mono pair's second half came out as -2^S -> the negative rail, after a change that moved the allocation).
+    auto keep = [&](const v16f (&acc)[G]) {
+#pragma unroll
+        for (int g = 0; g < G; ++g) asm volatile("" :: "v"(acc[g]));
+    };
 
     uint8_t* const mono_out[2] = {reinterpret_cast<uint8_t*>(jobs[0].out), reinterpret_cast<uint8_t*>(jobs[1].out)};      // (MONO2: each half's own frames)
     // dither keys of the two channels (uniform)
-    uint32_t rkey[2], rstep[2], rlo0[2];
+    uint32_t rkey[NCH], rstep[NCH], rlo0[NCH];
+    int32_t vdev[NCH];                                      // running max |v| of a channel, fast path and careful path alike (one register per channel)
 #pragma unroll
-    for (int c = 0; c < 2; ++c) { rkey[c] = jobs[c].rng_key; rstep[c] = jobs[c].rng_kstep; rlo0[c] = jobs[c].rng_lo0; }
-    double pk[2] = {0.0, 0.0};                              // peaks met on the slow path, in LSB
-    int32_t vmn[2] = {kBias, kBias}, vmx[2] = {kBias, kBias};   // running extremes of v (EB: of v + 2^S) on the fast path
+    for (int c = 0; c < NCH; ++c) { rkey[c] = jobs[c].rng_key; rstep[c] = jobs[c].rng_kstep; rlo0[c] = jobs[c].rng_lo0; vdev[c] = 0; }
 
     // constants of the fast epilogue, parked in VGPRs
     const int F_ = SBY == 4 ? 1 : m.fbits;                  // 0 < F <= 16 (integer depths)
@@ -385,7 +410,10 @@ __global__ __launch_bounds__(D2D_MX_THREADS) void d2d_fir_mx_kernel(Mfma2Args m)
             return mx_lshl_add((int32_t)hi, k15, (int32_t)lo);
         }
     };
-    auto noise = [&](uint32_t c, uint32_t nl) -> uint32_t {
+    // (the channel is a compile-time constant everywhere: a lambda left out of line would otherwise index the per-channel arrays at run time,
+    // which sends them to scratch memory)
+    auto noise = [&](auto cc, uint32_t nl) -> uint32_t {
+        constexpr uint32_t c = decltype(cc)::value;
         const uint32_t nlo = (uint32_t)j0.n0 + nl;
         uint32_t z = nlo + rkey[c] + (nlo < rlo0[c] ? rstep[c] : 0u);
         z ^= z >> 16; z *= 0x7feb352dU;
@@ -418,10 +446,10 @@ __global__ __launch_bounds__(D2D_MX_THREADS) void d2d_fir_mx_kernel(Mfma2Args m)
         return (int32_t)rq << m.qsh;                                   // (20-bit samples ride in 24 bits as r << 4)
     };
     // the general per-sample requantiser (any tile): x = v * 2^-F LSB, dither in 2^-16 (2^-17) LSB, round half away, clip
-    auto quant_slow = [&](int32_t v, uint32_t c, uint32_t nl) -> int32_t {
+    auto quant_slow = [&](int32_t v, auto cc, uint32_t nl) -> int32_t {
         if constexpr (GN) {
             uint32_t t = 0;
-            if constexpr (DK != 0) { const uint32_t z = noise(c, nl); t = DK == 1 ? (z & 0xFFFFu) + (z >> 16) + 1u : DK == 2 ? 2u * (z >> 16) + 1u : z; }
+            if constexpr (DK != 0) { const uint32_t z = noise(cc, nl); t = DK == 1 ? (z & 0xFFFFu) + (z >> 16) + 1u : DK == 2 ? 2u * (z >> 16) + 1u : z; }
             return quant_gain(v, t);
         }
         const int F = m.fbits;
@@ -429,14 +457,14 @@ __global__ __launch_bounds__(D2D_MX_THREADS) void d2d_fir_mx_kernel(Mfma2Args m)
         const uint32_t vl = (uint32_t)v & ((1u << F) - 1u);
         int32_t rr;
         if constexpr (KIND == 2) {
-            const uint32_t z = noise(c, nl);
+            const uint32_t z = noise(cc, nl);
             const int32_t w = (int32_t)(vl << (17 - F)) + (int32_t)(2u * (z >> 16) + 1u) - 65536;
             const int32_t neg = (vh + (w >> 17)) >> 31;
             rr = vh + ((w + 65536 + neg) >> 17);
         } else {
             int32_t w = (int32_t)(vl << (16 - F));
             if constexpr (KIND == 1) {
-                const uint32_t z = noise(c, nl);
+                const uint32_t z = noise(cc, nl);
                 w += (int32_t)((z & 0xFFFFu) + (z >> 16)) - 65535;
             }
             const int32_t neg = (vh + (w >> 16)) >> 31;
@@ -456,7 +484,8 @@ __global__ __launch_bounds__(D2D_MX_THREADS) void d2d_fir_mx_kernel(Mfma2Args m)
         int32_t vprev; uint32_t wprev;
         int32_t tmn, tmx; uint32_t tie;
     };
-    auto fast_begin = [&](Fast& f, uint32_t tile, uint32_t c) {
+    auto fast_begin = [&](Fast& f, uint32_t tile, auto cc) {
+        constexpr uint32_t c = decltype(cc)::value;
         const uint32_t first = (uint32_t)j0.n0 + tile * (uint32_t)TILE;
         const uint32_t key_eff = rkey[c] + (first < rlo0[c] ? rstep[c] : 0u);
         f.zb = first + key_eff + lane_fr;
@@ -534,27 +563,30 @@ __global__ __launch_bounds__(D2D_MX_THREADS) void d2d_fir_mx_kernel(Mfma2Args m)
         return __builtin_amdgcn_ballot_w64(bad) != 0;
     };
     // the careful way, sample by sample, from a chain's accumulators
-    auto redo_acc = [&](const v16f (&t)[G], uint32_t tile, uint32_t c, int32_t (&out)[NS]) {
+    auto redo_acc = [&](const v16f (&t)[G], uint32_t tile, auto cc, int32_t (&out)[NS]) {
+        constexpr uint32_t c = decltype(cc)::value;
         const bool full = tile * (uint32_t)TILE + (uint32_t)TILE <= j0.nout;
         const uint32_t nl_base = tile * (uint32_t)TILE + lane_fr;
-        uint32_t vmax = 0;
+        int32_t lo = kBias, hi = kBias;                      // (of the samples that exist, on v + kBias like the fast path's)
 #pragma unroll
         for (int i = 0; i < NS; ++i) {
             const uint32_t nl = nl_base + 6u * (i / 3) + (i % 3);
-            const int32_t v = recombine(t[i / 3], i % 3) - kBias;
-            if constexpr (SBY == 4 && !GN) out[i] = __float_as_int((float)v * kFs); else out[i] = quant_slow(v, c, nl);
-            const uint32_t va = (uint32_t)(v < 0 ? -v : v);
-            vmax = max(vmax, full || nl < j0.nout ? va : 0u);
+            const int32_t vb = recombine(t[i / 3], i % 3), v = vb - kBias;
+            if constexpr (SBY == 4 && !GN) out[i] = __float_as_int((float)v * kFs); else out[i] = quant_slow(v, cc, nl);
+            const bool live = full || nl < j0.nout;
+            lo = live && vb < lo ? vb : lo;
+            hi = live && vb > hi ? vb : hi;
         }
-        pk[c] = fmax(pk[c], ldexp((double)vmax, -m.fbits));   // |x| = |v| * 2^-F exactly
+        vdev[c] = mx_max3(vdev[c], hi - kBias, kBias - lo);
+        keep(t);
     };
     // ... after the channel's chain run again (its stream bytes are still in that channel's buffer): the tiles at a call's edges
-    auto redo = [&](uint32_t cbuf, uint32_t tile, uint32_t c, int32_t (&out)[NS]) {
+    auto redo = [&](uint32_t cbuf, uint32_t tile, auto cc, int32_t (&out)[NS]) {
         v16f t[G];
         chain(cbuf, t, no_hook);
         pin(t);                                     // the chain ends here, its results are complete before the first one is read
         __builtin_amdgcn_s_sleep(1);
-        redo_acc(t, tile, c, out);
+        redo_acc(t, tile, cc, out);
     };
     auto tile_full = [&](uint32_t tile) -> bool { return tile * (uint32_t)TILE + (uint32_t)TILE <= j0.nout; };
     // a channel's samples of the tile in flight -> the wave's output slice [channel][TILE] (dwords): a lane owns runs of three
@@ -565,7 +597,8 @@ __global__ __launch_bounds__(D2D_MX_THREADS) void d2d_fir_mx_kernel(Mfma2Args m)
     };
     // the tile's frames out of the slice: a lane takes groups of four consecutive frames (24 / 16 / 32 contiguous bytes)
     constexpr int NQ = TILE / 4, QPASS = (NQ + 63) / 64;
-    auto store_tile = [&](uint32_t tile, bool known_full = false) {
+    // (always inline: out of line, the closure's captures -- the job, the slice pointer, the lane -- would live in scratch memory for the whole kernel)
+    auto store_tile = [&](uint32_t tile, bool known_full = false) __attribute__((always_inline)) {
         const bool full = known_full || tile_full(tile);
         uint8_t* gout = reinterpret_cast<uint8_t*>(j0.out) + (size_t)tile * (TILE * FB);
         const uint32_t nl0 = tile * (uint32_t)TILE;
@@ -605,6 +638,64 @@ __global__ __launch_bounds__(D2D_MX_THREADS) void d2d_fir_mx_kernel(Mfma2Args m)
                 }
                 return;
             }
+        }
+        if constexpr (NPR > 1) {
+            // frames of 2 NPR channels: a lane takes four consecutive frames = 4 FB contiguous bytes, two frames at a time (fewer live registers);
+            // every dword of them is one v_perm_b32 of two neighbouring samples (sample NCH k + c = frame k, channel c)
+            typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
+            typedef uint32_t u32x2_a4 __attribute__((ext_vector_type(2), aligned(4)));
+            constexpr int NH = NPR * (int)SBY;                   // dwords of two frames
+#pragma unroll
+            for (int p = 0; p < QPASS; ++p) {
+                const uint32_t Q = lane + 64u * p;
+                if ((NQ % 64) != 0 && p == QPASS - 1 && Q >= (uint32_t)NQ) continue;
+                static_for<0, 2>([&](auto hc) {
+                    constexpr int h = decltype(hc)::value;
+                    uint32_t S[2 * NCH];
+                    static_for<0, NCH>([&](auto cc) {
+                        constexpr int c = decltype(cc)::value;
+                        const u32x2 v = *reinterpret_cast<const u32x2*>(ob + c * TILE + 4 * Q + 2 * h);
+                        S[c] = v.x; S[NCH + c] = v.y;
+                    });
+                    uint8_t* gh = gout + 4u * FB * Q + 2u * FB * h;
+                    if (full) {
+                        if (dbg & 64) {
+#pragma unroll
+                            for (int i = 0; i < 2 * NCH; ++i) asm volatile("" :: "v"(S[i]));
+                        } else {
+                            uint32_t D[NH];
+                            static_for<0, NH>([&](auto dc) {
+                                constexpr int d = decltype(dc)::value;
+                                if constexpr (SBY == 4) D[d] = S[d];
+                                else {
+                                    constexpr int b0 = 4 * d, s0 = b0 / (int)SBY, o = b0 % (int)SBY;
+                                    constexpr int s1 = s0 + 1 < 2 * NCH ? s0 + 1 : s0;
+                                    D[d] = __builtin_amdgcn_perm(S[s1], S[s0], mx_pack_sel((int)SBY, o));
+                                }
+                            });
+                            static_for<0, NH / 4>([&](auto ic) {
+                                constexpr int i = decltype(ic)::value;
+                                *reinterpret_cast<D2D_GLOBAL u32x4_a4*>(as_global(gh + 16 * i)) = u32x4_a4{D[4 * i], D[4 * i + 1], D[4 * i + 2], D[4 * i + 3]};
+                            });
+                            constexpr int R0 = NH / 4 * 4;
+                            if constexpr (NH - R0 >= 2) *reinterpret_cast<D2D_GLOBAL u32x2_a4*>(as_global(gh + 4 * R0)) = u32x2_a4{D[R0], D[R0 + 1]};
+                            if constexpr ((NH - R0) % 2 == 1) *reinterpret_cast<D2D_GLOBAL uint32_t*>(as_global(gh + 4 * (NH - 1))) = D[NH - 1];
+                        }
+                    } else {
+                        // the file's last, partial tile: byte by byte
+                        static_for<0, 2 * NCH>([&](auto ic) {
+                            constexpr int i = decltype(ic)::value, k = i / NCH, c = i % NCH;
+                            if (nl0 + 4u * Q + 2u * h + k < j0.nout) {
+                                D2D_GLOBAL uint8_t* pb = as_global(gh + FB * k + c * (int)SBY);
+#pragma unroll
+                                for (int b = 0; b < (int)SBY; ++b) pb[b] = (uint8_t)(S[i] >> (8 * b));
+                            }
+                        });
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                });
+            }
+            return;
         }
 #pragma unroll
         for (int p = 0; p < QPASS; ++p) {
@@ -679,7 +770,7 @@ __global__ __launch_bounds__(D2D_MX_THREADS) void d2d_fir_mx_kernel(Mfma2Args m)
             }
         }
     };
-    auto merge_extremes = [&](const Fast& f, uint32_t c) { vmn[c] = min(vmn[c], f.tmn); vmx[c] = max(vmx[c], f.tmx); };
+    auto merge_extremes = [&](const Fast& f, auto cc) { constexpr uint32_t c = decltype(cc)::value; vdev[c] = mx_max3(vdev[c], f.tmx - kBias, kBias - f.tmn); };
 
     const uint32_t wv = coop ? blockIdx.x : blockIdx.x * m.nwaves + wave;       // this wave's (COOP: this block's) index among the file's tile workers
 #if D2D_MX_STAMPS
@@ -739,6 +830,18 @@ __global__ __launch_bounds__(D2D_MX_THREADS) void d2d_fir_mx_kernel(Mfma2Args m)
         for (; wt < t_end; wt += wstride) {
             const bool more = wt + wstride < t_end;
             const uint32_t nxt = more ? wt + wstride : wt;
+            // a trip = (tile wt, channel pair pp): its channels 2 pp (buffer 0, accA) and 2 pp + 1 (buffer 1, accB); the epilogue that still
+            // waits when it starts is channel 1 of the trip before -- the last pair of the tile before for pp = 0, whose frames are then complete
+            static_for<0, NPR>([&](auto ppc) {
+            constexpr int pp = decltype(ppc)::value;
+            using CH0 = std::integral_constant<int, 2 * pp>;
+            using CH1 = std::integral_constant<int, 2 * pp + 1>;
+            using CHN = std::integral_constant<int, pp + 1 < NPR ? 2 * pp + 2 : 0>;      // the next trip's first channel
+            constexpr uint32_t chp = pp == 0 ? (uint32_t)NCH - 1u : 2u * pp - 1u;
+            using CHP = std::integral_constant<uint32_t, chp>;
+            using CHA = std::integral_constant<uint32_t, 2u * pp>;
+            const uint32_t tp = pp == 0 ? pw : wt;
+            const bool prev = pp > 0 || have_prev;
             // ---- region A ----
             stamp(2);
             if (coop) {
@@ -760,25 +863,26 @@ __global__ __launch_bounds__(D2D_MX_THREADS) void d2d_fir_mx_kernel(Mfma2Args m)
                 wave_sync2();
                 if (!(dbg & 4)) {
                     write_lds(C0{});
-                    issue_loads(wt, C1{}, af);
+                    issue_loads(wt, CH1{}, af);
                 }
                 wave_sync2();
             }
             stamp(0);
             {
                 Fast f;
-                fast_begin(f, pw, 1);
+                fast_begin(f, tp, CHP{});
                 if (dbg & 2) chain(0u, accA, no_hook);
                 else if (dbg & 1) { static_for<0, NJ>([&](auto jc) { fast_job(f, accB, jc); }); for (int g = 0; g < G; ++g) accA[g] = cinit + (float)lane; }
                 else chain(0u, accA, [&](auto uc) { fast_hook(f, accB, uc); });
                 pin(accA);                      // the chain ends HERE (or the compiler sinks its MFMAs into the blocks that use them, behind the epilogue)
                 stamp(1);
-                if (have_prev) {
-                    if constexpr (SCR) put_samples(1, f.res);
+                if (prev) {
+                    if constexpr (SCR) put_samples(chp, f.res);
                     else {
-                        if (!(dbg & 3) && fast_failed(f, pw)) { int32_t o[NS]; redo_acc(accB, pw, 1, o); put_samples(1, o); } else merge_extremes(f, 1);
+                        if (!(dbg & 3) && fast_failed(f, tp)) { int32_t o[NS]; redo_acc(accB, tp, CHP{}, o); put_samples(chp, o); } else merge_extremes(f, CHP{});
                     }
                 }
+                keep(accB);
             }
             // ---- region B ----
             stamp(2);
@@ -788,16 +892,19 @@ __global__ __launch_bounds__(D2D_MX_THREADS) void d2d_fir_mx_kernel(Mfma2Args m)
                 il_issue(nxt, C1{});
             } else if (!(dbg & 4) && !coop) {
                 write_lds(C1{});
-                if (AF || more) issue_loads(nxt, C0{}, af);
+                if constexpr (pp + 1 < NPR) issue_loads(wt, CHN{}, af);
+                else if (AF || more) issue_loads(nxt, C0{}, af);
             }
-            if constexpr (AF) { if (!SCR) store_tile(pw, true); }
-            else if (have_prev && !SCR) store_tile(pw);
-            if constexpr (SCR) { if (have_prev) { wave_sync2(); store_scr_tile(pw); } }
+            if constexpr (pp == 0) {
+                if constexpr (AF) { if (!SCR) store_tile(pw, true); }
+                else if (have_prev && !SCR) store_tile(pw);
+                if constexpr (SCR) { if (have_prev) { wave_sync2(); store_scr_tile(pw); } }
+            }
             wave_sync2();
             stamp(0);
             {
                 Fast f;
-                fast_begin(f, wt, 0);
+                fast_begin(f, wt, CHA{});
                 if (dbg & 2) chain(1u, accB, no_hook);
                 else if (dbg & 1) { static_for<0, NJ>([&](auto jc) { fast_job(f, accA, jc); }); for (int g = 0; g < G; ++g) accB[g] = cinit - (float)lane; }
                 else chain(1u, accB, [&](auto uc) { fast_hook(f, accA, uc); });
@@ -805,19 +912,24 @@ __global__ __launch_bounds__(D2D_MX_THREADS) void d2d_fir_mx_kernel(Mfma2Args m)
                 stamp(1);
                 if constexpr (SCR) put_samples(0, f.res);
                 else {
-                    if (!(dbg & 3) && fast_failed(f, wt)) { int32_t o[NS]; redo_acc(accA, wt, 0, o); put_samples(0, o); } else merge_extremes(f, 0);
+                    if (!(dbg & 3) && fast_failed(f, wt)) { int32_t o[NS]; redo_acc(accA, wt, CHA{}, o); put_samples(CHA::value, o); } else merge_extremes(f, CHA{});
                 }
+                keep(accA);
             }
+            });
             have_prev = true; pw = wt;
         }
         if (have_prev) {
-            // drain: channel 1 of the wave's last tile
+            // drain: the last channel of the wave's last tile
+            constexpr uint32_t chl = (uint32_t)NCH - 1u;
+            using CHL = std::integral_constant<uint32_t, chl>;
             Fast f;
-            fast_begin(f, pw, 1);
+            fast_begin(f, pw, CHL{});
             static_for<0, NJ>([&](auto jc) { fast_job(f, accB, jc); });
-            if constexpr (SCR) { put_samples(1, f.res); wave_sync2(); store_scr_tile(pw); wave_sync2(); }
+            if constexpr (SCR) { keep(accB); put_samples(1, f.res); wave_sync2(); store_scr_tile(pw); wave_sync2(); }
             else {
-                if (fast_failed(f, pw)) { int32_t o[NS]; redo_acc(accB, pw, 1, o); put_samples(1, o); } else merge_extremes(f, 1);
+                if (fast_failed(f, pw)) { int32_t o[NS]; redo_acc(accB, pw, CHL{}, o); put_samples(chl, o); } else merge_extremes(f, CHL{});
+                keep(accB);
                 wave_sync2();
                 store_tile(pw);
                 wave_sync2();
@@ -827,6 +939,28 @@ __global__ __launch_bounds__(D2D_MX_THREADS) void d2d_fir_mx_kernel(Mfma2Args m)
     // One tile the careful way, start to finish (call edges: the window reaches into the carried history or past the call's full
     // blocks, so its bytes are gathered one by one).
     auto slow_tile = [&](uint32_t t) {
+        if constexpr (NPR > 1) {
+            static_for<0, NPR>([&](auto ppc) {
+                constexpr int pp = decltype(ppc)::value;
+                wave_sync2();
+                issue_loads(t, std::integral_constant<int, 2 * pp>{}, std::false_type{}); write_lds(C0{});
+                issue_loads(t, std::integral_constant<int, 2 * pp + 1>{}, std::false_type{}); write_lds(C1{});
+                wave_sync2();
+                {
+                    int32_t o0[NS];
+                    redo(0u, t, std::integral_constant<uint32_t, 2u * pp>{}, o0);
+                    put_samples(2u * pp, o0);
+                }
+                {
+                    int32_t o1[NS];
+                    redo(1u, t, std::integral_constant<uint32_t, 2u * pp + 1u>{}, o1);
+                    put_samples(2u * pp + 1u, o1);
+                }
+            });
+            wave_sync2();
+            store_tile(t);
+            return;
+        }
         wave_sync2();
         issue_loads(t, C0{}, std::false_type{});
         if (il) write_lds_t(C0{}, std::true_type{}); else write_lds(C0{});
@@ -842,19 +976,20 @@ __global__ __launch_bounds__(D2D_MX_THREADS) void d2d_fir_mx_kernel(Mfma2Args m)
                 chain(c, acc, no_hook);
                 pin(acc);
                 Fast f;
-                fast_begin(f, t, c);
+                fast_begin(f, t, std::integral_constant<uint32_t, c>{});
                 static_for<0, NJ>([&](auto jc) { fast_job(f, acc, jc); });
+                keep(acc);
                 store_scr(t, c, f.res);
             });
         } else {
             {
                 int32_t o0[NS];
-                redo(0u, t, 0, o0);
+                redo(0u, t, std::integral_constant<uint32_t, 0u>{}, o0);
                 put_samples(0, o0);
             }
             {
                 int32_t o1[NS];
-                redo(1u, t, 1, o1);
+                redo(1u, t, std::integral_constant<uint32_t, 1u>{}, o1);
                 put_samples(1, o1);
             }
             wave_sync2();
@@ -878,7 +1013,7 @@ __global__ __launch_bounds__(D2D_MX_THREADS) void d2d_fir_mx_kernel(Mfma2Args m)
             while (t_hi < nwt && t_hi >= t_lo && is_fast(t_hi) && (t_hi > t_lo || is_fast(t_lo))) ++t_hi;
         }
         { const uint32_t nfull = j0.nout / (uint32_t)TILE; if (t_hi > nfull) t_hi = nfull > t_lo ? nfull : t_lo; }     // whole tiles only
-        if (il) run_loop(t_lo, t_hi, std::true_type{}, std::true_type{});
+        if (NPR == 1 && il) { if constexpr (NPR == 1) run_loop(t_lo, t_hi, std::true_type{}, std::true_type{}); }       // (several pairs per wave: planar input only)
         else if constexpr (!SCR || D2D_MX_SCR_AF) run_loop(t_lo, t_hi, std::true_type{}, std::false_type{});
         const uint32_t n_edge = t_lo + (nwt - t_hi);
         for (uint32_t i = wv; i < n_edge; i += wstride) slow_tile(i < t_lo ? i : t_hi + (i - t_lo));
@@ -898,9 +1033,9 @@ __global__ __launch_bounds__(D2D_MX_THREADS) void d2d_fir_mx_kernel(Mfma2Args m)
     // peak meter: |x| in LSB; undo the power-of-two part exactly
     const double unscale = 1.0 / (double)(1u << (a.epi.bits - 1));   // (float: fbits = S - 31, so dev * 2^-fbits * 2^-31 = dev * 2^-S)
 #pragma unroll
-    for (int c = 0; c < 2; ++c) {
-        const int32_t dev = max(vmx[c] - kBias, kBias - vmn[c]);
-        double p = fmax(pk[c], ldexp((double)dev, -m.fbits)) * unscale;
+    for (int c = 0; c < NCH; ++c) {
+        const int32_t dev = vdev[c];                                       // |x| = |v| * 2^-F exactly
+        double p = ldexp((double)dev, -m.fbits) * unscale;
         if constexpr (GN) p = p * a.epi.gain;                          // |y| is exact: one rounding, as the oracle's |y * gain| of the largest sample
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) p = fmax(p, __shfl_xor(p, o));
@@ -953,6 +1088,19 @@ __global__ __launch_bounds__(D2D_MX_THREADS) void d2d_fir_mx_kernel(Mfma2Args m)
 #define D2D_MX_GSHAPES_5(X) X(16, 2192)
 #endif
 #define D2D_MX_GSHAPES(X) D2D_MX_GSHAPES_0(X) D2D_MX_GSHAPES_1(X) D2D_MX_GSHAPES_2(X) D2D_MX_GSHAPES_3(X) D2D_MX_GSHAPES_4(X) D2D_MX_GSHAPES_5(X)
+// several channel pairs per wave (planar multichannel frames; NPR = 3: a 5.1 stream), one object per shape too (Makefile: -DD2D_MX_MPART=0..2, D2D_MX_PART=99)
+#define D2D_MX_MSHAPES_0(X) X(4, 560)
+#ifdef D2D_MX_DEV
+#define D2D_MX_MSHAPES_1(X)
+#define D2D_MX_MSHAPES_2(X)
+#else
+#define D2D_MX_MSHAPES_1(X) X(8, 1104)
+#define D2D_MX_MSHAPES_2(X) X(16, 2192)
+#endif
+#define D2D_MX_MSHAPES(X) D2D_MX_MSHAPES_0(X) D2D_MX_MSHAPES_1(X) D2D_MX_MSHAPES_2(X)
+hipError_t launch_fir_mx_mp0(Mfma2Args& m, int MB, int NT, uint32_t max_nout, uint32_t nrows, hipStream_t s);
+hipError_t launch_fir_mx_mp1(Mfma2Args& m, int MB, int NT, uint32_t max_nout, uint32_t nrows, hipStream_t s);
+hipError_t launch_fir_mx_mp2(Mfma2Args& m, int MB, int NT, uint32_t max_nout, uint32_t nrows, hipStream_t s);
 #define D2D_MX_DECL(n) hipError_t launch_fir_mx_part##n(Mfma2Args& m, int MB, int NT, uint32_t max_nout, uint32_t nrows, hipStream_t s); \
                        hipError_t launch_fir_mx_gain##n(Mfma2Args& m, int MB, int NT, uint32_t max_nout, uint32_t nrows, hipStream_t s);
 D2D_MX_DECL(0) D2D_MX_DECL(1) D2D_MX_DECL(2) D2D_MX_DECL(3) D2D_MX_DECL(4) D2D_MX_DECL(5) D2D_MX_DECL(6) D2D_MX_DECL(7)
@@ -961,6 +1109,13 @@ D2D_MX_DECL(0) D2D_MX_DECL(1) D2D_MX_DECL(2) D2D_MX_DECL(3) D2D_MX_DECL(4) D2D_M
 bool mx_supported(int MB, int NT) {
 #define X(mb, nt) if (MB == mb && NT == nt) return true;
     D2D_MX_SHAPES(X)
+#undef X
+    return false;
+}
+bool mx_pairs_supported(int MB, int NT, int npairs) {
+    if (npairs != 3) return false;
+#define X(mb, nt) if (MB == mb && NT == nt) return true;
+    D2D_MX_MSHAPES(X)
 #undef X
     return false;
 }
@@ -1046,22 +1201,22 @@ std::vector<int8_t> build_mx_tables(const d2d_filter_def& f, bool msb_first) {
 
 #endif   // part 0
 
-template <int MB, int NT, int G, int KIND, int SBY>
+template <int MB, int NT, int G, int KIND, int SBY, int NPR = 1>
 static hipError_t launch_mx_t(Mfma2Args& m, uint32_t max_nout, uint32_t nrows, hipStream_t s) {
     static KernelPrep prep;
     int dev = 0;
-    const void* fn = reinterpret_cast<const void*>(&d2d_fir_mx_kernel<MB, NT, G, KIND, SBY>);
+    const void* fn = reinterpret_cast<const void*>(&d2d_fir_mx_kernel<MB, NT, G, KIND, SBY, NPR>);
     hipError_t e = prep.max_dynamic_lds(fn, 160 * 1024, &dev);
     if (e != hipSuccess) return e;
     constexpr uint32_t TILE = 32u * 6u * G;
     // LDS: the shared tap table, then per wave two stream buffers and the output slice; eight waves per block = two per SIMD
     m.off_waves = (uint32_t)mx_nf(MB, NT) * MX_FRAG_BYTES;
     m.off_out = 2u * (uint32_t)mx_stream_bytes(MB, NT, G);
-    m.wave_lds = m.off_out + 2u * TILE * 4u;                 // (the scratch flavour too: its integers leave as rows of the slice)
+    m.wave_lds = m.off_out + 2u * (uint32_t)NPR * TILE * 4u; // the slice: a row of TILE dwords per channel (the scratch flavour too: its integers leave as rows of the slice)
     const uint32_t wdbg = (m.f.dbg_flags >> 8) & 0xFFu;   // diagnostic override (d2d_params.debug_flags bits 8..15)
     uint32_t nwaves = wdbg ? wdbg : (uint32_t)(D2D_MX_THREADS / 64);
     if (nwaves < 1 || nwaves > D2D_MX_THREADS / 64) nwaves = D2D_MX_THREADS / 64;
-    while (nwaves > 1 && (size_t)m.off_waves + (size_t)nwaves * m.wave_lds > 160 * 1024) nwaves >>= 1;
+    while (nwaves > 1 && (size_t)m.off_waves + (size_t)nwaves * m.wave_lds > 160 * 1024) { if (NPR > 1) --nwaves; else nwaves >>= 1; }
     const bool coop = SBY == 0 && m.f.coop;                 // a block = all channel pairs of a file on one tile: one wave per pair, one grid row per file
     if (coop) { nwaves = m.f.epi.channels / 2u; nrows /= m.ngroups; }
     m.nwaves = nwaves;
@@ -1074,7 +1229,7 @@ static hipError_t launch_mx_t(Mfma2Args& m, uint32_t max_nout, uint32_t nrows, h
             hipDeviceProp_t prop;
             if ((e = hipGetDeviceProperties(&prop, dev)) != hipSuccess) return e;
             int nb = 0;
-            e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, d2d_fir_mx_kernel<MB, NT, G, KIND, SBY>, (int)(64 * m.nwaves), smem);
+            e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, d2d_fir_mx_kernel<MB, NT, G, KIND, SBY, NPR>, (int)(64 * m.nwaves), smem);
             if (e != hipSuccess) return e;
             prep.ncu[dev] = prop.multiProcessorCount;
             prep.blocks_per_cu[dev] = nb < 1 ? 1 : nb;
@@ -1088,8 +1243,9 @@ static hipError_t launch_mx_t(Mfma2Args& m, uint32_t max_nout, uint32_t nrows, h
     if (gx < 1) gx = 1;
     const uint32_t need = coop ? nwt_max : (nwt_max + m.nwaves - 1) / m.nwaves;
     if (gx > need) gx = need;
-    hipLaunchKernelGGL((d2d_fir_mx_kernel<MB, NT, G, KIND, SBY>), dim3(gx, nrows), dim3(64 * m.nwaves), smem, s, m);
-    d2d_last_launched_kernel = launched_name<MB, NT, G, KIND, SBY>("d2d_fir_mx_kernel");
+    hipLaunchKernelGGL((d2d_fir_mx_kernel<MB, NT, G, KIND, SBY, NPR>), dim3(gx, nrows), dim3(64 * m.nwaves), smem, s, m);
+    if constexpr (NPR == 1) d2d_last_launched_kernel = launched_name<MB, NT, G, KIND, SBY>("d2d_fir_mx_kernel");
+    else d2d_last_launched_kernel = launched_name<MB, NT, G, KIND, SBY, NPR>("d2d_fir_mx_kernel");
     return hipGetLastError();
 }
 
@@ -1112,7 +1268,33 @@ static hipError_t launch_mx_t(Mfma2Args& m, uint32_t max_nout, uint32_t nrows, h
         shapes(D2D_MX_LAUNCH)                                                                                      \
         return hipErrorInvalidValue;                                                                               \
     }
-#ifdef D2D_MX_GPART
+#ifdef D2D_MX_MPART
+#define D2D_MX_MLAUNCH(mb, nt)                                                                                     \
+    if (MB == mb && NT == nt && m.npairs == 3) {                                                                   \
+        constexpr int G = mx_g(mb);                                                                                \
+        if (m.f.epi.sample_bytes == 4) return launch_mx_t<mb, nt, G, 0, 4, 3>(m, max_nout, nrows, s);               \
+        if (m.f.epi.sample_bytes == 2) {                                                                           \
+            if (m.dkind == 1) return launch_mx_t<mb, nt, G, 1, 2, 3>(m, max_nout, nrows, s);                        \
+            if (m.dkind == 2) return launch_mx_t<mb, nt, G, 2, 2, 3>(m, max_nout, nrows, s);                        \
+            return launch_mx_t<mb, nt, G, 0, 2, 3>(m, max_nout, nrows, s);                                          \
+        }                                                                                                          \
+        if (m.dkind == 1) return launch_mx_t<mb, nt, G, 1, 3, 3>(m, max_nout, nrows, s);                            \
+        if (m.dkind == 2) return launch_mx_t<mb, nt, G, 2, 3, 3>(m, max_nout, nrows, s);                            \
+        return launch_mx_t<mb, nt, G, 0, 3, 3>(m, max_nout, nrows, s);                                              \
+    }
+#define D2D_MX_MPART_FN(n, shapes)                                                                                 \
+    hipError_t launch_fir_mx_mp##n(Mfma2Args& m, int MB, int NT, uint32_t max_nout, uint32_t nrows, hipStream_t s) { \
+        shapes(D2D_MX_MLAUNCH)                                                                                     \
+        return hipErrorInvalidValue;                                                                               \
+    }
+#if D2D_MX_MPART == 0
+D2D_MX_MPART_FN(0, D2D_MX_MSHAPES_0)
+#elif D2D_MX_MPART == 1
+D2D_MX_MPART_FN(1, D2D_MX_MSHAPES_1)
+#else
+D2D_MX_MPART_FN(2, D2D_MX_MSHAPES_2)
+#endif
+#elif defined(D2D_MX_GPART)
 #define D2D_MX_GLAUNCH(mb, nt)                                                                                     \
     if (MB == mb && NT == nt) {                                                                                    \
         constexpr int G = mx_g(mb);                                                                                \
@@ -1152,6 +1334,13 @@ D2D_MX_PART_FN(0, D2D_MX_SHAPES_0)
 hipError_t launch_fir_mx(Mfma2Args& m, int MB, int NT, uint32_t max_nout, uint32_t nrows, hipStream_t s) {
 #define D2D_MX_ROUTE(list, fn) { auto route = [&]() -> int { list(X) return 0; }; if (route()) return fn(m, MB, NT, max_nout, nrows, s); }
 #define X(mb, nt) if (MB == mb && NT == nt) return 1;
+    if (m.npairs > 1) {
+        D2D_MX_ROUTE(D2D_MX_MSHAPES_0, launch_fir_mx_mp0)
+#ifndef D2D_MX_DEV
+        D2D_MX_ROUTE(D2D_MX_MSHAPES_1, launch_fir_mx_mp1) D2D_MX_ROUTE(D2D_MX_MSHAPES_2, launch_fir_mx_mp2)
+#endif
+        return hipErrorInvalidValue;
+    }
     if (m.gainq && !m.f.to_scratch) {
         D2D_MX_ROUTE(D2D_MX_GSHAPES_0, launch_fir_mx_gain0)
 #ifndef D2D_MX_DEV

@@ -41,6 +41,7 @@ struct Mfma2Args {
     uint32_t gainq;       // 1 (pipelined kernels): another level in dB -- the f64 requantiser inside the pipelined epilogue (KIND + 4)
     int32_t  fbits;       // intq: x = v * 2^-fbits LSB (v = sum q s), fbits = S - (bits - 1)
     uint32_t dbg;         // diagnostic ablation mask (make DIAG=1, env D2D_DBG): 1 no chain, 2 no epilogue, 4 no staging
+    uint32_t npairs;      // fp6 kernel: channel pairs a wave converts per tile (1; 3: planar 5.1 frames -- whole frames from one wave, one block row per file)
 };
 
 #ifndef D2D_DIAG

@@ -58,6 +58,7 @@ __host__ __device__ constexpr int mx_g(int MB) { return MB == 4 ? D2D_MX_G4 : MB
 
 struct Mfma2Args;
 bool mx_supported(int MB, int NT);                 // is a kernel compiled for this shape?
+bool mx_pairs_supported(int MB, int NT, int npairs);   // ... for `npairs` channel pairs per wave (planar multichannel frames)?
 bool mx_gain_supported(int MB, int NT);            // ... and its gain flavours (frames at another level than 0 dB)?
 bool mx_exact(const d2d_filter_def& f);            // do the digit sums of this table recombine exactly in f32?
 int mx_groups(int MB);
