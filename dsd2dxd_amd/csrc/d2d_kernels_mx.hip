@@ -370,9 +370,10 @@ __global__ __launch_bounds__(D2D_MX_THREADS) void d2d_fir_mx_kernel(Mfma2Args m)
     // of the inline-asm instructions of the epilogue (v_lshl_add_u32, v_min3 ...): the compiler's hazard recogniser does not look inside inline
     // asm, no wait states are inserted, and the chain's last MFMA, still in flight, lands its zero row on top of the value (round 4: sample 0 of
     // every lane of a mono pair's second half came out as -2^S -> the negative rail, after a change that moved the allocation).
-    auto keep = [&](const v16f (&acc)[G]) {
+    // (the in/out form of `pin`: with an input-only operand of sixteen registers the kernel silently fails to instantiate -- no diagnostic, no code object)
+    auto hold_acc = [&](v16f (&acc)[G]) {
 #pragma unroll
-        for (int g = 0; g < G; ++g) asm volatile("" :: "v"(acc[g]));
+        for (int g = 0; g < G; ++g) asm volatile("" : "+v"(acc[g]));
     };
 
     uint8_t* const mono_out[2] = {reinterpret_cast<uint8_t*>(jobs[0].out), reinterpret_cast<uint8_t*>(jobs[1].out)};      // (MONO2: each half's own frames)
@@ -563,7 +564,7 @@ __global__ __launch_bounds__(D2D_MX_THREADS) void d2d_fir_mx_kernel(Mfma2Args m)
         return __builtin_amdgcn_ballot_w64(bad) != 0;
     };
     // the careful way, sample by sample, from a chain's accumulators
-    auto redo_acc = [&](const v16f (&t)[G], uint32_t tile, auto cc, int32_t (&out)[NS]) {
+    auto redo_acc = [&](v16f (&t)[G], uint32_t tile, auto cc, int32_t (&out)[NS]) {
         constexpr uint32_t c = decltype(cc)::value;
         const bool full = tile * (uint32_t)TILE + (uint32_t)TILE <= j0.nout;
         const uint32_t nl_base = tile * (uint32_t)TILE + lane_fr;
@@ -578,7 +579,7 @@ __global__ __launch_bounds__(D2D_MX_THREADS) void d2d_fir_mx_kernel(Mfma2Args m)
             hi = live && vb > hi ? vb : hi;
         }
         vdev[c] = mx_max3(vdev[c], hi - kBias, kBias - lo);
-        keep(t);
+        hold_acc(t);
     };
     // ... after the channel's chain run again (its stream bytes are still in that channel's buffer): the tiles at a call's edges
     auto redo = [&](uint32_t cbuf, uint32_t tile, auto cc, int32_t (&out)[NS]) {
@@ -882,7 +883,7 @@ __global__ __launch_bounds__(D2D_MX_THREADS) void d2d_fir_mx_kernel(Mfma2Args m)
                         if (!(dbg & 3) && fast_failed(f, tp)) { int32_t o[NS]; redo_acc(accB, tp, CHP{}, o); put_samples(chp, o); } else merge_extremes(f, CHP{});
                     }
                 }
-                keep(accB);
+                hold_acc(accB);
             }
             // ---- region B ----
             stamp(2);
@@ -914,7 +915,7 @@ __global__ __launch_bounds__(D2D_MX_THREADS) void d2d_fir_mx_kernel(Mfma2Args m)
                 else {
                     if (!(dbg & 3) && fast_failed(f, wt)) { int32_t o[NS]; redo_acc(accA, wt, CHA{}, o); put_samples(CHA::value, o); } else merge_extremes(f, CHA{});
                 }
-                keep(accA);
+                hold_acc(accA);
             }
             });
             have_prev = true; pw = wt;
@@ -926,10 +927,10 @@ __global__ __launch_bounds__(D2D_MX_THREADS) void d2d_fir_mx_kernel(Mfma2Args m)
             Fast f;
             fast_begin(f, pw, CHL{});
             static_for<0, NJ>([&](auto jc) { fast_job(f, accB, jc); });
-            if constexpr (SCR) { keep(accB); put_samples(1, f.res); wave_sync2(); store_scr_tile(pw); wave_sync2(); }
+            if constexpr (SCR) { hold_acc(accB); put_samples(1, f.res); wave_sync2(); store_scr_tile(pw); wave_sync2(); }
             else {
                 if (fast_failed(f, pw)) { int32_t o[NS]; redo_acc(accB, pw, CHL{}, o); put_samples(chl, o); } else merge_extremes(f, CHL{});
-                keep(accB);
+                hold_acc(accB);
                 wave_sync2();
                 store_tile(pw);
                 wave_sync2();
@@ -978,7 +979,7 @@ __global__ __launch_bounds__(D2D_MX_THREADS) void d2d_fir_mx_kernel(Mfma2Args m)
                 Fast f;
                 fast_begin(f, t, std::integral_constant<uint32_t, c>{});
                 static_for<0, NJ>([&](auto jc) { fast_job(f, acc, jc); });
-                keep(acc);
+                hold_acc(acc);
                 store_scr(t, c, f.res);
             });
         } else {

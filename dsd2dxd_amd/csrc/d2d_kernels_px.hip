@@ -247,10 +247,10 @@ __global__ __launch_bounds__(PX_THREADS) void d2d_fir_px_kernel(PxArgs a) {
     auto no_hook = [](auto) {};
     // ... and an accumulator set stays live as a whole until its last sample has been taken: register 15 of a set belongs to no output row and
     // is dead when the chain ends; handed to a temporary that an inline-asm instruction writes (no hazard wait states are inserted for those),
-    // the chain's last MFMA, still in flight, would land its zero row on top of it (d2d_kernels_mx.hip: `keep`)
-    auto keep = [&](const px_v16f (&acc)[G]) {
+    // the chain's last MFMA, still in flight, would land its zero row on top of it (d2d_kernels_mx.hip: `hold_acc`)
+    auto keep = [&](px_v16f (&acc)[G]) {
 #pragma unroll
-        for (int g = 0; g < G; ++g) asm volatile("" :: "v"(acc[g]));
+        for (int g = 0; g < G; ++g) asm volatile("" : "+v"(acc[g]));
     };
     // v0 = v + 2^S = 2 sum Q b of sample i of a group's accumulators: the digits S0 .. S4 are registers 5 i .. 5 i + 4 (exact integers in f32)
     auto recombine0 = [&](const px_v16f& A, int i) -> int32_t {
