@@ -56,6 +56,7 @@ WORKLOADS = {
     "dsd256_to_176k4_s24_stereo": (4, 176400, 24, "T", 2, 64 / 8 + 3),
     "dsd128_to_88k2_s24_stereo_ns": (2, 88200, 24, "N", 2, 64 / 8 + 3),   # BASELINE config 3's noise-shaped variant (an extension)
     "dsd64_to_96k_s24_stereo": (1, 96000, 24, "T", 2, 29.4 / 8 + 3),
+    "dsd64_to_96k_s24_6ch": (1, 96000, 24, "T", 6, 29.4 / 8 + 3),          # a 5.1 stream into the 48k family
     "dsd64_to_192k_s24_stereo": (1, 192000, 24, "T", 2, 14.7 / 8 + 3),
     "dsd128_to_384k_s24_stereo": (2, 384000, 24, "T", 2, 14.7 / 8 + 3),
     "dsd128_to_96k_s24_stereo": (2, 96000, 24, "T", 2, 58.8 / 8 + 3),

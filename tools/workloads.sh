@@ -11,17 +11,19 @@ try:
 except Exception as e: print("   failed", e)
 PY
 }
-for w in dsd64_to_88k2_s16_stereo dsd64_to_88k2_f32_stereo dsd64_to_88k2_s24_stereo_nodither dsd64_to_176k4_s24_stereo dsd64_to_352k8_s24_stereo dsd64_to_352k8_f32_stereo dsd128_to_88k2_s24_stereo dsd128_to_88k2_s24_stereo_ns dsd64_to_96k_s24_stereo dsd64_to_192k_s24_stereo dsd128_to_384k_s24_stereo dsd64_to_88k2_s24_stereo_dff dsd64_to_352k8_s24_stereo_dff dsd64_to_96k_s24_stereo_dff; do
+for w in dsd64_to_88k2_s16_stereo dsd64_to_88k2_f32_stereo dsd64_to_88k2_s24_stereo_nodither dsd64_to_176k4_s24_stereo dsd64_to_352k8_s24_stereo dsd64_to_352k8_f32_stereo dsd128_to_88k2_s24_stereo dsd128_to_88k2_s24_stereo_ns dsd64_to_96k_s24_stereo dsd64_to_192k_s24_stereo dsd128_to_384k_s24_stereo dsd128_to_96k_s24_stereo dsd64_to_88k2_s24_stereo_dff dsd64_to_352k8_s24_stereo_dff dsd64_to_96k_s24_stereo_dff; do
   run $w --workload $w
 done
 run dsd512_to_96k_s24_8ch --workload dsd512_to_96k_s24_8ch --distinct 8             # (64 distinct 8-channel files would be 87 GB of host memory)
 run dsd512_to_96k_s24_8ch_rank0of8 --workload dsd512_to_96k_s24_8ch --distinct 8 --shard channels --as-rank 0/8     # config 5's own partition: one channel per GPU ...
 run dsd512_to_96k_s24_8ch_rank0of4 --workload dsd512_to_96k_s24_8ch --distinct 8 --shard channels --as-rank 0/4     # ... or a pair
 run dsd64_to_88k2_s24_6ch --workload dsd64_to_88k2_s24_6ch
+run dsd64_to_96k_s24_6ch --workload dsd64_to_96k_s24_6ch
 run dsd64_to_88k2_s24_mono --workload dsd64_to_88k2_s24_mono --files 128
 run dsd64_to_352k8_s24_mono_level4 --workload dsd64_to_352k8_s24_mono --files 128 --level 4
 run dsd256_to_88k2_s24_stereo --workload dsd256_to_88k2_s24_stereo --seconds 30      # M = 128
 run dsd256_to_176k4_s24_stereo --workload dsd256_to_176k4_s24_stereo --seconds 30
+run dsd256_to_192k_s24_stereo --workload dsd256_to_192k_s24_stereo --seconds 30
 run dsd64_to_88k2_s24_stereo_level-3 --workload dsd64_to_88k2_s24_stereo --level -3
 run dsd64_to_352k8_s24_stereo_level-3 --workload dsd64_to_352k8_s24_stereo --level -3
 run dsd64_to_88k2_s24_stereo_taps32 --workload dsd64_to_88k2_s24_stereo --tap-bits 32
