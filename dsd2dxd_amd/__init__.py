@@ -6,4 +6,4 @@ drive it through; there is no Python or CPU implementation of the conversion beh
 """
 from ._capi import (D2DError, Engine, FileIO, Params, lib, library_path, build_library,  # noqa: F401
                     KERNEL_AUTO, KERNEL_LUT, KERNEL_MFMA,
-                    DBG_NO_MX, DBG_NO_GAINQ, DBG_NO_COOP, DBG_HOST_STAGED, DBG_NO_PIPE, DBG_MFMA_V1, DBG_NO_INTQ, DBG_NS_GENERAL, dbg_waves)
+                    DBG_NO_MX, DBG_NO_GAINQ, DBG_NO_COOP, DBG_HOST_STAGED, DBG_NO_PIPE, DBG_MFMA_V1, DBG_NO_INTQ, DBG_NS_GENERAL, DBG_TAPS32_2PASS, dbg_waves)

@@ -8,6 +8,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 KERNEL_AUTO, KERNEL_LUT, KERNEL_MFMA = 0, 1, 2
 # d2d_params.debug_flags (include/dsd2dxd_amd.h: D2D_DBG_*): diagnostic dispatch switches, 0 in production
 DBG_NO_MX, DBG_NO_GAINQ, DBG_NO_COOP, DBG_HOST_STAGED, DBG_NO_PIPE, DBG_MFMA_V1, DBG_NO_INTQ, DBG_NS_GENERAL = (1 << i for i in range(8))
+DBG_TAPS32_2PASS = 1 << 16
 
 
 def dbg_waves(n):

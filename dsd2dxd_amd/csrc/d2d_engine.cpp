@@ -93,6 +93,7 @@ struct d2d_engine {
     // tap_bits = 32: the FIR runs twice into the scratch (the 24-bit table, then the residual table q32 - 256 q) and d2d_fine_combine_kernel
     // finishes v = 256 v_hi + v_lo; the second half of the scratch, of the job table and `lo_*` belong to the second pass
     bool fine = false;
+    bool taps32 = false;                  // tap_bits = 32 in ONE pass (round 4): stereo at M = 32 on the fp6 kernel's seven-digit flavour -- one table, no scratch, no combining pass
     std::vector<int32_t> lo_half;
     d2d_filter_def lo_def{};
     void* d_fir_tables_lo = nullptr;
@@ -207,7 +208,8 @@ static void fir_args_static(const d2d_engine* e, FirArgs& a, bool lo_pass = fals
     a.B = e->B; a.keep = e->keep;
     a.to_scratch = (e->cascade() || e->noise_shape || e->fine) ? 1u : 0u;
     a.ksteps = (uint32_t)e->mfma.ksteps;
-    a.scale_bits = e->S;
+    a.scale_bits = e->S + (e->taps32 ? 8 : 0);
+    a.taps32 = e->taps32 ? 1u : 0u;
     a.in_channels = e->Cin;
     uint64_t sa = 0;
     for (int j = 0; j < e->N; ++j) { const int64_t q = tap_q(fd, j); sa += (uint64_t)(q < 0 ? -q : q); }
@@ -349,6 +351,12 @@ int d2d_create(const d2d_params* params, uint32_t n_files, d2d_engine** out) {
         CK(hipMalloc(&e->d_fir_tables, e->fir_table_bytes));
         CK(hipMemcpy(e->d_fir_tables, t.data(), e->fir_table_bytes, hipMemcpyHostToDevice));
     } else {
+        // 32-bit taps in ONE pass (round 4) where the fp6 kernel's seven-digit flavour is compiled for the table and its digit sums are exact: stereo frames,
+        // any depth, dither and level (D2D_DBG_TAPS32_2PASS: the two scratch passes and the combining pass, which serve everything else)
+        if (e->fine && e->mfma_v2 && e->C == 2 && e->Cin == 2 && mx_wide_supported(e->M / 8, e->N) && mx_wide_exact(f) &&
+            !(e->p.debug_flags & (D2D_DBG_TAPS32_2PASS | D2D_DBG_NO_MX | D2D_DBG_NO_PIPE | D2D_DBG_MFMA_V1 | D2D_DBG_NO_GAINQ))) {
+            e->fine = false; e->taps32 = true;
+        }
         if (e->mfma_v2) { FirArgs a{}; fir_args_static(e, a); e->mfma_pipe = mfma2_pipelined(a, e->M, e->N); }
         // byte-interleaved 4- or 8-channel input into the scratch (48k family, noise shaping) through the fp6 kernel: no planar copy, the
         // kernel's staging de-interleaves (D2D_DBG_NO_COOP: the pre-pass)
@@ -366,7 +374,7 @@ int d2d_create(const d2d_params* params, uint32_t n_files, d2d_engine** out) {
                 e->il2 = true; e->deinterleave = false; e->B = 1;
             }
         }
-        std::vector<int8_t> t = e->mfma_pipe == 5 ? build_mx_tables(f, msb)
+        std::vector<int8_t> t = e->mfma_pipe == 5 ? build_mx_tables(f, msb, e->taps32)
                               : e->mfma_v2 ? build_mfma2_tables(f, msb, !e->mfma_pipe) : build_mfma_tables(f, e->mfma, msb);
         e->fir_table_bytes = t.size();
         CK(hipMalloc(&e->d_fir_tables, e->fir_table_bytes));
@@ -1030,6 +1038,7 @@ static TableBlobHeader make_header(const d2d_engine* e) {
     h.magic = 0x54443244u; h.abi = D2D_ABI_VERSION; h.kernel = e->kernel; h.endianness = e->p.endianness;
     h.ntaps = (uint32_t)e->N; h.M = (uint32_t)e->M; h.scale_bits = (uint32_t)e->S; h.filter_type = (uint32_t)e->fc.fir->type;
     h.table_variant = e->poly ? (e->poly_plain ? 7u : 6u) : e->kernel == D2D_KERNEL_MFMA && e->mfma_v2 ? (e->mfma_pipe ? (uint32_t)e->mfma_pipe : 2u) : 0u;
+    if (e->taps32) { h.table_variant = 8u; h.scale_bits = (uint32_t)(e->S + 8); }      // the seven-digit fragments of the 32-bit taps
     if (e->poly) { h.ntaps = (uint32_t)e->poly->NP; h.M = (uint32_t)e->poly->Mp; h.scale_bits = (uint32_t)e->poly->S; h.filter_type = (uint32_t)'P'; }
     h.fir_bytes = e->fir_table_bytes; h.resamp_bytes = e->resamp_bytes;
     return h;

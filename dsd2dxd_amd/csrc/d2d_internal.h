@@ -68,6 +68,8 @@ struct FirArgs {
                                // pulls the channels apart (one v_perm_b32 per channel and eight input bytes); B = 1, no planar copy
     uint32_t mx_exact;         // 1: the table's base-32 digit sums recombine exactly in f32 (d2d_mx.h: mx_exact)
     uint32_t dbg_flags;        // d2d_params.debug_flags (D2D_DBG_*), fixed when the engine was created
+    uint32_t taps32;           // 1 (d2d_kernels_mx.hip, stereo frames): the 32-bit tap grid in ONE pass -- `tables` hold the seven-digit fragments of the half32
+                               // taps, scale_bits = S + 8, v = sum q32 s is a 64-bit integer, the f64 requantiser finishes (tap_bits = 32, round 4)
     uint32_t mono2;            // 1 (d2d_kernels_mx.hip, frames): a MONO stream served as a planar pair -- jobs 2 f, 2 f + 1 are the two halves of file f's call
                                // (equal lengths and outputs; the second's history is the end of the first, its frames follow the first's)
     Epilogue epi;
@@ -121,7 +123,8 @@ struct TableBlobHeader {
     uint32_t scale_bits;
     uint32_t filter_type;
     uint32_t table_variant;    // layout of the FIR table: 0 LUT / one-group MFMA, 2 two-group (plane 0 unmasked), 3 pipelined (every plane masked),
-                               // 4 structured-sparse, 5 fp6 digits -- it depends on channels, depth, gain and dither, not only on the filter
+                               // 4 structured-sparse, 5 fp6 digits, 6 / 7 the composed polyphase tables, 8 fp6 digits of the 32-bit taps -- it depends on
+                               // channels, depth, gain and dither, not only on the filter
     uint32_t reserved;
     uint64_t fir_bytes;
     uint64_t resamp_bytes;

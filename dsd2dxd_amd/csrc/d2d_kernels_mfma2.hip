@@ -739,6 +739,7 @@ static bool mx_eligible(const FirArgs& a, const Mfma2Args& m, int MB, int N) {
 }
 
 int mfma2_pipelined(const FirArgs& a, int M, int N) {
+    if (a.taps32) return 5;                                   // (the engine has checked mx_wide_supported and mx_wide_exact)
     if (a.dbg_flags & D2D_DBG_NO_PIPE) return 0;
     const int MB = M / 8, NPG = mfma2_pairs(M, N);
     const bool nomx = (a.dbg_flags & D2D_DBG_NO_MX) != 0;

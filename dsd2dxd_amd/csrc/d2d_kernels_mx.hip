@@ -90,15 +90,21 @@ __host__ __device__ constexpr uint32_t mx_pack_sel(int SBY, int o) {
 // two stream buffers and accumulator sets -- the pipelined loop's trips are (tile, pair), the pair unrolled -- into a slice
 // [2 NPR channels][TILE], and the tile's WHOLE frames leave together (a pair storing its own 6 bytes of every 18-byte frame left each line
 // to three partial writes: 14.0 ms against the 4.7 ms of the same samples as stereo, profiles/r04_experiments.txt item 10).
-template <int MB, int NT, int G, int KIND, int SBY, int NPR = 1>
+// ND = 7 (tap_bits = 32 in ONE pass, round 4): the 32-bit taps in seven base-32 digits, four phases per group (28 of the 32 matrix rows; a lane half owns two
+// phases), v = sum q32 s as a 64-bit integer from three f32 parts, requantised by the f64 flavour's epilogue (KIND 4-7 only).
+template <int MB, int NT, int G, int KIND, int SBY, int NPR = 1, int ND = 5>
 __global__ __launch_bounds__(D2D_MX_THREADS) void d2d_fir_mx_kernel(Mfma2Args m) {
-    constexpr int CS = mx_cs(MB, G), DLY = mx_dly(MB), NF = mx_nf(MB, NT), TP = mx_nstep(MB, NT, G);
-    constexpr int OC = 6 * G, TILE = 32 * OC, NS = 3 * G;           // outputs per column / per tile; samples per lane and channel
-    constexpr int NCHK = mx_chunks(MB, NT, G), PF = mx_pf(MB, NT, G);
-    constexpr uint32_t SB = (uint32_t)mx_stream_bytes(MB, NT, G);
+    constexpr bool WIDE = ND == 7;
+    static_assert(ND == 5 || ND == 7, "five digits (24-bit taps) or seven (32-bit taps)");
+    constexpr int PH = WIDE ? 4 : 6, PHH = PH / 2;                  // phases (outputs) per group; per lane half
+    using vint = std::conditional_t<WIDE, int64_t, int32_t>;        // v = sum q s
+    constexpr int CS = mx_cs(MB, G, PH), DLY = mx_dly(MB, PH), NF = mx_nf(MB, NT, PH), TP = mx_nstep(MB, NT, G, PH);
+    constexpr int OC = PH * G, TILE = 32 * OC, NS = PHH * G;        // outputs per column / per tile; samples per lane and channel
+    constexpr int NCHK = mx_chunks(MB, NT, G, PH), PF = mx_pf(MB, NT, G, PH);
+    constexpr uint32_t SB = (uint32_t)mx_stream_bytes(MB, NT, G, PH);
     // FLAT: the column stride is 2 mod 4 dwords, so the 32 lanes of a half already read 16 different banks from an unpadded image: the
     // chunks go to LDS as they come, one 16-byte write each, at their own 16-byte slots
-    constexpr bool FLAT = mx_flat(MB, G);
+    constexpr bool FLAT = mx_flat(MB, G, PH);
     constexpr int NCH = 2 * NPR;                                    // channels a wave converts
     constexpr uint32_t FB = (uint32_t)NCH * (SBY ? SBY : 1);        // bytes per frame
     static_assert(NPR == 1 || (SBY != 0 && KIND < 4), "several pairs per wave: frames at unit gain");
@@ -107,6 +113,7 @@ __global__ __launch_bounds__(D2D_MX_THREADS) void d2d_fir_mx_kernel(Mfma2Args m)
     constexpr int DK = KIND & 3;                                    // the dither kind
     constexpr bool GN = KIND >= 4;                                  // any level: x = fl(v * (scale * 2^-S)), q = x + d, round half away, clip -- in f64
     static_assert(!GN || !SCR, "the scratch holds integers");
+    static_assert(!WIDE || (GN && NPR == 1 && MB < 16), "32-bit taps: the f64 requantiser, stereo");
     constexpr uint32_t dbg = D2D_MX_ABL;                  // compile-time ablation mask: 1 no chain, 2 no epilogue, 4 no staging, 8 never slow, 64 no stores
     const FirArgs& a = m.f;
     extern __shared__ __align__(16) unsigned char smem[];
@@ -320,7 +327,7 @@ __global__ __launch_bounds__(D2D_MX_THREADS) void d2d_fir_mx_kernel(Mfma2Args m)
 #pragma unroll
     for (int i = 0; i < 16; ++i) cinit[i] = (!EB && i < 15 && (i % 5) == 4) ? -(float)(1 << (a.scale_bits - 20)) : 0.0f;
     if constexpr (!EB) asm volatile("" : "+v"(cinit));
-    const int32_t kBias = EB ? (1 << a.scale_bits) : 0;
+    const vint kBias = EB ? ((vint)1 << a.scale_bits) : (vint)0;      // (WIDE: scale_bits = S + 8, a 64-bit bias)
 
     // One chain: TP steps of 64 stream bits; group g runs its NF MFMAs from step DLY g on, with the fragments group 0 read
     // DLY g steps earlier; LDS reads are issued AHEAD steps before their use; `hook(k)` is whatever else the wave does behind its k-th MFMA.
@@ -354,7 +361,7 @@ __global__ __launch_bounds__(D2D_MX_THREADS) void d2d_fir_mx_kernel(Mfma2Args m)
                     else acc[g] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(Av, Bv, acc[g], 2, 4, 0, scA, 0, scB);
                     // whatever else the wave does rides BEHIND an MFMA: an in-order wave that issues two MFMAs back to back sits out the
                     // first one's 32 cycles in the matrix pipe
-                    hook(std::integral_constant<int, mx_slot(MB, NT, G, u, g)>{});
+                    hook(std::integral_constant<int, mx_slot(MB, NT, G, u, g, PH)>{});
                     __builtin_amdgcn_sched_barrier(0);
                 }
             });
@@ -379,7 +386,7 @@ __global__ __launch_bounds__(D2D_MX_THREADS) void d2d_fir_mx_kernel(Mfma2Args m)
     uint8_t* const mono_out[2] = {reinterpret_cast<uint8_t*>(jobs[0].out), reinterpret_cast<uint8_t*>(jobs[1].out)};      // (MONO2: each half's own frames)
     // dither keys of the two channels (uniform)
     uint32_t rkey[NCH], rstep[NCH], rlo0[NCH];
-    int32_t vdev[NCH];                                      // running max |v| of a channel, fast path and careful path alike (one register per channel)
+    vint vdev[NCH];                                      // running max |v| of a channel, fast path and careful path alike (one register per channel)
 #pragma unroll
     for (int c = 0; c < NCH; ++c) { rkey[c] = jobs[c].rng_key; rstep[c] = jobs[c].rng_kstep; rlo0[c] = jobs[c].rng_lo0; vdev[c] = 0; }
 
@@ -394,13 +401,19 @@ __global__ __launch_bounds__(D2D_MX_THREADS) void d2d_fir_mx_kernel(Mfma2Args m)
     int32_t kHalf = 1 << (F_ - 1);
     asm volatile("" : "+v"(kF), "+v"(kSh), "+v"(kShR), "+v"(kC1), "+v"(kC2), "+v"(kTm), "+v"(k15), "+v"(k32), "+v"(k1024), "+v"(kHalf));
     const int32_t kSafe = (int32_t)(((uint32_t)m.qmax_i - 2u) << F_);
-    int32_t kNegBias = -kBias;
+    vint kNegBias = -kBias;
     asm volatile("" : "+v"(kNegBias));
-    const uint32_t lane_fr = (uint32_t)OC * r + 3u * h;     // the lane's first sample inside a tile; sample i = 3 g + q sits at lane_fr + 6 g + q
+    const uint32_t lane_fr = (uint32_t)OC * r + (uint32_t)PHH * h;     // the lane's first sample inside a tile; sample i = PHH g + q sits at lane_fr + PH g + q
 
     // v = sum q s of sample q of a group's accumulators: digits S0..S4 = registers 5q .. 5q+4 (exact integers)
-    auto recombine = [&](const v16f& A, int q) -> int32_t {
-        if constexpr (MB == 16) {
+    auto recombine = [&](const v16f& A, int q) -> vint {
+        if constexpr (WIDE) {
+            // seven digits: three f32 parts (each below 2^24: mx_wide_exact), v = lo + 2^15 mid + 2^25 hi in 64 bits
+            const float lo = __builtin_fmaf(A[7 * q + 2], k1024, __builtin_fmaf(A[7 * q + 1], k32, A[7 * q]));
+            const float mid = __builtin_fmaf(A[7 * q + 4], k32, A[7 * q + 3]);
+            const float hi = __builtin_fmaf(A[7 * q + 6], k32, A[7 * q + 5]);
+            return (int64_t)(int32_t)lo + ((int64_t)(int32_t)mid << 15) + ((int64_t)(int32_t)hi << 25);
+        } else if constexpr (MB == 16) {
             // 2192 taps: S0 + 32 S1 + 1024 S2 can pass 2^24; split after two digits instead (mx_exact checks this form for M = 128)
             const float lo = __builtin_fmaf(A[5 * q + 1], k32, A[5 * q]);
             const float hi = __builtin_fmaf(A[5 * q + 4], k1024, __builtin_fmaf(A[5 * q + 3], k32, A[5 * q + 2]));
@@ -427,7 +440,7 @@ __global__ __launch_bounds__(D2D_MX_THREADS) void d2d_fir_mx_kernel(Mfma2Args m)
     double kCg = ldexp(a.epi.bits == 32 ? a.epi.gain : a.epi.scale, -a.scale_bits);
     double kLim = a.epi.bits == 32 ? 1.0 : (double)(1u << (a.epi.bits - 1));
     if constexpr (GN) asm volatile("" : "+v"(kCg), "+v"(kLim));
-    auto quant_gain = [&](int32_t v, uint32_t t) -> int32_t {
+    auto quant_gain = [&](vint v, uint32_t t) -> int32_t {
         const double x = (double)v * kCg;
         if constexpr (SBY == 4) {
             if constexpr (DK == 3) {
@@ -447,7 +460,7 @@ __global__ __launch_bounds__(D2D_MX_THREADS) void d2d_fir_mx_kernel(Mfma2Args m)
         return (int32_t)rq << m.qsh;                                   // (20-bit samples ride in 24 bits as r << 4)
     };
     // the general per-sample requantiser (any tile): x = v * 2^-F LSB, dither in 2^-16 (2^-17) LSB, round half away, clip
-    auto quant_slow = [&](int32_t v, auto cc, uint32_t nl) -> int32_t {
+    auto quant_slow = [&](vint v, auto cc, uint32_t nl) -> int32_t {
         if constexpr (GN) {
             uint32_t t = 0;
             if constexpr (DK != 0) { const uint32_t z = noise(cc, nl); t = DK == 1 ? (z & 0xFFFFu) + (z >> 16) + 1u : DK == 2 ? 2u * (z >> 16) + 1u : z; }
@@ -479,11 +492,11 @@ __global__ __launch_bounds__(D2D_MX_THREADS) void d2d_fir_mx_kernel(Mfma2Args m)
     struct Fast {
         uint32_t zb;            // hash input of the lane's first sample
         uint32_t T;             // the sample in work: its dither term ...
-        int32_t v;              // ... and its v = sum q s
+        vint v;                 // ... and its v = sum q s
         int32_t res[SCR ? NS : 1];
         int32_t* slot;          // the lane's first sample of this channel in the wave's output slice
-        int32_t vprev; uint32_t wprev;
-        int32_t tmn, tmx; uint32_t tie;
+        vint vprev; uint32_t wprev;
+        vint tmn, tmx; uint32_t tie;
     };
     auto fast_begin = [&](Fast& f, uint32_t tile, auto cc) {
         constexpr uint32_t c = decltype(cc)::value;
@@ -498,10 +511,10 @@ __global__ __launch_bounds__(D2D_MX_THREADS) void d2d_fir_mx_kernel(Mfma2Args m)
     constexpr int NSLOT = NF * G;                           // MFMAs of a chain
     auto fast_job = [&](Fast& f, const v16f (&o)[G], auto jc) {
         constexpr int j = decltype(jc)::value;
-        constexpr int i = j / JPS;                          // sample 0..NS-1: group i / 3, q = i % 3
+        constexpr int i = j / JPS;                          // sample 0..NS-1: group i / PHH, q = i % PHH
         constexpr int t = j % JPS + (DK == 0 ? 1 : 0);      // 0 hash, 1 recombine, 2 finish
         if constexpr (t == 0) {
-            uint32_t z = f.zb + (uint32_t)(6 * (i / 3) + (i % 3));
+            uint32_t z = f.zb + (uint32_t)(PH * (i / PHH) + (i % PHH));
             z ^= z >> 16; z *= kC1;
             z ^= z >> 15; z *= kC2;
             z ^= z >> 16;
@@ -510,10 +523,10 @@ __global__ __launch_bounds__(D2D_MX_THREADS) void d2d_fir_mx_kernel(Mfma2Args m)
             else f.T = z >> kShR;                                                         // (2*hi16 + 1) >> (17 - F)
             asm volatile("" : "+v"(f.T));
         } else if constexpr (t == 1) {
-            f.v = recombine(o[i / 3], i % 3);
+            f.v = recombine(o[i / PHH], i % PHH);
             asm volatile("" : "+v"(f.v));
         } else {
-            const int32_t v = f.v;
+            const vint v = f.v;
             int32_t s;
             if constexpr (GN) {
                 s = 0;
@@ -538,8 +551,9 @@ __global__ __launch_bounds__(D2D_MX_THREADS) void d2d_fir_mx_kernel(Mfma2Args m)
             // the sample goes straight into the wave's output slice (the tile that sat there left before this region began); the scratch
             // flavour keeps it in a register for its store after the region
             if constexpr (SCR) { f.res[i] = rv; asm volatile("" : "+v"(f.res[i])); }
-            else f.slot[6 * (i / 3) + (i % 3)] = rv;
-            if constexpr (!SCR) {
+            else f.slot[PH * (i / PHH) + (i % PHH)] = rv;
+            if constexpr (WIDE) { f.tmn = v < f.tmn ? v : f.tmn; f.tmx = v > f.tmx ? v : f.tmx; }
+            else if constexpr (!SCR) {
                 if constexpr (i & 1) { f.tmn = mx_min3(f.tmn, f.vprev, v); f.tmx = mx_max3(f.tmx, f.vprev, v); }
                 else if constexpr (i == NS - 1) { f.tmn = min(f.tmn, v); f.tmx = max(f.tmx, v); }
                 else f.vprev = v;
@@ -568,17 +582,18 @@ __global__ __launch_bounds__(D2D_MX_THREADS) void d2d_fir_mx_kernel(Mfma2Args m)
         constexpr uint32_t c = decltype(cc)::value;
         const bool full = tile * (uint32_t)TILE + (uint32_t)TILE <= j0.nout;
         const uint32_t nl_base = tile * (uint32_t)TILE + lane_fr;
-        int32_t lo = kBias, hi = kBias;                      // (of the samples that exist, on v + kBias like the fast path's)
+        vint lo = kBias, hi = kBias;                         // (of the samples that exist, on v + kBias like the fast path's)
 #pragma unroll
         for (int i = 0; i < NS; ++i) {
-            const uint32_t nl = nl_base + 6u * (i / 3) + (i % 3);
-            const int32_t vb = recombine(t[i / 3], i % 3), v = vb - kBias;
+            const uint32_t nl = nl_base + (uint32_t)PH * (i / PHH) + (i % PHH);
+            const vint vb = recombine(t[i / PHH], i % PHH), v = vb - kBias;
             if constexpr (SBY == 4 && !GN) out[i] = __float_as_int((float)v * kFs); else out[i] = quant_slow(v, cc, nl);
             const bool live = full || nl < j0.nout;
             lo = live && vb < lo ? vb : lo;
             hi = live && vb > hi ? vb : hi;
         }
-        vdev[c] = mx_max3(vdev[c], hi - kBias, kBias - lo);
+        if constexpr (WIDE) { const vint d = hi - kBias > kBias - lo ? hi - kBias : kBias - lo; vdev[c] = d > vdev[c] ? d : vdev[c]; }
+        else vdev[c] = mx_max3(vdev[c], hi - kBias, kBias - lo);
         hold_acc(t);
     };
     // ... after the channel's chain run again (its stream bytes are still in that channel's buffer): the tiles at a call's edges
@@ -594,7 +609,9 @@ __global__ __launch_bounds__(D2D_MX_THREADS) void d2d_fir_mx_kernel(Mfma2Args m)
     auto put_samples = [&](uint32_t c, const int32_t (&v)[NS]) {
         int32_t* d = ob + c * TILE + lane_fr;
 #pragma unroll
-        for (int g = 0; g < G; ++g) { d[6 * g] = v[3 * g]; d[6 * g + 1] = v[3 * g + 1]; d[6 * g + 2] = v[3 * g + 2]; }
+        for (int g = 0; g < G; ++g)
+#pragma unroll
+            for (int k = 0; k < PHH; ++k) d[PH * g + k] = v[PHH * g + k];
     };
     // the tile's frames out of the slice: a lane takes groups of four consecutive frames (24 / 16 / 32 contiguous bytes)
     constexpr int NQ = TILE / 4, QPASS = (NQ + 63) / 64;
@@ -744,10 +761,12 @@ __global__ __launch_bounds__(D2D_MX_THREADS) void d2d_fir_mx_kernel(Mfma2Args m)
         const uint32_t nl = tile * (uint32_t)TILE + lane_fr;
 #pragma unroll
         for (int g = 0; g < G; ++g) {
-            if (nl + 6u * g + 2u < j0.nout) { xs[6 * g] = v[3 * g]; xs[6 * g + 1] = v[3 * g + 1]; xs[6 * g + 2] = v[3 * g + 2]; }
-            else
+            if (nl + (uint32_t)PH * g + (uint32_t)PHH - 1u < j0.nout) {
 #pragma unroll
-                for (int k = 0; k < 3; ++k) if (nl + 6u * g + k < j0.nout) xs[6 * g + k] = v[3 * g + k];
+                for (int k = 0; k < PHH; ++k) xs[PH * g + k] = v[PHH * g + k];
+            } else
+#pragma unroll
+                for (int k = 0; k < PHH; ++k) if (nl + (uint32_t)PH * g + k < j0.nout) xs[PH * g + k] = v[PHH * g + k];
         }
     };
     // SCR, the pipelined loop: both channels' integers of a tile leave the slice as 16-byte rows along their scratch lines (a lane storing its
@@ -771,7 +790,7 @@ __global__ __launch_bounds__(D2D_MX_THREADS) void d2d_fir_mx_kernel(Mfma2Args m)
             }
         }
     };
-    auto merge_extremes = [&](const Fast& f, auto cc) { constexpr uint32_t c = decltype(cc)::value; vdev[c] = mx_max3(vdev[c], f.tmx - kBias, kBias - f.tmn); };
+    auto merge_extremes = [&](const Fast& f, auto cc) { constexpr uint32_t c = decltype(cc)::value; if constexpr (WIDE) { const vint d = f.tmx - kBias > kBias - f.tmn ? f.tmx - kBias : kBias - f.tmn; vdev[c] = d > vdev[c] ? d : vdev[c]; } else vdev[c] = mx_max3(vdev[c], f.tmx - kBias, kBias - f.tmn); };
 
     const uint32_t wv = coop ? blockIdx.x : blockIdx.x * m.nwaves + wave;       // this wave's (COOP: this block's) index among the file's tile workers
 #if D2D_MX_STAMPS
@@ -1035,7 +1054,7 @@ __global__ __launch_bounds__(D2D_MX_THREADS) void d2d_fir_mx_kernel(Mfma2Args m)
     const double unscale = 1.0 / (double)(1u << (a.epi.bits - 1));   // (float: fbits = S - 31, so dev * 2^-fbits * 2^-31 = dev * 2^-S)
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
-        const int32_t dev = vdev[c];                                       // |x| = |v| * 2^-F exactly
+        const vint dev = vdev[c];                                          // |x| = |v| * 2^-F exactly
         double p = ldexp((double)dev, -m.fbits) * unscale;
         if constexpr (GN) p = p * a.epi.gain;                          // |y| is exact: one rounding, as the oracle's |y * gain| of the largest sample
 #pragma unroll
@@ -1099,6 +1118,16 @@ __global__ __launch_bounds__(D2D_MX_THREADS) void d2d_fir_mx_kernel(Mfma2Args m)
 #define D2D_MX_MSHAPES_2(X) X(16, 2192)
 #endif
 #define D2D_MX_MSHAPES(X) D2D_MX_MSHAPES_0(X) D2D_MX_MSHAPES_1(X) D2D_MX_MSHAPES_2(X)
+// the one-pass form of the 32-bit tap grid (seven digits, four phases per group; stereo frames through the f64 requantiser): one object (Makefile: -DD2D_MX_WPART=0, D2D_MX_PART=99)
+#define D2D_MX_WSHAPES_0(X) X(4, 560)
+#ifdef D2D_MX_DEV
+#define D2D_MX_WSHAPES_1(X)
+#else
+#define D2D_MX_WSHAPES_1(X) X(8, 1104)
+#endif
+#define D2D_MX_WSHAPES(X) D2D_MX_WSHAPES_0(X) D2D_MX_WSHAPES_1(X)
+hipError_t launch_fir_mx_wide0(Mfma2Args& m, int MB, int NT, uint32_t max_nout, uint32_t nrows, hipStream_t s);
+hipError_t launch_fir_mx_wide1(Mfma2Args& m, int MB, int NT, uint32_t max_nout, uint32_t nrows, hipStream_t s);
 hipError_t launch_fir_mx_mp0(Mfma2Args& m, int MB, int NT, uint32_t max_nout, uint32_t nrows, hipStream_t s);
 hipError_t launch_fir_mx_mp1(Mfma2Args& m, int MB, int NT, uint32_t max_nout, uint32_t nrows, hipStream_t s);
 hipError_t launch_fir_mx_mp2(Mfma2Args& m, int MB, int NT, uint32_t max_nout, uint32_t nrows, hipStream_t s);
@@ -1117,6 +1146,12 @@ bool mx_pairs_supported(int MB, int NT, int npairs) {
     if (npairs != 3) return false;
 #define X(mb, nt) if (MB == mb && NT == nt) return true;
     D2D_MX_MSHAPES(X)
+#undef X
+    return false;
+}
+bool mx_wide_supported(int MB, int NT) {
+#define X(mb, nt) if (MB == mb && NT == nt) return true;
+    D2D_MX_WSHAPES(X)
 #undef X
     return false;
 }
@@ -1168,10 +1203,31 @@ bool mx_exact(const d2d_filter_def& f) {
 // 2f (lane half 0) and 2f + 1 (half 1) of a column's window.  A lane l = matrix row l & 31, K half l >> 5; its element j (a 6-bit
 // e2m3 code at bits [6j, 6j+6) of the lane's 192) meets B register p = j >> 3, nibble n = j & 7 = bit 4n + p of the dword, which
 // arrives as 0.5 (p even) or 1.0 (p odd).  D row i lands in lane half (i >> 2) & 1, register 4 (i >> 3) + (i & 3) = 5 q + digit:
-// phase 3 half + q.
-std::vector<int8_t> build_mx_tables(const d2d_filter_def& f, bool msb_first) {
+// phase 3 half + q (wide: register 7 q + digit, phase 2 half + q).
+// full 32-bit tap j (0..N-1) of the 2^-(S+8) grid (filters/filter_tables.inc: half32), stored like the 24-bit halves
+static inline int64_t tap_q32(const d2d_filter_def& f, int j) {
+    const int h = f.ntaps / 2;
+    return j >= h ? f.half32[j - h] : f.half32[h - 1 - j];
+}
+// the one-pass form of the 32-bit grid: 2 q32 in seven balanced base-32 digits, v = lo + 2^15 mid + 2^25 hi with lo = S0 + 32 S1 + 2^10 S2,
+// mid = S3 + 32 S4, hi = S5 + 32 S6, each formed in f32 (accumulators from zero; the -2^(S+8) is subtracted in 64 bits)
+bool mx_wide_exact(const d2d_filter_def& f) {
+    if (!f.half32) return false;
+    int64_t sa[7] = {0, 0, 0, 0, 0, 0, 0};
+    for (int k = 0; k < f.ntaps; ++k) {
+        const int64_t q2 = 2 * tap_q32(f, k);
+        int64_t back = 0, w = 1;
+        for (int l = 0; l < 7; ++l) { const int d = digit32(q2, l); sa[l] += d < 0 ? -d : d; back += d * w; w *= 32; }
+        if (back != q2) return false;                                  // 2 q32 does not fit seven digits
+    }
+    const int64_t lo = sa[0] + 32 * sa[1] + 1024 * sa[2], mid = sa[3] + 32 * sa[4], hi = sa[5] + 32 * sa[6];
+    return f.S + 8 >= 28 && f.S + 8 <= 40 && lo < (1 << 24) && mid < (1 << 24) && hi < (1 << 24);
+}
+
+std::vector<int8_t> build_mx_tables(const d2d_filter_def& f, bool msb_first, bool wide) {
     const int M = f.M, N = f.ntaps, MB = M / 8;
-    const int NF = mx_nf(MB, N);
+    const int PH = wide ? 4 : 6, PHH = PH / 2, ND = wide ? 7 : 5;
+    const int NF = mx_nf(MB, N, PH);
     const size_t per = (size_t)NF * MX_FRAG_BYTES;
     std::vector<int8_t> t(4 * per, 0);
     for (int sh = 0; sh < 4; ++sh)
@@ -1180,15 +1236,15 @@ std::vector<int8_t> build_mx_tables(const d2d_filter_def& f, bool msb_first) {
                 const int row = l & 31, kh = l >> 5;
                 const int half = (row >> 2) & 1, rho = 4 * (row >> 3) + (row & 3);
                 uint32_t regs[6] = {0, 0, 0, 0, 0, 0};
-                if (rho < 15) {
-                    const int ph = 3 * half + rho / 5, dg = rho % 5;
+                if (rho < PHH * ND) {
+                    const int ph = PHH * half + rho / ND, dg = rho % ND;
                     for (int j = 0; j < 32; ++j) {
                         const int p = j >> 3, n = j & 7;
                         const int wb = 32 * (2 * fr + kh) + 4 * n + p;                             // bit of the staged window
                         const int tau = (msb_first ? (wb & ~7) + 7 - (wb & 7) : wb) - 8 * sh;     // its time index in the window
                         const int tap = tau - ph * M;
                         if (tau < 0 || tap < 0 || tap >= N) continue;
-                        const int d = digit32(2 * (int64_t)tap_q(f, tap), dg);
+                        const int d = digit32(wide ? 2 * tap_q32(f, tap) : 2 * (int64_t)tap_q(f, tap), dg);
                         const uint32_t code = e2m3_code((p & 1) ? d * 0.125 : d * 0.25);
                         for (int b = 0; b < 6; ++b) if ((code >> b) & 1) regs[(6 * j + b) >> 5] |= 1u << ((6 * j + b) & 31);
                     }
@@ -1202,17 +1258,18 @@ std::vector<int8_t> build_mx_tables(const d2d_filter_def& f, bool msb_first) {
 
 #endif   // part 0
 
-template <int MB, int NT, int G, int KIND, int SBY, int NPR = 1>
+template <int MB, int NT, int G, int KIND, int SBY, int NPR = 1, int ND = 5>
 static hipError_t launch_mx_t(Mfma2Args& m, uint32_t max_nout, uint32_t nrows, hipStream_t s) {
     static KernelPrep prep;
     int dev = 0;
-    const void* fn = reinterpret_cast<const void*>(&d2d_fir_mx_kernel<MB, NT, G, KIND, SBY, NPR>);
+    constexpr int PH = ND == 7 ? 4 : 6;
+    const void* fn = reinterpret_cast<const void*>(&d2d_fir_mx_kernel<MB, NT, G, KIND, SBY, NPR, ND>);
     hipError_t e = prep.max_dynamic_lds(fn, 160 * 1024, &dev);
     if (e != hipSuccess) return e;
-    constexpr uint32_t TILE = 32u * 6u * G;
+    constexpr uint32_t TILE = 32u * (uint32_t)PH * G;
     // LDS: the shared tap table, then per wave two stream buffers and the output slice; eight waves per block = two per SIMD
-    m.off_waves = (uint32_t)mx_nf(MB, NT) * MX_FRAG_BYTES;
-    m.off_out = 2u * (uint32_t)mx_stream_bytes(MB, NT, G);
+    m.off_waves = (uint32_t)mx_nf(MB, NT, PH) * MX_FRAG_BYTES;
+    m.off_out = 2u * (uint32_t)mx_stream_bytes(MB, NT, G, PH);
     m.wave_lds = m.off_out + 2u * (uint32_t)NPR * TILE * 4u; // the slice: a row of TILE dwords per channel (the scratch flavour too: its integers leave as rows of the slice)
     const uint32_t wdbg = (m.f.dbg_flags >> 8) & 0xFFu;   // diagnostic override (d2d_params.debug_flags bits 8..15)
     uint32_t nwaves = wdbg ? wdbg : (uint32_t)(D2D_MX_THREADS / 64);
@@ -1230,7 +1287,7 @@ static hipError_t launch_mx_t(Mfma2Args& m, uint32_t max_nout, uint32_t nrows, h
             hipDeviceProp_t prop;
             if ((e = hipGetDeviceProperties(&prop, dev)) != hipSuccess) return e;
             int nb = 0;
-            e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, d2d_fir_mx_kernel<MB, NT, G, KIND, SBY, NPR>, (int)(64 * m.nwaves), smem);
+            e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, d2d_fir_mx_kernel<MB, NT, G, KIND, SBY, NPR, ND>, (int)(64 * m.nwaves), smem);
             if (e != hipSuccess) return e;
             prep.ncu[dev] = prop.multiProcessorCount;
             prep.blocks_per_cu[dev] = nb < 1 ? 1 : nb;
@@ -1244,8 +1301,9 @@ static hipError_t launch_mx_t(Mfma2Args& m, uint32_t max_nout, uint32_t nrows, h
     if (gx < 1) gx = 1;
     const uint32_t need = coop ? nwt_max : (nwt_max + m.nwaves - 1) / m.nwaves;
     if (gx > need) gx = need;
-    hipLaunchKernelGGL((d2d_fir_mx_kernel<MB, NT, G, KIND, SBY, NPR>), dim3(gx, nrows), dim3(64 * m.nwaves), smem, s, m);
-    if constexpr (NPR == 1) d2d_last_launched_kernel = launched_name<MB, NT, G, KIND, SBY>("d2d_fir_mx_kernel");
+    hipLaunchKernelGGL((d2d_fir_mx_kernel<MB, NT, G, KIND, SBY, NPR, ND>), dim3(gx, nrows), dim3(64 * m.nwaves), smem, s, m);
+    if constexpr (ND != 5) d2d_last_launched_kernel = launched_name<MB, NT, G, KIND, SBY, NPR, ND>("d2d_fir_mx_kernel");
+    else if constexpr (NPR == 1) d2d_last_launched_kernel = launched_name<MB, NT, G, KIND, SBY>("d2d_fir_mx_kernel");
     else d2d_last_launched_kernel = launched_name<MB, NT, G, KIND, SBY, NPR>("d2d_fir_mx_kernel");
     return hipGetLastError();
 }
@@ -1269,7 +1327,36 @@ static hipError_t launch_mx_t(Mfma2Args& m, uint32_t max_nout, uint32_t nrows, h
         shapes(D2D_MX_LAUNCH)                                                                                      \
         return hipErrorInvalidValue;                                                                               \
     }
-#ifdef D2D_MX_MPART
+#ifdef D2D_MX_WPART
+// (wide: the groups per column of the 24-bit form -- twelve outputs at M = 32, eight at M = 64)
+#define D2D_MX_WLAUNCH(mb, nt)                                                                                     \
+    if (MB == mb && NT == nt) {                                                                                    \
+        constexpr int G = mx_g(mb);                                                                                \
+        if (m.f.epi.sample_bytes == 4) {                                                                           \
+            if (m.f.epi.dither == 'F') return launch_mx_t<mb, nt, G, 7, 4, 1, 7>(m, max_nout, nrows, s);            \
+            return launch_mx_t<mb, nt, G, 4, 4, 1, 7>(m, max_nout, nrows, s);                                       \
+        }                                                                                                          \
+        if (m.f.epi.sample_bytes == 2) {                                                                           \
+            if (m.dkind == 1) return launch_mx_t<mb, nt, G, 5, 2, 1, 7>(m, max_nout, nrows, s);                     \
+            if (m.dkind == 2) return launch_mx_t<mb, nt, G, 6, 2, 1, 7>(m, max_nout, nrows, s);                     \
+            return launch_mx_t<mb, nt, G, 4, 2, 1, 7>(m, max_nout, nrows, s);                                       \
+        }                                                                                                          \
+        if (m.dkind == 1) return launch_mx_t<mb, nt, G, 5, 3, 1, 7>(m, max_nout, nrows, s);                         \
+        if (m.dkind == 2) return launch_mx_t<mb, nt, G, 6, 3, 1, 7>(m, max_nout, nrows, s);                         \
+        return launch_mx_t<mb, nt, G, 4, 3, 1, 7>(m, max_nout, nrows, s);                                           \
+    }
+#if D2D_MX_WPART == 0
+hipError_t launch_fir_mx_wide0(Mfma2Args& m, int MB, int NT, uint32_t max_nout, uint32_t nrows, hipStream_t s) {
+    D2D_MX_WSHAPES_0(D2D_MX_WLAUNCH)
+    return hipErrorInvalidValue;
+}
+#else
+hipError_t launch_fir_mx_wide1(Mfma2Args& m, int MB, int NT, uint32_t max_nout, uint32_t nrows, hipStream_t s) {
+    D2D_MX_WSHAPES_1(D2D_MX_WLAUNCH)
+    return hipErrorInvalidValue;
+}
+#endif
+#elif defined(D2D_MX_MPART)
 #define D2D_MX_MLAUNCH(mb, nt)                                                                                     \
     if (MB == mb && NT == nt && m.npairs == 3) {                                                                   \
         constexpr int G = mx_g(mb);                                                                                \
@@ -1335,6 +1422,13 @@ D2D_MX_PART_FN(0, D2D_MX_SHAPES_0)
 hipError_t launch_fir_mx(Mfma2Args& m, int MB, int NT, uint32_t max_nout, uint32_t nrows, hipStream_t s) {
 #define D2D_MX_ROUTE(list, fn) { auto route = [&]() -> int { list(X) return 0; }; if (route()) return fn(m, MB, NT, max_nout, nrows, s); }
 #define X(mb, nt) if (MB == mb && NT == nt) return 1;
+    if (m.f.taps32) {
+        D2D_MX_ROUTE(D2D_MX_WSHAPES_0, launch_fir_mx_wide0)
+#ifndef D2D_MX_DEV
+        D2D_MX_ROUTE(D2D_MX_WSHAPES_1, launch_fir_mx_wide1)
+#endif
+        return hipErrorInvalidValue;
+    }
     if (m.npairs > 1) {
         D2D_MX_ROUTE(D2D_MX_MSHAPES_0, launch_fir_mx_mp0)
 #ifndef D2D_MX_DEV

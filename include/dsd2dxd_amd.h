@@ -60,8 +60,9 @@ enum {
     D2D_DBG_NO_PIPE     = 1u << 4,   /* stereo conversions stay on the two-group kernel (no software-pipelined kernel)                    */
     D2D_DBG_MFMA_V1     = 1u << 5,   /* the one-group matrix-core kernel of round 1 for every decimation                                   */
     D2D_DBG_NO_INTQ     = 1u << 6,   /* the f64 epilogues instead of the all-integer requantisers                                           */
-    D2D_DBG_NS_GENERAL  = 1u << 7    /* the general noise-shaping kernel for stereo too                                                     */
+    D2D_DBG_NS_GENERAL  = 1u << 7,   /* the general noise-shaping kernel for stereo too                                                     */
     /* bits 8..15: waves per block of the matrix-core kernels (0 = their own choice)                                                        */
+    D2D_DBG_TAPS32_2PASS = 1u << 16  /* tap_bits = 32: the two scratch passes and the combining pass where the one-pass kernel would serve  */
 };
 
 /* The conversion parameters of Rdsd2Pcm::new (src/main.rs:325-342) that concern the hot path.

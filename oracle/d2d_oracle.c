@@ -378,7 +378,11 @@ int orc_translate_f64(orc_ctx* c, const uint8_t* dsd, size_t L, void* pcm_out, s
                 /* absolute index im -> xs[im - nfir]; history below */
                 const double* xp = xs + (ptrdiff_t)(im - c->nfir);
                 int64_t isum = 0;
-                if (!c->rs_f64) for (int k = 0; k < P; ++k) isum += (int64_t)g[k] * (int64_t)(xp[-k] * xscale);   /* x * 2^S is an integer, exactly */
+                if (!c->rs_f64) for (int k = 0; k < P; ++k) {
+                    const double xi = xp[-k] * xscale;                    /* x * 2^S is an integer, exactly ... */
+                    if (xi != (double)(int64_t)xi) return -21;            /* ... or the restatement is broken: say so instead of truncating */
+                    isum += (int64_t)g[k] * (int64_t)xi;
+                }
                 double acc = (double)isum * yscale;
                 if (c->rs_f64) {   /* study mode (orc_use_f64_resamp_coef): the design's own f64 coefficients, summed in f64 in this order */
                     const double* gd = c->r->coef + (size_t)phi * P;

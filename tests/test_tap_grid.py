@@ -226,3 +226,43 @@ def test_batch_of_files_with_32_bit_taps(engine_lib, oracle_mod, fmt):
             pos[f] += lens[f][call]
     for f in range(3):
         assert [e.peak(c, f) for c in range(2)] == [oracles[f].peak(c) for c in range(2)]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dsd_rate,bits,dither,level,fmt", [(1, 24, "T", 0.0, "P"), (1, 16, "R", 0.0, "P"), (1, 32, "X", 0.0, "P"), (1, 32, "F", -3.0, "P"), (1, 20, "T", 0.0, "P"),
+                                                            (1, 24, "X", 4.0, "P"), (1, 24, "T", 0.0, "I"), (1, 16, "T", -6.0, "I"), (1, 24, "F", 0.0, "P"),
+                                                            (2, 24, "T", 0.0, "P"), (2, 16, "R", -2.0, "I"), (2, 32, "X", 0.0, "P"), (4, 24, "T", 0.0, "P")])
+def test_32_bit_taps_in_one_pass(engine_lib, oracle_mod, dsd_rate, bits, dither, level, fmt):
+    """tap_bits = 32 for stereo at M = 32 and 64 (round 4; the last case, DSD256 -> 176.4 kHz, is M = 64 too): ONE pass of the fp6 kernel's seven-digit flavour -- the 32-bit taps in seven base-32 digits, four phases
+    per group, v = sum q32 s as a 64-bit integer, the f64 requantiser -- instead of two scratch passes and a combining pass.  The same bytes as the
+    oracle's 32-bit-tap conversion and as the two-pass route (D2D_DBG_TAPS32_2PASS), peaks included: rails (an integer depth clips, float does not),
+    ragged calls, a short last call, byte-interleaved input (de-interleaved in the kernel's staging), levels other than 0 dB, every dither."""
+    rng = np.random.default_rng(3)
+    nbytes = 4096 * 40 * dsd_rate
+    msb = fmt == "I"
+    chans = []
+    for c in range(2):
+        x = synth("sine" if c == 0 else "pink", nbytes, seed=70 + c, dsd_rate=dsd_rate, msb_first=msb, amp=0.5 if c == 0 else 0.098).copy()
+        for _ in range(4):
+            a = int(rng.integers(0, nbytes - 3000))
+            x[a:a + int(rng.integers(200, 3000))] = 0xFF if rng.integers(0, 2) else 0x00
+        chans.append(x)
+    block = 4096 if fmt == "P" else 1
+    kw = dict(dsd_rate=dsd_rate, output_rate=176400 if dsd_rate == 4 else 88200, channels=2, fmt=fmt, endianness="M" if msb else "L", block_size=block, filter="E",
+              bit_depth=bits, dither=dither, seed=17, level_db=level)
+    e = engine_lib.Engine(kernel=2, tap_bits=32, **kw)
+    e2 = engine_lib.Engine(kernel=2, tap_bits=32, debug=engine_lib.DBG_TAPS32_2PASS, **kw)
+    o = oracle_mod.Oracle(tap_bits=32, **kw)
+    cuts = [0, 4096 * 7, 4096 * 7 + 4096 * 20, nbytes - 4096 - (0 if fmt == "P" else 333), nbytes]
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        buf = pack_layout([ch[a:b] for ch in chans], fmt, block)
+        g, gf = e.translate(buf)
+        g2, gf2 = e2.translate(buf)
+        w, wf = o.translate(buf)
+        assert gf == wf and np.array_equal(g, w[:wf * e.frame_bytes]), (a, b)
+        assert gf2 == wf and np.array_equal(g2, w[:wf * e.frame_bytes]), (a, b)
+    kind = 7 if (bits == 32 and dither == "F") else {"T": 5, "R": 6}.get(dither, 4)
+    shape = "4, 560, 3" if dsd_rate == 1 else "8, 1104, 2"
+    assert e.kernel_name() == "d2d_fir_mx_kernel<%s, %d, %d, 1, 7>" % (shape, kind, {16: 2, 20: 3, 24: 3, 32: 4}[bits])
+    assert not e2.kernel_name().endswith(", 7>")
+    assert [e.peak(c) for c in range(2)] == [o.peak(c) for c in range(2)] == [e2.peak(c) for c in range(2)]
