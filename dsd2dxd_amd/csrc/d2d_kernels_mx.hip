@@ -1302,9 +1302,7 @@ static hipError_t launch_mx_t(Mfma2Args& m, uint32_t max_nout, uint32_t nrows, h
     const uint32_t need = coop ? nwt_max : (nwt_max + m.nwaves - 1) / m.nwaves;
     if (gx > need) gx = need;
     hipLaunchKernelGGL((d2d_fir_mx_kernel<MB, NT, G, KIND, SBY, NPR, ND>), dim3(gx, nrows), dim3(64 * m.nwaves), smem, s, m);
-    if constexpr (ND != 5) d2d_last_launched_kernel = launched_name<MB, NT, G, KIND, SBY, NPR, ND>("d2d_fir_mx_kernel");
-    else if constexpr (NPR == 1) d2d_last_launched_kernel = launched_name<MB, NT, G, KIND, SBY>("d2d_fir_mx_kernel");
-    else d2d_last_launched_kernel = launched_name<MB, NT, G, KIND, SBY, NPR>("d2d_fir_mx_kernel");
+    d2d_last_launched_kernel = launched_name<MB, NT, G, KIND, SBY, NPR, ND>("d2d_fir_mx_kernel");     // (all seven arguments: the way rocprofv3 prints the instantiation)
     return hipGetLastError();
 }
 

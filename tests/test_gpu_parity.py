@@ -500,7 +500,7 @@ def test_level_in_db_inside_the_pipelined_kernel(engine_lib, oracle_mod, dsd_rat
         name = e.kernel_name()
         pipelined = "d2d_fir_mx_kernel" if 2822400 * dsd_rate // out_rate >= 32 else "d2d_fir_mfma3_kernel"
         if off == "0":
-            assert pipelined in name and name.split(",")[-2].strip() in ("4", "5", "6", "7"), name
+            assert pipelined in name and name.split("<")[1].split(",")[3].strip() in ("4", "5", "6", "7"), name
         else:
             assert pipelined not in name, name
     assert np.array_equal(outs["0"], outs["1"])
@@ -526,7 +526,7 @@ def test_f64_flavour_when_waves_walk_several_tiles(engine_lib, oracle_mod, dsd_r
     buf = pack_layout([ch[:n4] for ch in chans], "P", 4096)
     g, gf = e.translate(buf)
     w, wf = o.translate(buf)
-    assert e.kernel_name().split(",")[-2].strip() in ("4", "5", "6", "7"), e.kernel_name()
+    assert e.kernel_name().split("<")[1].split(",")[3].strip() in ("4", "5", "6", "7"), e.kernel_name()
     assert gf == wf and np.array_equal(g, w[:wf * e.frame_bytes])
     assert [e.peak(c) for c in range(2)] == [o.peak(c) for c in range(2)]
 
@@ -615,14 +615,14 @@ def test_six_channel_frames_leave_whole_from_one_wave(engine_lib, oracle_mod, ds
     bufs = [pack_layout([ch[a:b] for ch in chans], fmt, block) for a, b in zip(cuts[:-1], cuts[1:])]
     g, r, e, o = run_pair(engine_lib, oracle_mod, bufs, kw, 2)
     M = 2822400 * dsd_rate // out_rate
-    assert e.kernel_name() == "d2d_fir_mx_kernel<%d, %d, %d, %d, %d, 3>" % (M // 8, e.info()["ntaps"], {4: 3, 8: 2, 16: 1}[M // 8], {"T": 1, "R": 2, "X": 0}[dither], bits // 8)
+    assert e.kernel_name() == "d2d_fir_mx_kernel<%d, %d, %d, %d, %d, 3, 5>" % (M // 8, e.info()["ntaps"], {4: 3, 8: 2, 16: 1}[M // 8], {"T": 1, "R": 2, "X": 0}[dither], bits // 8)
     assert g.size == r.size and g.size > 0
     assert np.array_equal(g, r)
     assert [e.peak(c) for c in range(6)] == [o.peak(c) for c in range(6)]
     # a channel subset (a rank's share of a channel split) and another level keep the two-group kernel
     sub = engine_lib.Engine(kernel=2, **dict(kw, channel_first=2, channel_count=3))
     sub.translate(bufs[0])
-    assert not sub.kernel_name().endswith(", 3>")
+    assert not sub.kernel_name().endswith(", 3, 5>")
     lev = engine_lib.Engine(kernel=2, **dict(kw, level_db=-3.0))
     lev.translate(bufs[0])
     assert not lev.kernel_name().startswith("d2d_fir_mx_kernel")

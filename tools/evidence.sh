@@ -17,7 +17,9 @@ case $PART in
     prof dsd64_to_96k_s24_stereo; prof dsd64_to_192k_s24_stereo; prof dsd128_to_384k_s24_stereo; prof dsd64_to_352k8_f32_stereo ;;
   prof2)
     prof dsd128_to_88k2_s24_stereo_ns
-    prof dsd512_to_96k_s24_8ch --distinct 8 ;;   # (config 5: 64 distinct 8-channel files would be 87 GB of host memory)
+    prof dsd512_to_96k_s24_8ch --distinct 8      # (config 5: 64 distinct 8-channel files would be 87 GB of host memory)
+    prof dsd64_to_88k2_s24_6ch                   # whole 5.1 frames from one wave
+    bash tools/prof.sh ${R}_taps32 --workload dsd64_to_88k2_s24_stereo --tap-bits 32 --steps 3 --warmup 1 --reps 1 > gpurun_out/$R/prof_taps32.txt 2>&1; echo "taps32 profiled" ;;   # 32-bit taps in one pass
   workloads)
     bash tools/workloads.sh ${R}_workloads > gpurun_out/$R/workloads.txt 2>&1; tail -40 gpurun_out/$R/workloads.txt ;;
   default)
