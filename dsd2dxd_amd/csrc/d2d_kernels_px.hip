@@ -245,13 +245,10 @@ __global__ __launch_bounds__(PX_THREADS) void d2d_fir_px_kernel(PxArgs a) {
         for (int g = 0; g < G; ++g) asm volatile("" : "+v"(acc[g]));
     };
     auto no_hook = [](auto) {};
-    // ... and an accumulator set stays live as a whole until its last sample has been taken: register 15 of a set belongs to no output row and
-    // is dead when the chain ends; handed to a temporary that an inline-asm instruction writes (no hazard wait states are inserted for those),
-    // the chain's last MFMA, still in flight, would land its zero row on top of it (d2d_kernels_mx.hip: `hold_acc`)
-    auto keep = [&](px_v16f (&acc)[G]) {
-#pragma unroll
-        for (int g = 0; g < G; ++g) asm volatile("" : "+v"(acc[g]));
-    };
+    // (The one inline-asm instruction of this kernel's epilogues writes its result over one of its own live operands, never into a fresh register: register
+    // 15 of an accumulator set belongs to no output row and is dead when the chain ends, and a temporary that an inline-asm instruction writes there gets
+    // no hazard wait states -- the chain's last MFMA, still in flight, would land its zero row on top of it (d2d_kernels_mx.hip: `hold_acc`; holding the
+    // sets here instead cost the four-group shapes 42-62 spilled registers).)
     // v0 = v + 2^S = 2 sum Q b of sample i of a group's accumulators: the digits S0 .. S4 are registers 5 i .. 5 i + 4 (exact integers in f32)
     auto recombine0 = [&](const px_v16f& A, int i) -> int32_t {
         const float lo = __builtin_fmaf(A[5 * i + 2], k1024, __builtin_fmaf(A[5 * i + 1], k32, A[5 * i]));
@@ -393,7 +390,6 @@ __global__ __launch_bounds__(PX_THREADS) void d2d_fir_px_kernel(PxArgs a) {
             px_v16f acc[G];
             chain(c, cbit, acc, no_hook);
             epilogue_exact(c, acc, nl0);
-            keep(acc);
         });
         wave_sync2();
         store_tile(nl0);
@@ -474,7 +470,7 @@ __global__ __launch_bounds__(PX_THREADS) void d2d_fir_px_kernel(PxArgs a) {
                         // r = floor(x + d + 1/2) = (v + (T >> (16 - F))) >> F; an exact tie (the only case where round-half-away differs) has the low 16 bits of v 2^(16-F) + T zero
                         sres = v0 + ((int32_t)f.T >> kSh) + kNegB;
                         const uint32_t w = ((uint32_t)v0 << kSh) + f.T;
-                        uint32_t tmin; asm("v_min3_u16 %0, %1, %2, %3" : "=v"(tmin) : "v"(f.tie), "v"(w), "v"(w)); f.tie = tmin;
+                        asm("v_min3_u16 %0, %0, %1, %1" : "+v"(f.tie) : "v"(w));               // (the result in the register that holds the running value: see the note above)
                     } else if constexpr (KIND == 2) {
                         sres = v0 + (int32_t)f.T + kNegB;                                  // never a tie
                     } else {
@@ -525,9 +521,8 @@ __global__ __launch_bounds__(PX_THREADS) void d2d_fir_px_kernel(PxArgs a) {
                     Fast f;
                     fast_begin(f, pw, 1);
                     chain(0u, cbit, accA, [&](auto kc) { fast_hook(f, C1{}, accB, kc); });
-                    if (have_prev) finish_channel(f, pw, C1{}, accB);
-                    keep(accB);
                     if (have_prev) {
+                        finish_channel(f, pw, C1{}, accB);
                         wave_sync2();
                         store_tile(tile_nl0(pw));
                         wave_sync2();
@@ -538,7 +533,6 @@ __global__ __launch_bounds__(PX_THREADS) void d2d_fir_px_kernel(PxArgs a) {
                     fast_begin(f, t, 0);
                     chain(1u, cbit, accB, [&](auto kc) { fast_hook(f, C0{}, accA, kc); });
                     finish_channel(f, t, C0{}, accA);
-                    keep(accA);
                 }
                 have_prev = true; pw = t;
             }
@@ -548,7 +542,6 @@ __global__ __launch_bounds__(PX_THREADS) void d2d_fir_px_kernel(PxArgs a) {
                 fast_begin(f, pw, 1);
                 static_for<0, NJ>([&](auto jc) { fast_job(f, C1{}, accB, jc); });
                 finish_channel(f, pw, C1{}, accB);
-                keep(accB);
                 wave_sync2();
                 store_tile(tile_nl0(pw));
             }

@@ -28,4 +28,3 @@ run dsd64_to_88k2_s24_stereo_level-3 --workload dsd64_to_88k2_s24_stereo --level
 run dsd64_to_352k8_s24_stereo_level-3 --workload dsd64_to_352k8_s24_stereo --level -3
 run dsd64_to_88k2_s24_stereo_taps32 --workload dsd64_to_88k2_s24_stereo --tap-bits 32
 run dsd128_to_88k2_s24_stereo_taps32 --workload dsd128_to_88k2_s24_stereo --tap-bits 32
-run dsd64_to_88k2_s24_6ch_taps32 --workload dsd64_to_88k2_s24_6ch --tap-bits 32                # (six channels: the two-pass route)
