@@ -902,7 +902,9 @@ __global__ __launch_bounds__(D2D_MX_THREADS) void d2d_fir_mx_kernel(Mfma2Args m)
                         if (!(dbg & 3) && fast_failed(f, tp)) { int32_t o[NS]; redo_acc(accB, tp, CHP{}, o); put_samples(chp, o); } else merge_extremes(f, CHP{});
                     }
                 }
-                hold_acc(accB);
+                // (the scratch flavour's region tails run no inline-asm instruction, and its next epilogue starts a whole staging phase later; holding
+                // the sets there cost <8, 688, 2, 0, 0> thirty spilled registers and config 5 a fifth of its stage A)
+                if constexpr (!SCR) hold_acc(accB);
             }
             // ---- region B ----
             stamp(2);
@@ -934,7 +936,7 @@ __global__ __launch_bounds__(D2D_MX_THREADS) void d2d_fir_mx_kernel(Mfma2Args m)
                 else {
                     if (!(dbg & 3) && fast_failed(f, wt)) { int32_t o[NS]; redo_acc(accA, wt, CHA{}, o); put_samples(CHA::value, o); } else merge_extremes(f, CHA{});
                 }
-                hold_acc(accA);
+                if constexpr (!SCR) hold_acc(accA);
             }
             });
             have_prev = true; pw = wt;
