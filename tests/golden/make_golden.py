@@ -43,6 +43,9 @@ CASES = [
     ("dsd64_f32_192k_dff", dict(dsd_rate=1, output_rate=192000, channels=2, fmt="I", endianness="M", block_size=1, filter="E", bit_depth=32, dither="F", seed=8, level_db=-3.0)),
     ("dsd128_s16_384k_mono", dict(dsd_rate=2, output_rate=384000, channels=1, fmt="P", endianness="L", block_size=4096, filter="E", bit_depth=16, dither="R", seed=9)),
     ("dsd128_s24_96k_ns_3ch", dict(dsd_rate=2, output_rate=96000, channels=3, fmt="P", endianness="M", block_size=512, filter="E", bit_depth=24, dither="N", seed=10)),
+    # round 4: a 5.1 stream (whole frames from one wave on the GPU) and the 32-bit tap grid (one pass on the GPU)
+    ("dsd64_s24_88k2_6ch", dict(dsd_rate=1, output_rate=88200, channels=6, fmt="P", endianness="L", block_size=4096, filter="E", bit_depth=24, dither="T", seed=11)),
+    ("dsd64_s16_88k2_taps32", dict(dsd_rate=1, output_rate=88200, channels=2, fmt="P", endianness="L", block_size=4096, filter="E", bit_depth=16, dither="R", seed=12, level_db=-2.0, tap_bits=32)),
     ("dsd256_s24_1411k2", dict(dsd_rate=4, output_rate=1411200, channels=2, fmt="P", endianness="M", block_size=512, filter="E", bit_depth=24, dither="X", seed=0)),
 ]
 
