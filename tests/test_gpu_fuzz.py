@@ -64,3 +64,34 @@ def test_random_configuration(engine_lib, oracle_mod, seed):
         got = np.concatenate([e.translate(b)[0] for b in bufs])
         assert np.array_equal(got, want), (kernel, kw)
         assert e.peak_dbfs() == o.peak_dbfs() or (np.isinf(e.peak_dbfs()) and np.isinf(o.peak_dbfs()))
+
+
+@pytest.mark.parametrize("seed", [2000 + i for i in range(24 + _EXTRA // 10)])
+def test_random_long_streams(engine_lib, oracle_mod, seed):
+    """the third family: streams long enough for every wave of the pipelined kernels to walk several tiles in its fixed-order loop (the first
+    two families' calls are a tile or two: careful tiles mostly) -- mono pairs, stereo, 5.1 whole frames, the one-pass 32-bit taps, the composed
+    48k kernels, planar power-of-two blocks or byte-interleaved, two or three ragged calls"""
+    rng = np.random.default_rng(seed)
+    dsd_rate, out_rate = [(1, 88200), (2, 88200), (4, 176400), (4, 88200), (1, 352800), (1, 176400), (1, 96000), (1, 192000), (2, 384000)][rng.integers(9)]
+    channels = int(rng.choice([1, 2, 2, 6]))
+    fmt = str(rng.choice(["P", "P", "I"]))
+    kw = dict(dsd_rate=dsd_rate, output_rate=out_rate, channels=channels, fmt=fmt, endianness=str(rng.choice(["L", "M"])), block_size=4096 if fmt == "P" else 1,
+              filter="E", bit_depth=int(rng.choice([16, 24, 24, 32])), dither=str(rng.choice(["T", "R", "X"])), seed=int(rng.integers(1 << 30)),
+              level_db=float(rng.choice([0.0, 0.0, 0.0, -3.0])))
+    if out_rate % 44100 == 0 and rng.integers(4) == 0:
+        kw["tap_bits"] = 32
+    total = 4096 * int(rng.integers(40, 150)) * dsd_rate
+    c1 = 4096 * int(rng.integers(1, 30)) * dsd_rate
+    cuts = [0, c1, total - (0 if fmt == "P" else int(rng.integers(0, 500))), total]
+    chans = [random_bytes(total, 77 * seed + c) if c % 2 else np.where(np.arange(total) % 9 < 5, 0xA5, 0x5A).astype(np.uint8) ^ random_bytes(total, 78 * seed + c) // 64
+             for c in range(channels)]
+    o = oracle_mod.Oracle(**kw)
+    e = engine_lib.Engine(kernel=2, **kw)
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        if b <= a:
+            continue
+        buf = pack_layout([ch[a:b] for ch in chans], fmt, kw["block_size"])
+        g, gf = e.translate(buf)
+        w, wf = o.translate(buf)
+        assert gf == wf and np.array_equal(g, w[:wf * o.frame_bytes]), (kw, a, b, e.kernel_name())
+    assert [e.peak(c) for c in range(channels)] == [o.peak(c) for c in range(channels)]
