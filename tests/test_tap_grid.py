@@ -266,3 +266,29 @@ def test_32_bit_taps_in_one_pass(engine_lib, oracle_mod, dsd_rate, bits, dither,
     assert e.kernel_name() == "d2d_fir_mx_kernel<%s, %d, %d, 1, 7>" % (shape, kind, {16: 2, 20: 3, 24: 3, 32: 4}[bits])
     assert not e2.kernel_name().endswith(", 7>")
     assert [e.peak(c) for c in range(2)] == [o.peak(c) for c in range(2)] == [e2.peak(c) for c in range(2)]
+
+
+@pytest.mark.gpu
+def test_one_pass_32_bit_tap_engine_exports_and_adopts_its_table(engine_lib, oracle_mod):
+    """the one-pass route holds ONE table (blob variant 8, scale S + 8): it can be exported and adopted by another engine of the same
+    conversion (bench.py's table broadcast), a 24-bit engine refuses it and vice versa; the two-pass route still has no blob"""
+    import torch
+    kw = dict(dsd_rate=1, output_rate=88200, channels=2, fmt="P", endianness="L", block_size=4096, filter="E", bit_depth=24, dither="T", seed=4)
+    a = engine_lib.Engine(kernel=2, tap_bits=32, **kw)
+    b = engine_lib.Engine(kernel=2, tap_bits=32, **kw)
+    c24 = engine_lib.Engine(kernel=2, **kw)
+    nb = a.tables_bytes()
+    blob = torch.zeros(nb, dtype=torch.uint8, device="cuda")
+    a.tables_export_device(blob.data_ptr(), nb)
+    torch.cuda.synchronize()
+    b.tables_import_device(blob.data_ptr(), nb)
+    buf = pack_layout([synth("sine", 4096 * 12, seed=1), synth("pink", 4096 * 12, seed=2, amp=0.098)], "P", 4096)
+    g, gf = b.translate(buf)
+    w, wf = oracle_mod.Oracle(tap_bits=32, **kw).translate(buf)
+    assert gf == wf and np.array_equal(g, w[:wf * 6]) and b.kernel_name().endswith(", 1, 7>")
+    if c24.tables_bytes() <= nb:
+        with pytest.raises(engine_lib.D2DError):
+            c24.tables_import_device(blob.data_ptr(), c24.tables_bytes())
+    two = engine_lib.Engine(kernel=2, tap_bits=32, debug=engine_lib.DBG_TAPS32_2PASS, **kw)
+    with pytest.raises(engine_lib.D2DError):
+        two.tables_export_device(blob.data_ptr(), nb)
