@@ -44,6 +44,8 @@ WORKLOADS = {
     "dsd64_to_88k2_s24_stereo": (1, 88200, 24, "T", 2, 32 / 8 + 3),
     "dsd64_to_88k2_s24_stereo_nodither": (1, 88200, 24, "X", 2, 32 / 8 + 3),
     "dsd64_to_88k2_s24_6ch": (1, 88200, 24, "T", 6, 32 / 8 + 3),          # a 5.1 stream, planar
+    "dsd64_to_88k2_s24_4ch": (1, 88200, 24, "T", 4, 32 / 8 + 3),          # a quad stream, planar
+    "dsd512_to_352k8_s24_8ch": (8, 352800, 24, "T", 8, 64 / 8 + 3),       # DSD512's one documented output rate (main.rs:90), eight channels byte-interleaved MSB-first
     "dsd64_to_88k2_s24_mono": (1, 88200, 24, "T", 1, 32 / 8 + 3),         # six of the reference's eleven fixtures are mono (test/1kHz_mono_p.dsf ...)
     "dsd64_to_352k8_s24_mono": (1, 352800, 24, "T", 1, 8 / 8 + 3),        # run_all_tests.sh:8 / build_test_mono.sh convert mono at +4 dB (bench.py --level 4)
     "dsd64_to_88k2_s16_stereo": (1, 88200, 16, "T", 2, 32 / 8 + 2),
@@ -66,7 +68,7 @@ WORKLOADS = {
     "dsd64_to_352k8_s24_stereo_dff": (1, 352800, 24, "T", 2, 8 / 8 + 3),  # ... at the CLI's default output rate
     "dsd64_to_96k_s24_stereo_dff": (1, 96000, 24, "T", 2, 29.4 / 8 + 3),  # ... into the 48k cascade
 }
-LAYOUTS = {"dsd512_to_96k_s24_8ch": ("I", "M", 1), "dsd64_to_88k2_s24_stereo_dff": ("I", "M", 1),
+LAYOUTS = {"dsd512_to_96k_s24_8ch": ("I", "M", 1), "dsd512_to_352k8_s24_8ch": ("I", "M", 1), "dsd64_to_88k2_s24_stereo_dff": ("I", "M", 1),
            "dsd64_to_352k8_s24_stereo_dff": ("I", "M", 1), "dsd64_to_96k_s24_stereo_dff": ("I", "M", 1)}                # default: planar 4096 LSB-first
 
 

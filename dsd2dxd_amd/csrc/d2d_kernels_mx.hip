@@ -1110,16 +1110,18 @@ __global__ __launch_bounds__(D2D_MX_THREADS) void d2d_fir_mx_kernel(Mfma2Args m)
 #define D2D_MX_GSHAPES_5(X) X(16, 2192)
 #endif
 #define D2D_MX_GSHAPES(X) D2D_MX_GSHAPES_0(X) D2D_MX_GSHAPES_1(X) D2D_MX_GSHAPES_2(X) D2D_MX_GSHAPES_3(X) D2D_MX_GSHAPES_4(X) D2D_MX_GSHAPES_5(X)
-// several channel pairs per wave (planar multichannel frames; NPR = 3: a 5.1 stream), one object per shape too (Makefile: -DD2D_MX_MPART=0..2, D2D_MX_PART=99)
-#define D2D_MX_MSHAPES_0(X) X(4, 560)
+// several channel pairs per wave (planar multichannel frames: NPR = 2 quad, 3 a 5.1 stream, 4 a 7.1 / eight-channel stream), one object per (shape, pairs)
+// (Makefile: -DD2D_MX_MPART=n, D2D_MX_PART=99): X(object, MB, taps, pairs)
 #ifdef D2D_MX_DEV
-#define D2D_MX_MSHAPES_1(X)
-#define D2D_MX_MSHAPES_2(X)
+#define D2D_MX_MLIST(X) X(0, 4, 560, 3)
 #else
-#define D2D_MX_MSHAPES_1(X) X(8, 1104)
-#define D2D_MX_MSHAPES_2(X) X(16, 2192)
+#define D2D_MX_MLIST(X) X(0, 4, 560, 3) X(1, 8, 1104, 3) X(2, 16, 2192, 3) X(3, 4, 560, 2) X(4, 4, 560, 4) X(5, 8, 1104, 2) X(6, 8, 1104, 4)
 #endif
-#define D2D_MX_MSHAPES(X) D2D_MX_MSHAPES_0(X) D2D_MX_MSHAPES_1(X) D2D_MX_MSHAPES_2(X)
+template <int N> struct MxPairsPart;
+#define X(n, mb, nt, npr) template <> struct MxPairsPart<n> { static constexpr int MBv = mb, NTv = nt, NPRv = npr; }; \
+                          hipError_t launch_fir_mx_mp##n(Mfma2Args& m, int MB, int NT, uint32_t max_nout, uint32_t nrows, hipStream_t s);
+D2D_MX_MLIST(X)
+#undef X
 // the one-pass form of the 32-bit tap grid (seven digits, four phases per group; stereo frames through the f64 requantiser): one object (Makefile: -DD2D_MX_WPART=0, D2D_MX_PART=99)
 #define D2D_MX_WSHAPES_0(X) X(4, 560)
 #ifdef D2D_MX_DEV
@@ -1130,9 +1132,6 @@ __global__ __launch_bounds__(D2D_MX_THREADS) void d2d_fir_mx_kernel(Mfma2Args m)
 #define D2D_MX_WSHAPES(X) D2D_MX_WSHAPES_0(X) D2D_MX_WSHAPES_1(X)
 hipError_t launch_fir_mx_wide0(Mfma2Args& m, int MB, int NT, uint32_t max_nout, uint32_t nrows, hipStream_t s);
 hipError_t launch_fir_mx_wide1(Mfma2Args& m, int MB, int NT, uint32_t max_nout, uint32_t nrows, hipStream_t s);
-hipError_t launch_fir_mx_mp0(Mfma2Args& m, int MB, int NT, uint32_t max_nout, uint32_t nrows, hipStream_t s);
-hipError_t launch_fir_mx_mp1(Mfma2Args& m, int MB, int NT, uint32_t max_nout, uint32_t nrows, hipStream_t s);
-hipError_t launch_fir_mx_mp2(Mfma2Args& m, int MB, int NT, uint32_t max_nout, uint32_t nrows, hipStream_t s);
 #define D2D_MX_DECL(n) hipError_t launch_fir_mx_part##n(Mfma2Args& m, int MB, int NT, uint32_t max_nout, uint32_t nrows, hipStream_t s); \
                        hipError_t launch_fir_mx_gain##n(Mfma2Args& m, int MB, int NT, uint32_t max_nout, uint32_t nrows, hipStream_t s);
 D2D_MX_DECL(0) D2D_MX_DECL(1) D2D_MX_DECL(2) D2D_MX_DECL(3) D2D_MX_DECL(4) D2D_MX_DECL(5) D2D_MX_DECL(6) D2D_MX_DECL(7)
@@ -1145,9 +1144,8 @@ bool mx_supported(int MB, int NT) {
     return false;
 }
 bool mx_pairs_supported(int MB, int NT, int npairs) {
-    if (npairs != 3) return false;
-#define X(mb, nt) if (MB == mb && NT == nt) return true;
-    D2D_MX_MSHAPES(X)
+#define X(n, mb, nt, npr) if (MB == mb && NT == nt && npairs == npr) return true;
+    D2D_MX_MLIST(X)
 #undef X
     return false;
 }
@@ -1357,31 +1355,22 @@ hipError_t launch_fir_mx_wide1(Mfma2Args& m, int MB, int NT, uint32_t max_nout, 
 }
 #endif
 #elif defined(D2D_MX_MPART)
-#define D2D_MX_MLAUNCH(mb, nt)                                                                                     \
-    if (MB == mb && NT == nt && m.npairs == 3) {                                                                   \
-        constexpr int G = mx_g(mb);                                                                                \
-        if (m.f.epi.sample_bytes == 4) return launch_mx_t<mb, nt, G, 0, 4, 3>(m, max_nout, nrows, s);               \
-        if (m.f.epi.sample_bytes == 2) {                                                                           \
-            if (m.dkind == 1) return launch_mx_t<mb, nt, G, 1, 2, 3>(m, max_nout, nrows, s);                        \
-            if (m.dkind == 2) return launch_mx_t<mb, nt, G, 2, 2, 3>(m, max_nout, nrows, s);                        \
-            return launch_mx_t<mb, nt, G, 0, 2, 3>(m, max_nout, nrows, s);                                          \
-        }                                                                                                          \
-        if (m.dkind == 1) return launch_mx_t<mb, nt, G, 1, 3, 3>(m, max_nout, nrows, s);                            \
-        if (m.dkind == 2) return launch_mx_t<mb, nt, G, 2, 3, 3>(m, max_nout, nrows, s);                            \
-        return launch_mx_t<mb, nt, G, 0, 3, 3>(m, max_nout, nrows, s);                                              \
+#define D2D_MX_CAT2(a, b) a##b
+#define D2D_MX_CAT(a, b) D2D_MX_CAT2(a, b)
+hipError_t D2D_MX_CAT(launch_fir_mx_mp, D2D_MX_MPART)(Mfma2Args& m, int MB, int NT, uint32_t max_nout, uint32_t nrows, hipStream_t s) {
+    using P = MxPairsPart<D2D_MX_MPART>;
+    constexpr int mb = P::MBv, nt = P::NTv, npr = P::NPRv, G = mx_g(mb);
+    if (MB != mb || NT != nt || (int)m.npairs != npr) return hipErrorInvalidValue;
+    if (m.f.epi.sample_bytes == 4) return launch_mx_t<mb, nt, G, 0, 4, npr>(m, max_nout, nrows, s);
+    if (m.f.epi.sample_bytes == 2) {
+        if (m.dkind == 1) return launch_mx_t<mb, nt, G, 1, 2, npr>(m, max_nout, nrows, s);
+        if (m.dkind == 2) return launch_mx_t<mb, nt, G, 2, 2, npr>(m, max_nout, nrows, s);
+        return launch_mx_t<mb, nt, G, 0, 2, npr>(m, max_nout, nrows, s);
     }
-#define D2D_MX_MPART_FN(n, shapes)                                                                                 \
-    hipError_t launch_fir_mx_mp##n(Mfma2Args& m, int MB, int NT, uint32_t max_nout, uint32_t nrows, hipStream_t s) { \
-        shapes(D2D_MX_MLAUNCH)                                                                                     \
-        return hipErrorInvalidValue;                                                                               \
-    }
-#if D2D_MX_MPART == 0
-D2D_MX_MPART_FN(0, D2D_MX_MSHAPES_0)
-#elif D2D_MX_MPART == 1
-D2D_MX_MPART_FN(1, D2D_MX_MSHAPES_1)
-#else
-D2D_MX_MPART_FN(2, D2D_MX_MSHAPES_2)
-#endif
+    if (m.dkind == 1) return launch_mx_t<mb, nt, G, 1, 3, npr>(m, max_nout, nrows, s);
+    if (m.dkind == 2) return launch_mx_t<mb, nt, G, 2, 3, npr>(m, max_nout, nrows, s);
+    return launch_mx_t<mb, nt, G, 0, 3, npr>(m, max_nout, nrows, s);
+}
 #elif defined(D2D_MX_GPART)
 #define D2D_MX_GLAUNCH(mb, nt)                                                                                     \
     if (MB == mb && NT == nt) {                                                                                    \
@@ -1430,10 +1419,9 @@ hipError_t launch_fir_mx(Mfma2Args& m, int MB, int NT, uint32_t max_nout, uint32
         return hipErrorInvalidValue;
     }
     if (m.npairs > 1) {
-        D2D_MX_ROUTE(D2D_MX_MSHAPES_0, launch_fir_mx_mp0)
-#ifndef D2D_MX_DEV
-        D2D_MX_ROUTE(D2D_MX_MSHAPES_1, launch_fir_mx_mp1) D2D_MX_ROUTE(D2D_MX_MSHAPES_2, launch_fir_mx_mp2)
-#endif
+#define Y(n, mb, nt, npr) if (MB == mb && NT == nt && (int)m.npairs == npr) return launch_fir_mx_mp##n(m, MB, NT, max_nout, nrows, s);
+        D2D_MX_MLIST(Y)
+#undef Y
         return hipErrorInvalidValue;
     }
     if (m.gainq && !m.f.to_scratch) {

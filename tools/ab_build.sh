@@ -14,11 +14,11 @@ ROOT=$(cd "$(dirname "$0")/.." && pwd); CS=$ROOT/dsd2dxd_amd/csrc; O=$ROOT/ab/$N
 mkdir -p $O
 FL="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wall -Wno-unused-function -Wno-unused-value -Wno-unused-result -I$CS -I$ROOT/filters"
 PX="$(echo $CS/d2d_kernels_px{0,1,2,3,4,5,6,7}.o)"
-K=$CS/d2d_kernels.o; M3=$CS/d2d_kernels_mfma3.o; M3B=$CS/d2d_kernels_mfma3b.o; MX="$CS/d2d_kernels_mx.o $(echo $CS/d2d_kernels_mx{1,2,3,4,5,6,7}.o)"; MXG="$(echo $CS/d2d_kernels_mxg{0,1,2,3,4,5}.o)"; MXM="$(echo $CS/d2d_kernels_mxm{0,1,2}.o)"
+K=$CS/d2d_kernels.o; M3=$CS/d2d_kernels_mfma3.o; M3B=$CS/d2d_kernels_mfma3b.o; MX="$CS/d2d_kernels_mx.o $(echo $CS/d2d_kernels_mx{1,2,3,4,5,6,7}.o)"; MXG="$(echo $CS/d2d_kernels_mxg{0,1,2,3,4,5}.o)"; MXM="$(echo $CS/d2d_kernels_mxm{0,1,2,3,4,5,6}.o)"
 case $UNIT in
   mx)      /opt/rocm/bin/hipcc $FL -DD2D_MX_DEV=1 "$@" -c $CS/d2d_kernels_mx.hip -o $O/d2d_kernels_mx.o; MX=$O/d2d_kernels_mx.o
            /opt/rocm/bin/hipcc $FL -DD2D_MX_DEV=1 -DD2D_MX_PART=99 -DD2D_MX_GPART=0 "$@" -c $CS/d2d_kernels_mx.hip -o $O/d2d_kernels_mxg0.o; MXG="$O/d2d_kernels_mxg0.o $(echo $CS/d2d_kernels_mxg{1,2,3,4,5}.o)" ;;
-  mxm)     /opt/rocm/bin/hipcc $FL -DD2D_MX_PART=99 -DD2D_MX_MPART=0 "$@" -c $CS/d2d_kernels_mx.hip -o $O/d2d_kernels_mxm0.o; MXM="$O/d2d_kernels_mxm0.o $(echo $CS/d2d_kernels_mxm{1,2}.o)" ;;
+  mxm)     /opt/rocm/bin/hipcc $FL -DD2D_MX_PART=99 -DD2D_MX_MPART=0 "$@" -c $CS/d2d_kernels_mx.hip -o $O/d2d_kernels_mxm0.o; MXM="$O/d2d_kernels_mxm0.o $(echo $CS/d2d_kernels_mxm{1,2,3,4,5,6}.o)" ;;
   mfma3)   /opt/rocm/bin/hipcc $FL "$@" -c $CS/d2d_kernels_mfma3.hip -o $O/d2d_kernels_mfma3.o & /opt/rocm/bin/hipcc $FL -DD2D_M3_PART=1 "$@" -c $CS/d2d_kernels_mfma3.hip -o $O/d2d_kernels_mfma3b.o; wait
            M3=$O/d2d_kernels_mfma3.o; M3B=$O/d2d_kernels_mfma3b.o ;;
   px)      for i in 0 1 2 3 4 5 6 7; do /opt/rocm/bin/hipcc $FL -DD2D_PX_PART=$i "$@" -c $CS/d2d_kernels_px.hip -o $O/d2d_kernels_px$i.o & done; wait

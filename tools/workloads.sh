@@ -19,6 +19,8 @@ run dsd512_to_96k_s24_8ch_rank0of8 --workload dsd512_to_96k_s24_8ch --distinct 8
 run dsd512_to_96k_s24_8ch_rank0of4 --workload dsd512_to_96k_s24_8ch --distinct 8 --shard channels --as-rank 0/4     # ... or a pair
 run dsd64_to_88k2_s24_6ch --workload dsd64_to_88k2_s24_6ch
 run dsd64_to_96k_s24_6ch --workload dsd64_to_96k_s24_6ch
+run dsd64_to_88k2_s24_4ch --workload dsd64_to_88k2_s24_4ch
+run dsd512_to_352k8_s24_8ch --workload dsd512_to_352k8_s24_8ch --distinct 8      # eight channels byte-interleaved: the planar pre-pass, then whole frames from one wave (four pairs)
 run dsd64_to_88k2_s24_mono --workload dsd64_to_88k2_s24_mono --files 128
 run dsd64_to_352k8_s24_mono_level4 --workload dsd64_to_352k8_s24_mono --files 128 --level 4
 run dsd256_to_88k2_s24_stereo --workload dsd256_to_88k2_s24_stereo --seconds 30      # M = 128
